@@ -1,0 +1,133 @@
+"""Image encoder: ResNet-18/50 feature extractor (stock PyTorch-ROCm / MIOpen convolutions).
+
+Same contract as ``mano_train/networks/bases/resnet.py:99-248`` (reference):
+``forward(x) -> (features [B, 512|2048], {})`` where the features are the global
+mean over the last stage's spatial map (``x.mean(3).mean(2)``, ``resnet.py:179-185``;
+resolution-agnostic, the 7x7 avgpool is unused) and the state-dict key names are
+torchvision's (``conv1, bn1, layer{1..4}.{i}.conv{1,2,3}/bn{1,2,3}/downsample.{0,1}, fc``)
+so reference / ImageNet checkpoints load.  Per north_star the conv backbone is
+not a HIP-kernel target; it runs in channels_last so MIOpen picks its NHWC kernels.
+
+No network in this environment: ``pretrained=True`` loads
+``$OBMAN_RESNET_WEIGHTS/resnet{18,50}.pth`` if present and otherwise keeps the
+seeded default init (a warning is printed once).
+"""
+import os
+import warnings
+
+import torch
+from torch import nn
+
+__all__ = ["ResNet", "resnet18", "resnet50"]
+
+
+def _conv(cin, cout, k, stride=1):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(cin, planes, 3, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv(planes, planes, 3)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + skip)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(cin, planes, 1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + skip)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, depths, num_classes=1000, features=True):
+        super().__init__()
+        self.features = features
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        width = 64
+        stages = []
+        for s, (planes, n) in enumerate(zip((64, 128, 256, 512), depths)):
+            blocks = []
+            for i in range(n):
+                stride = 2 if (i == 0 and s > 0) else 1
+                down = None
+                if stride != 1 or width != planes * block.expansion:
+                    down = nn.Sequential(
+                        nn.Conv2d(width, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                        nn.BatchNorm2d(planes * block.expansion),
+                    )
+                blocks.append(block(width, planes, stride, down))
+                width = planes * block.expansion
+            stages.append(nn.Sequential(*blocks))
+        self.layer1, self.layer2, self.layer3, self.layer4 = stages
+        # never reached with features=True (resnet.py:184-186) but part of the checkpoint layout
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = x.mean(3).mean(2)
+        x = x.view(x.size(0), -1)
+        if self.features:
+            return x, {}
+        return self.fc(x)
+
+
+def _maybe_pretrained(model, name, pretrained):
+    if not pretrained:
+        return model
+    root = os.environ.get("OBMAN_RESNET_WEIGHTS", "")
+    path = os.path.join(root, name + ".pth")
+    if root and os.path.exists(path):
+        model.load_state_dict(torch.load(path, map_location="cpu"))
+    else:
+        warnings.warn(
+            "%s: no ImageNet weights available offline (set OBMAN_RESNET_WEIGHTS); using seeded random init" % name
+        )
+    return model
+
+
+def resnet18(pretrained=False, **kw):
+    return _maybe_pretrained(ResNet(BasicBlock, (2, 2, 2, 2), **kw), "resnet18", pretrained)
+
+
+def resnet50(pretrained=False, **kw):
+    return _maybe_pretrained(ResNet(Bottleneck, (3, 4, 6, 3), **kw), "resnet50", pretrained)

@@ -1,0 +1,49 @@
+"""Oracle: pairwise squared distances, bidirectional min / Chamfer.
+
+Follows ``mano_train/networks/branches/atlasutils.py:11-39`` (ChamferLoss) and
+``contactloss.py:60-79`` (batch_pairwise_dist), incl. the materialised N x M
+matrix and the expanded form |x|^2 + |y|^2 - 2 x.y, so it costs what the
+reference costs.  ``pairmin_direct`` is the direct-difference form the HIP
+kernel evaluates (exactly rounded differences, no cancellation).
+"""
+import torch
+
+
+def batch_pairwise_dist(x, y):
+    """x [B,Nx,3], y [B,Ny,3] -> P [B,Nx,Ny] squared distances, expanded form (atlasutils.py:20-39)."""
+    gram_x = torch.bmm(x, x.transpose(2, 1))
+    gram_y = torch.bmm(y, y.transpose(2, 1))
+    cross = torch.bmm(x, y.transpose(2, 1))
+    sq_x = torch.diagonal(gram_x, dim1=1, dim2=2)  # |x_i|^2  [B,Nx]
+    sq_y = torch.diagonal(gram_y, dim1=1, dim2=2)  # |y_j|^2  [B,Ny]
+    return sq_x.unsqueeze(2) + sq_y.unsqueeze(1) - 2 * cross
+
+
+def chamfer_loss(preds, gts):
+    """ChamferLoss.forward (atlasutils.py:11-18): P = dist(gts, preds);
+    loss_1[b] = mean_j min_i P ; loss_2[b] = mean_i min_j P."""
+    P = batch_pairwise_dist(gts, preds)
+    loss_1 = P.min(1)[0].mean(1)
+    loss_2 = P.min(2)[0].mean(1)
+    return loss_1, loss_2
+
+
+def pairwise_direct(x, y):
+    """Direct-difference squared distances [B,Nx,Ny], accumulation order of the HIP kernel:
+    d = fma(dz,dz, fma(dy,dy, dx*dx)) (``csrc/pairmin.hip``)."""
+    d = x.unsqueeze(2) - y.unsqueeze(1)
+    dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+    return dz * dz + (dy * dy + dx * dx)
+
+
+def pairmin_direct(x, y):
+    """-> (min_j d[b,i,j], argmin_j, min_i d[b,i,j], argmin_i) with first-index tie-break."""
+    P = pairwise_direct(x, y)
+    mx, ix = P.min(2)
+    my, iy = P.min(1)
+    return mx, ix, my, iy
+
+
+def chamfer_direct(preds, gts):
+    P = pairwise_direct(gts, preds)
+    return P.min(1)[0].mean(1), P.min(2)[0].mean(1)

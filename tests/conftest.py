@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests must FAIL (not skip) on a GPU box whose HIP library is missing; on a
+    CPU-only box they are deselected by ``-m "not gpu"`` and skipped if selected anyway."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    from tests.golden.common import GOLDEN_DIR
+
+    def _load(name):
+        return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+    return _load
