@@ -1,0 +1,65 @@
+"""ctypes binding of the C-ABI in ``include/obman_hip.h`` (the drop-in boundary).
+
+There is NO fallback: if ``csrc/libobman_hip.so`` is missing or stale-incompatible the import of
+any op fails loudly with the build command.
+"""
+import ctypes
+import os
+
+from .build import LIB
+
+_c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); 'p' pointer, 'i' int, 'l' long, 'f' float
+_SIGNATURES = {
+    "obman_abi_version": (_c_int, ""),
+    "obman_pairmin_ws_bytes": (_c_long, "iii"),
+    "obman_pairmin_fwd": (_c_int, "ppiiipppp" "plp"),
+    "obman_pairmin_bwd": (_c_int, "ppiiipppppp" "p"),
+    "obman_chamfer_fwd": (_c_int, "ppiiipppppp" "plp"),
+    "obman_chamfer_bwd": (_c_int, "ppiiipppppp" "p"),
+}
+_KIND = {"p": _c_void_p, "i": _c_int, "l": _c_long, "f": _c_float}
+_lib = None
+
+
+class ObmanHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise ObmanHipError(
+            "HIP kernel library %s not built - run `python -m obman_train_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU/PyTorch fallback." % LIB
+        )
+    handle = ctypes.CDLL(LIB)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = [_KIND[a] for a in args]
+    got = handle.obman_abi_version()
+    if got != ABI_VERSION:
+        raise ObmanHipError("libobman_hip.so ABI %d != expected %d - rebuild" % (got, ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        kind = "bad argument" if status < 0 else "hipError_t"
+        raise ObmanHipError("%s failed: %s %d" % (what, kind, status))
+
+
+def declared_symbols(header_path):
+    """Names of every ``obman_*`` function declared in the C header (used by the loader test)."""
+    import re
+
+    with open(header_path) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(obman_[a-z0-9_]+)\s*\(", text)))

@@ -1,0 +1,123 @@
+"""Host-side operators over the HIP C-ABI: thin ``torch.autograd.Function`` wrappers.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic of these ops runs
+in ``csrc/*.hip``.  Every op requires fp32 ROCm tensors and raises otherwise - no CPU path.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.ObmanHipError("%s must be a ROCm device tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check_pair(x, y):
+    if x.dim() != 3 or y.dim() != 3 or x.shape[2] != 3 or y.shape[2] != 3 or x.shape[0] != y.shape[0]:
+        raise ValueError("expected x [B,Nx,3], y [B,Ny,3]; got %s %s" % (tuple(x.shape), tuple(y.shape)))
+    if x.shape[1] == 0 or y.shape[1] == 0:
+        # same failure the reference hits in torch.min over an empty dimension
+        raise IndexError("min(): cannot reduce over an empty point set")
+
+
+def _workspace(B, nx, ny, device):
+    nbytes = _lib.lib().obman_pairmin_ws_bytes(B, nx, ny)
+    small, large = (nx, ny) if nx < ny else (ny, nx)
+    if large < 8192 or B * ((small + 1023) // 1024) >= 512:
+        return None, 0  # the launcher would not split: skip the allocation
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+class _PairMin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, want_x, want_y):
+        x, y = _dev(x, "x"), _dev(y, "y")
+        _check_pair(x, y)
+        B, nx, ny = x.shape[0], x.shape[1], y.shape[1]
+        o = dict(device=x.device)
+        min_x = torch.empty((B, nx), dtype=torch.float32, **o) if want_x else None
+        idx_x = torch.empty((B, nx), dtype=torch.int32, **o) if want_x else None
+        min_y = torch.empty((B, ny), dtype=torch.float32, **o) if want_y else None
+        idx_y = torch.empty((B, ny), dtype=torch.int32, **o) if want_y else None
+        ws, ws_bytes = _workspace(B, nx, ny, x.device)
+        _lib.check(_lib.lib().obman_pairmin_fwd(
+            x.data_ptr(), y.data_ptr(), B, nx, ny, _ptr(min_x), _ptr(idx_x), _ptr(min_y), _ptr(idx_y),
+            _ptr(ws), ws_bytes, _stream()), "obman_pairmin_fwd")
+        ctx.save_for_backward(x, y, idx_x, idx_y)
+        ctx.mark_non_differentiable(*[t for t in (idx_x, idx_y) if t is not None])
+        return min_x, idx_x, min_y, idx_y
+
+    @staticmethod
+    def backward(ctx, g_min_x, _gi, g_min_y, _gj):
+        x, y, idx_x, idx_y = ctx.saved_tensors
+        B, nx, ny = x.shape[0], x.shape[1], y.shape[1]
+        need_x, need_y = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_min_x = g_min_x.contiguous() if g_min_x is not None else None
+        g_min_y = g_min_y.contiguous() if g_min_y is not None else None
+        grad_x = torch.empty_like(x) if need_x else None
+        grad_y = torch.empty_like(y) if need_y else None
+        _lib.check(_lib.lib().obman_pairmin_bwd(
+            x.data_ptr(), y.data_ptr(), B, nx, ny, _ptr(idx_x), _ptr(idx_y), _ptr(g_min_x), _ptr(g_min_y),
+            _ptr(grad_x), _ptr(grad_y), _stream()), "obman_pairmin_bwd")
+        return grad_x, grad_y, None, None
+
+
+def pairmin(x, y, want_x=True, want_y=True):
+    """x [B,Nx,3], y [B,Ny,3] -> (min_x [B,Nx], idx_x int32, min_y [B,Ny], idx_y int32).
+
+    min_x[b,i] = min_j |x_i-y_j|^2 (squared, like the reference's batch_pairwise_dist + torch.min,
+    contactloss.py:164-166); a direction not wanted returns None."""
+    return _PairMin.apply(x, y, bool(want_x), bool(want_y))
+
+
+class _Chamfer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, gts):
+        preds, gts = _dev(preds, "preds"), _dev(gts, "gts")
+        _check_pair(preds, gts)
+        B, n_p, n_g = preds.shape[0], preds.shape[1], gts.shape[1]
+        o = dict(device=preds.device)
+        loss = torch.empty((2, B), dtype=torch.float32, **o)
+        mins = torch.empty((B, n_p + n_g), dtype=torch.float32, **o)
+        idx = torch.empty((B * (n_p + n_g),), dtype=torch.int32, **o)
+        min_pred, min_gt = mins.view(-1)[: B * n_p], mins.view(-1)[B * n_p:]
+        idx_pred, idx_gt = idx[: B * n_p], idx[B * n_p:]
+        ws, ws_bytes = _workspace(B, n_p, n_g, preds.device)
+        _lib.check(_lib.lib().obman_chamfer_fwd(
+            preds.data_ptr(), gts.data_ptr(), B, n_p, n_g, loss[0].data_ptr(), loss[1].data_ptr(),
+            min_pred.data_ptr(), idx_pred.data_ptr(), min_gt.data_ptr(), idx_gt.data_ptr(),
+            _ptr(ws), ws_bytes, _stream()), "obman_chamfer_fwd")
+        ctx.save_for_backward(preds, gts, idx)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        preds, gts, idx = ctx.saved_tensors
+        B, n_p, n_g = preds.shape[0], preds.shape[1], gts.shape[1]
+        idx_pred, idx_gt = idx[: B * n_p], idx[B * n_p:]
+        g1 = g1.contiguous() if g1 is not None else None
+        g2 = g2.contiguous() if g2 is not None else None
+        grad_p = torch.empty_like(preds) if ctx.needs_input_grad[0] else None
+        grad_g = torch.empty_like(gts) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.lib().obman_chamfer_bwd(
+            preds.data_ptr(), gts.data_ptr(), B, n_p, n_g, idx_pred.data_ptr(), idx_gt.data_ptr(),
+            _ptr(g1), _ptr(g2), _ptr(grad_p), _ptr(grad_g), _stream()), "obman_chamfer_bwd")
+        return grad_p, grad_g
+
+
+def chamfer(preds, gts):
+    """ChamferLoss.forward (atlasutils.py:11-18): -> (loss_1 [B] mean over preds of nearest-gt
+    squared distance, loss_2 [B] mean over gts of nearest-pred squared distance)."""
+    return _Chamfer.apply(preds, gts)

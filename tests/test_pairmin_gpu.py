@@ -1,0 +1,148 @@
+"""GPU parity: HIP pair-min / Chamfer (through the C-ABI) vs the CPU oracle and the reference's
+golden vectors.  Tolerances: minima rtol 2e-6 (direct form on both sides, fma vs mul+add rounding);
+loss scalars vs the reference 1e-4 rel (north_star); arg-mins compared tie-tolerantly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chamfer as ocham
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _rand(B, n, seed, offset=0.0, scale=40.0):
+    rng = np.random.RandomState(seed)
+    return T((rng.normal(0, scale, size=(B, n, 3)) + offset).astype(np.float32))
+
+
+def _check_dir(x, y, mn, idx, P=None):
+    P = ocham.pairwise_direct(x.double(), y.double()) if P is None else P
+    ref_min, _ = P.min(2)
+    np.testing.assert_allclose(mn.cpu().numpy(), ref_min.numpy(), rtol=2e-6, atol=1e-7)
+    picked = torch.gather(P, 2, idx.cpu().long().unsqueeze(2)).squeeze(2)
+    np.testing.assert_allclose(picked.numpy(), ref_min.numpy(), rtol=2e-6, atol=1e-7)  # argmin valid up to ties
+
+
+@pytest.mark.parametrize("B,nx,ny", [(1, 1, 1), (2, 5, 3), (3, 50, 37), (2, 642, 600), (4, 778, 642),
+                                     (1, 1030, 257), (2, 3, 2100)])
+def test_pairmin_matches_oracle(B, nx, ny):
+    from obman_train_amd import ops
+
+    x, y = _rand(B, nx, 1, offset=15.0), _rand(B, ny, 2, offset=-5.0)
+    mx, ix, my, iy = ops.pairmin(x.cuda(), y.cuda())
+    assert ix.dtype == torch.int32 and mx.shape == (B, nx) and my.shape == (B, ny)
+    _check_dir(x, y, mx, ix)
+    _check_dir(y, x, my, iy)
+    # one-directional calls (K3) agree bit-for-bit with the bidirectional launch
+    mx1, ix1, none_a, none_b = ops.pairmin(x.cuda(), y.cuda(), want_y=False)
+    assert none_a is None and none_b is None
+    assert torch.equal(mx1, mx) and torch.equal(ix1, ix)
+
+
+def test_pairmin_first_index_on_ties_and_self_distance():
+    from obman_train_amd import ops
+
+    x = _rand(2, 300, 3)
+    y = torch.cat([x, x], 1)  # every x_i appears twice in y: the first copy must win
+    mx, ix, my, iy = ops.pairmin(x.cuda(), y.cuda())
+    assert torch.all(mx == 0)
+    assert torch.equal(ix.cpu().long(), torch.arange(300).expand(2, 300))
+    assert torch.equal(iy.cpu().long(), torch.cat([torch.arange(300)] * 2).expand(2, 600))
+
+
+def test_pairmin_split_reference_path_is_identical():
+    """Few queries vs a long reference set takes the split + 64-bit atomicMin merge path."""
+    from obman_train_amd import ops
+
+    x, y = _rand(2, 600, 5), _rand(2, 20000, 6)
+    mx, ix, my, iy = ops.pairmin(x.cuda(), y.cuda())
+    _check_dir(x, y, mx, ix)
+    _check_dir(y, x, my, iy)
+    # run-to-run bitwise determinism of the merged result
+    mx2, ix2, _, _ = ops.pairmin(x.cuda(), y.cuda())
+    assert torch.equal(mx, mx2) and torch.equal(ix, ix2)
+
+
+def test_chamfer_matches_reference_golden(golden):
+    from obman_train_amd import ops
+
+    g = golden("chamfer")
+    preds = T(g["preds"]).cuda().requires_grad_()
+    gts = T(g["gts"]).cuda().requires_grad_()
+    l1, l2 = ops.chamfer(preds, gts)
+    np.testing.assert_allclose(l1.detach().cpu().numpy(), g["loss_1"], rtol=1e-4)
+    np.testing.assert_allclose(l2.detach().cpu().numpy(), g["loss_2"], rtol=1e-4)
+    torch.mean(l1 + l2).backward()
+    for got, want in ((preds.grad, g["grad_preds"]), (gts.grad, g["grad_gts"])):
+        err = np.abs(got.cpu().numpy() - want).max()
+        assert err <= 1e-4 * np.abs(want).max() + 1e-6, err
+
+
+@pytest.mark.parametrize("B,n_p,n_g", [(2, 42, 40), (3, 642, 600), (2, 1300, 77)])
+def test_chamfer_fwd_bwd_matches_oracle_autograd(B, n_p, n_g):
+    from obman_train_amd import ops
+
+    preds, gts = _rand(B, n_p, 7, offset=10.0), _rand(B, n_g, 8, offset=12.0)
+    w1, w2 = torch.rand(B) + 0.5, torch.rand(B) + 0.5
+    pc, gc = preds.cuda().requires_grad_(), gts.cuda().requires_grad_()
+    l1, l2 = ops.chamfer(pc, gc)
+    (l1 * w1.cuda()).sum().add((l2 * w2.cuda()).sum()).backward()
+    po, go = preds.double().requires_grad_(), gts.double().requires_grad_()
+    o1, o2 = ocham.chamfer_direct(po, go)
+    ((o1 * w1.double()).sum() + (o2 * w2.double()).sum()).backward()
+    np.testing.assert_allclose(l1.detach().cpu().numpy(), o1.detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(l2.detach().cpu().numpy(), o2.detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(pc.grad.cpu().numpy(), po.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gc.grad.cpu().numpy(), go.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_pairmin_general_backward_matches_oracle():
+    from obman_train_amd import ops
+
+    x, y = _rand(2, 130, 9), _rand(2, 75, 10)
+    wx, wy = torch.randn(2, 130), torch.randn(2, 75)
+    xc, yc = x.cuda().requires_grad_(), y.cuda().requires_grad_()
+    mx, _, my, _ = ops.pairmin(xc, yc)
+    ((mx * wx.cuda()).sum() + (my * wy.cuda()).sum()).backward()
+    xo, yo = x.double().requires_grad_(), y.double().requires_grad_()
+    ox, _, oy, _ = ocham.pairmin_direct(xo, yo)
+    ((ox * wx.double()).sum() + (oy * wy.double()).sum()).backward()
+    np.testing.assert_allclose(xc.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(yc.grad.cpu().numpy(), yo.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_chamfer_full_size_properties():
+    """BASELINE sizes (bs=64, 642 x 600, and a 25-patch 16 050-vertex cloud): size-independent
+    properties instead of an O(N*M) oracle - role swap symmetry, permutation invariance,
+    translation invariance of the direct form, zero self-distance."""
+    from obman_train_amd import ops
+
+    for B, n_p, n_g in ((64, 642, 600), (8, 16050, 600)):
+        p, g = _rand(B, n_p, 11, offset=30.0).cuda(), _rand(B, n_g, 12, offset=25.0).cuda()
+        l1, l2 = ops.chamfer(p, g)
+        s2, s1 = ops.chamfer(g, p)  # swapped roles
+        assert torch.equal(l1, s1) and torch.equal(l2, s2)
+        perm = torch.randperm(n_p).cuda()
+        q1, q2 = ops.chamfer(p[:, perm].contiguous(), g)
+        torch.testing.assert_close(q1, l1, rtol=1e-5, atol=0)
+        assert torch.equal(q2, l2)  # per-gt minima see the same set of distances
+        shift = torch.tensor([64.0, -32.0, 16.0]).cuda()  # exactly representable shifts
+        t1, t2 = ops.chamfer(p + shift, g + shift)
+        torch.testing.assert_close(t1, l1, rtol=1e-4, atol=0)
+        z1, z2 = ops.chamfer(p, p)
+        assert torch.all(z1 == 0) and torch.all(z2 == 0)
+
+
+def test_empty_and_degenerate_inputs():
+    from obman_train_amd import ops
+
+    x = torch.zeros(2, 0, 3).cuda()
+    y = torch.zeros(2, 5, 3).cuda()
+    with pytest.raises(IndexError):
+        ops.pairmin(x, y)
+    e = torch.zeros(0, 7, 3).cuda()
+    mx, ix, my, iy = ops.pairmin(e, e)
+    assert mx.shape == (0, 7)
+    with pytest.raises(TypeError):
+        ops.chamfer(y.double(), y.double())
