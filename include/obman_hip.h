@@ -58,6 +58,28 @@ int obman_chamfer_bwd(const float* preds, const float* gts, int B, int Np, int N
                       const int* idx_pred, const int* idx_gt, const float* g_loss_1, const float* g_loss_2,
                       float* grad_preds, float* grad_gts, obman_stream_t stream);
 
+/* ---- K7: MANO linear-blend skinning ------------------------------------------------------------
+ * Replaces the external manopth.ManoLayer.forward the reference calls at manobranch.py:92-105,
+ * 170-182 (algorithm: SURVEY App. B; MANO parity unpinned - manopth is not vendored).
+ * model_right / model_left: packed fp32 model blobs of obman_mano_model_floats() floats each (layout
+ * in csrc/mano_lbs.hip, built by obman_train_amd/mano_model.py).  side [B] int32: 0 -> right model,
+ * 1 -> left model (NULL = all right; replaces the boolean-mask split/re-assembly of
+ * manobranch.py:133-207).  pose [B, 3+ncomps] (use_pca) or [B,48]; betas [B,10] or NULL (zeros).
+ * center_idx in [-1,20] (-1 = no centring); verts [B,778,3] mm, joints [B,21,3] mm; state
+ * [B, OBMAN_MANO_STATE_FLOATS] is saved for the backward (NULL = inference only). */
+#define OBMAN_MANO_STATE_FLOATS 2768
+int obman_mano_model_floats(void);
+int obman_mano_state_floats(void);
+int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const int* side, const float* pose,
+                       const float* betas, int B, int ncomps, int use_pca, int center_idx, int root_palm,
+                       float* verts, float* joints, float* state, obman_stream_t stream);
+
+/* Backward: g_verts [B,778,3] / g_joints [B,21,3] (either NULL = zeros) -> g_pose [B,npose],
+ * g_betas [B,10] (NULL = not wanted).  Deterministic (fixed reduction trees, no atomics). */
+int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const int* side, const float* state,
+                       const float* g_verts, const float* g_joints, int B, int ncomps, int use_pca, int center_idx,
+                       int root_palm, float* g_pose, float* g_betas, obman_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,10 @@ _SIGNATURES = {
     "obman_pairmin_bwd": (_c_int, "ppiiipppppp" "p"),
     "obman_chamfer_fwd": (_c_int, "ppiiipppppp" "plp"),
     "obman_chamfer_bwd": (_c_int, "ppiiipppppp" "p"),
+    "obman_mano_model_floats": (_c_int, ""),
+    "obman_mano_state_floats": (_c_int, ""),
+    "obman_mano_lbs_fwd": (_c_int, "ppppp" "iiiii" "ppp" "p"),
+    "obman_mano_lbs_bwd": (_c_int, "pppppp" "iiiii" "pp" "p"),
 }
 _KIND = {"p": _c_void_p, "i": _c_int, "l": _c_long, "f": _c_float}
 _lib = None

@@ -121,3 +121,53 @@ def chamfer(preds, gts):
     """ChamferLoss.forward (atlasutils.py:11-18): -> (loss_1 [B] mean over preds of nearest-gt
     squared distance, loss_2 [B] mean over gts of nearest-pred squared distance)."""
     return _Chamfer.apply(preds, gts)
+
+
+class _ManoLBS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose, betas, blob_right, blob_left, side, ncomps, use_pca, center_idx, root_palm):
+        pose = _dev(pose, "pose")
+        B = pose.shape[0]
+        npose = 3 + (ncomps if use_pca else 45)
+        if pose.dim() != 2 or pose.shape[1] != npose:
+            raise ValueError("pose must be [B,%d], got %s" % (npose, tuple(pose.shape)))
+        if betas is not None:
+            betas = _dev(betas, "betas")
+            if tuple(betas.shape) != (B, 10):
+                raise ValueError("betas must be [B,10]")
+        if side is not None:
+            side = _dev(side, "side", torch.int32)
+        o = dict(device=pose.device, dtype=torch.float32)
+        verts = torch.empty((B, 778, 3), **o)
+        joints = torch.empty((B, 21, 3), **o)
+        need_bwd = pose.requires_grad or (betas is not None and betas.requires_grad)
+        state = torch.empty((B, _lib.lib().obman_mano_state_floats()), **o) if need_bwd else None
+        cidx = -1 if center_idx is None else int(center_idx)
+        _lib.check(_lib.lib().obman_mano_lbs_fwd(
+            blob_right.data_ptr(), _ptr(blob_left), _ptr(side), pose.data_ptr(), _ptr(betas), B, int(ncomps),
+            int(bool(use_pca)), cidx, int(bool(root_palm)), verts.data_ptr(), joints.data_ptr(), _ptr(state),
+            _stream()), "obman_mano_lbs_fwd")
+        ctx.save_for_backward(state, blob_right, blob_left, side)
+        ctx.cfg = (B, int(ncomps), int(bool(use_pca)), cidx, int(bool(root_palm)), npose, betas is not None)
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, g_verts, g_joints):
+        state, blob_right, blob_left, side = ctx.saved_tensors
+        B, ncomps, use_pca, cidx, root_palm, npose, has_betas = ctx.cfg
+        g_verts = g_verts.contiguous() if g_verts is not None else None
+        g_joints = g_joints.contiguous() if g_joints is not None else None
+        o = dict(device=state.device, dtype=torch.float32)
+        g_pose = torch.empty((B, npose), **o)
+        g_betas = torch.empty((B, 10), **o) if (has_betas and ctx.needs_input_grad[1]) else None
+        _lib.check(_lib.lib().obman_mano_lbs_bwd(
+            blob_right.data_ptr(), _ptr(blob_left), _ptr(side), state.data_ptr(), _ptr(g_verts), _ptr(g_joints), B,
+            ncomps, use_pca, cidx, root_palm, g_pose.data_ptr(), _ptr(g_betas), _stream()), "obman_mano_lbs_bwd")
+        return g_pose, g_betas, None, None, None, None, None, None, None
+
+
+def mano_lbs(pose, betas, blob_right, blob_left=None, side=None, ncomps=30, use_pca=True, center_idx=0,
+             root_palm=False):
+    """ManoLayer.forward replacement: pose [B,3+ncomps], betas [B,10]|None -> (verts [B,778,3] mm,
+    joints [B,21,3] mm).  ``side`` int32 [B] picks right(0)/left(1) model blob per sample."""
+    return _ManoLBS.apply(pose, betas, blob_right, blob_left, side, ncomps, use_pca, center_idx, root_palm)

@@ -3,7 +3,10 @@
     python tools/kbench.py [chamfer|contains|mano|decoder|all]
 Prints one JSON line per measurement: algorithmic bytes/flops / average time."""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 
 import torch
 
