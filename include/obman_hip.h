@@ -80,6 +80,35 @@ int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const 
                        const float* g_verts, const float* g_joints, int B, int ncomps, int use_pca, int center_idx,
                        int root_palm, float* g_pose, float* g_betas, obman_stream_t stream);
 
+/* ---- K4: ray-parity inside test -----------------------------------------------------------------
+ * Replaces batch_mesh_contains_points (contactutils.py:62-159) + the obj_verts[:, faces] gather
+ * (contactloss.py:169).  points [B,P,3], verts [B,Nv,3] (object mesh vertices), faces [F,3] int32
+ * shared by the batch -> hits [B,P] int32 = number of triangles the fixed-direction ray crosses;
+ * exterior <=> hits even (contactutils.py:158).  No gradient (inputs are detached, contactloss.py:170). */
+int obman_mesh_contains_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
+                            int F, int* hits, obman_stream_t stream);
+
+/* ---- K5: contact / penetration loss tail ---------------------------------------------------------
+ * Replaces contactloss.py:173-308 (after pair-min and inside test).  hand [B,V,3], obj [B,N,3],
+ * idx21/mins21 [B,V] from obman_pairmin_fwd(hand,obj), hits [B,V] from obman_mesh_contains_fwd.
+ * zone_mode 0=all, 1=list (tips: ids in zone_ids[0:zone_offsets[1]]), 2=zones (per-zone arg-min of
+ * mins21; zone z = zone_ids[zone_offsets[z]:zone_offsets[z+1]]).  *_mode 0=dist_sq 1=dist 2=dist_tanh.
+ * Outputs: attr_mask/rep_mask [B,V] uint8, contact_points [B,V,3], partials [B,8] scratch,
+ * out [8] = {missed_loss, penetr_loss, max_penetr, mean_penetr, n_missed, n_penetr, 0, 0}. */
+int obman_contact_fwd(const float* hand, const float* obj, const int* idx21, const float* mins21, const int* hits,
+                      int B, int V, int N, const int* zone_ids, const int* zone_offsets, int n_zones, int zone_mode,
+                      int contact_mode, float contact_thresh, int collision_mode, float collision_thresh,
+                      unsigned char* attr_mask, unsigned char* rep_mask, float* contact_points, float* partials,
+                      float* out, obman_stream_t stream);
+
+/* Backward: g_missed / g_penetr are DEVICE scalars (upstream grads of out[0], out[1]; NULL = 0).
+ * target 0=all 1=obj 2=hand (contact_target, contactloss.py:176-203).  grad_hand [B,V,3],
+ * grad_obj [B,N,3] (either NULL = not wanted) are overwritten. */
+int obman_contact_bwd(const float* hand, const float* obj, const int* idx21, const unsigned char* attr_mask,
+                      const unsigned char* rep_mask, const float* out, const float* g_missed, const float* g_penetr,
+                      int B, int V, int N, int contact_mode, float contact_thresh, int collision_mode,
+                      float collision_thresh, int target, float* grad_hand, float* grad_obj, obman_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

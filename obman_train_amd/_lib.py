@@ -19,6 +19,9 @@ _SIGNATURES = {
     "obman_pairmin_bwd": (_c_int, "ppiiipppppp" "p"),
     "obman_chamfer_fwd": (_c_int, "ppiiipppppp" "plp"),
     "obman_chamfer_bwd": (_c_int, "ppiiipppppp" "p"),
+    "obman_mesh_contains_fwd": (_c_int, "ppp" "iiii" "pp"),
+    "obman_contact_fwd": (_c_int, "ppppp" "iii" "pp" "ii" "ifif" "ppppp" "p"),
+    "obman_contact_bwd": (_c_int, "pppppppp" "iii" "ifif" "i" "pp" "p"),
     "obman_mano_model_floats": (_c_int, ""),
     "obman_mano_state_floats": (_c_int, ""),
     "obman_mano_lbs_fwd": (_c_int, "ppppp" "iiiii" "ppp" "p"),

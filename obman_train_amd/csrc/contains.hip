@@ -1,0 +1,137 @@
+// K4 - ray-parity inside test: Moeller-Trumbore for every (point, triangle) pair, gfx950.
+//
+// Replaces batch_mesh_contains_points (contactutils.py:62-159): the reference materialises ~16
+// tensors of B x P x T elements (~8 GB live at bs 64).  Here each lane keeps PPT query points in
+// VGPRs; per-triangle constants (v0, e1, e2, pvec = dir x e2, 1/(det+1e-8) - NaN when |det| < tol so
+// every comparison fails exactly like the reference's `not parallel` factor) are computed ONCE per
+// block while staging the triangle chunk into LDS (4 x float4 per triangle, broadcast ds_read_b128),
+// then the hot loop is pure VALU (~31 lane-ops/pair).  Hit counts are integers: chunks of the
+// triangle list handled by different blocks merge with integer atomicAdd => deterministic.
+// Same constants/inequalities as the reference (App. C #8): fixed direction, tol 1e-7, strict
+// u>0,u<1,v>0,u+v<1, t>=tol, exterior <=> even hit count.
+// Bound: fp32 VALU; algorithmic bytes B*(P*12 + Nv*12 + F*12 + P*4).
+#include "common.h"
+#include "../../include/obman_hip.h"
+
+namespace {
+
+constexpr float RAY_X = 0.4395064455f, RAY_Y = 0.617598629942f, RAY_Z = 0.652231566745f;
+constexpr float TOL = 0.0000001f;
+constexpr int MC_THREADS = 256;
+constexpr int MC_TRI_TILE = 512;  // 4 float4 per triangle -> 32 KiB LDS
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+  return __fmaf_rn(az, bz, __fmaf_rn(ay, by, ax * bx));
+}
+
+template <int PPT>
+__global__ __launch_bounds__(MC_THREADS) void contains_kernel(const float* __restrict__ points,
+                                                              const float* __restrict__ verts,
+                                                              const int* __restrict__ faces, int P, int Nv, int F,
+                                                              int ptiles, int tchunk, int tsplit, int* __restrict__ hits) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int pt = blockIdx.x % ptiles, ts = blockIdx.x / ptiles;
+  const float* __restrict__ pb = points + (size_t)b * P * 3;
+  const float* __restrict__ vb = verts + (size_t)b * Nv * 3;
+  __shared__ float4 stri[MC_TRI_TILE * 4];
+
+  float ox[PPT], oy[PPT], oz[PPT];
+  int cnt[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int pi = pt * (MC_THREADS * PPT) + k * MC_THREADS + tid;
+    const int pc = pi < P ? pi : P - 1;
+    ox[k] = pb[(size_t)pc * 3];
+    oy[k] = pb[(size_t)pc * 3 + 1];
+    oz[k] = pb[(size_t)pc * 3 + 2];
+    cnt[k] = 0;
+  }
+  const int tbeg = ts * tchunk, tend = min(F, tbeg + tchunk);
+  for (int base = tbeg; base < tend; base += MC_TRI_TILE) {
+    const int n = min(MC_TRI_TILE, tend - base);
+    for (int t = tid; t < n; t += MC_THREADS) {
+      const int* f = faces + (size_t)(base + t) * 3;
+      const float* a = vb + (size_t)f[0] * 3;
+      const float* bb = vb + (size_t)f[1] * 3;
+      const float* c = vb + (size_t)f[2] * 3;
+      const float ax = a[0], ay = a[1], az = a[2];
+      const float e1x = bb[0] - ax, e1y = bb[1] - ay, e1z = bb[2] - az;
+      const float e2x = c[0] - ax, e2y = c[1] - ay, e2z = c[2] - az;
+      // pvec = dir x e2
+      const float px = RAY_Y * e2z - RAY_Z * e2y;
+      const float py = RAY_Z * e2x - RAY_X * e2z;
+      const float pz = RAY_X * e2y - RAY_Y * e2x;
+      const float det = e1x * px + e1y * py + e1z * pz;
+      float inv = 1.f / (det + 0.1f * TOL);
+      if (fabsf(det) < TOL) inv = __builtin_nanf("");  // parallel: every test below becomes false
+      stri[t * 4 + 0] = make_float4(ax, ay, az, inv);
+      stri[t * 4 + 1] = make_float4(e1x, e1y, e1z, 0.f);
+      stri[t * 4 + 2] = make_float4(e2x, e2y, e2z, 0.f);
+      stri[t * 4 + 3] = make_float4(px, py, pz, 0.f);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int t = 0; t < n; ++t) {
+      const float4 A = stri[t * 4], E1 = stri[t * 4 + 1], E2 = stri[t * 4 + 2], PV = stri[t * 4 + 3];
+      const float inv = A.w;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const float tx = ox[k] - A.x, ty = oy[k] - A.y, tz = oz[k] - A.z;
+        const float u = dot3(tx, ty, tz, PV.x, PV.y, PV.z) * inv;
+        // qvec = tvec x e1
+        const float qx = __fmaf_rn(ty, E1.z, -(tz * E1.y));
+        const float qy = __fmaf_rn(tz, E1.x, -(tx * E1.z));
+        const float qz = __fmaf_rn(tx, E1.y, -(ty * E1.x));
+        const float v = dot3(RAY_X, RAY_Y, RAY_Z, qx, qy, qz) * inv;
+        const float tt = dot3(E2.x, E2.y, E2.z, qx, qy, qz) * inv;
+        const bool hit = (u > 0.f) & (u < 1.f) & (v > 0.f) & (u + v < 1.f) & (tt >= TOL);
+        cnt[k] += hit ? 1 : 0;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int pi = pt * (MC_THREADS * PPT) + k * MC_THREADS + tid;
+    if (pi >= P) continue;
+    int* dst = hits + (size_t)b * P + pi;
+    if (tsplit == 1) *dst = cnt[k];
+    else if (cnt[k]) atomicAdd(dst, cnt[k]);
+  }
+}
+
+}  // namespace
+
+extern "C" int obman_mesh_contains_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
+                                       int F, int* hits, obman_stream_t stream) {
+  if (B < 0 || P < 0 || Nv <= 0 || F < 0 || !hits) return -1;
+  if (B == 0 || P == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 0) return (int)hipMemsetAsync(hits, 0, sizeof(int) * (size_t)B * P, st);
+  int ppt = 4;
+  while (ppt > 1 && MC_THREADS * (ppt / 2) >= P) ppt >>= 1;  // smallest PPT whose tile still covers P
+  if (P > MC_THREADS * 4) ppt = 4;
+  const int ptiles = obman_cdiv(P, MC_THREADS * ppt);
+  // split the triangle list until the grid covers the chip ~4x (chunks are multiples of 64 triangles)
+  int tsplit = 1;
+  const long base_blocks = (long)B * ptiles;
+  if (base_blocks < 1024) {
+    tsplit = (int)((1024 + base_blocks - 1) / base_blocks);
+    const int maxsplit = obman_cdiv(F, 64);
+    if (tsplit > maxsplit) tsplit = maxsplit;
+  }
+  int tchunk = obman_cdiv(obman_cdiv(F, tsplit), 64) * 64;
+  tsplit = obman_cdiv(F, tchunk);
+  if (tsplit > 1) {
+    hipError_t e = hipMemsetAsync(hits, 0, sizeof(int) * (size_t)B * P, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 grid(ptiles * tsplit, B);
+  switch (ppt) {
+    case 4: contains_kernel<4><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;
+    case 2: contains_kernel<2><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;
+    default: contains_kernel<1><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;
+  }
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,155 @@
+"""AtlasNet sphere-deformation branch and its loss, HIP-backed.
+
+Mirror of ``mano_train/networks/branches/atlasbranch.py:13-288`` (reference): ``AtlasBranch``
+(``forward`` random sphere samples :78-108, ``forward_inference`` template vertices :110-150),
+``edge_loss`` (:153-167) and ``AtlasLoss.compute_loss`` (:199-287).  Differences by design:
+the sphere template comes from this package's icosphere generator (trimesh is not a dependency),
+``test_verts`` is a registered (non-persistent) buffer so it follows ``.to(device)``, and
+``patches > 1`` concatenates P decoder evaluations (BASELINE.json configs 3/5).
+"""
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as torch_f
+
+from obman_train_amd.icosphere import multi_patch
+from obman_train_amd.networks.branches import atlasutils
+from obman_train_amd.queries import TransQueries
+
+
+def _head(cin, cout):
+    return nn.Sequential(nn.Linear(cin, cin // 2), nn.ReLU(), nn.Linear(cin // 2, cout))
+
+
+class AtlasBranch(nn.Module):
+    def __init__(self, use_residual=False, mode="sphere", points_nb=600, bottleneck_size=1024, use_tanh=False,
+                 inference_ico_divisions=3, predict_trans=False, predict_scale=False, out_factor=200,
+                 separate_encoder=False, patches=1):
+        super().__init__()
+        if use_residual:
+            raise NotImplementedError("PointGenConResidual is unreachable from the reference CLI (SURVEY §2.1 #5)")
+        if mode != "sphere":
+            raise ValueError("{} not in [sphere]".format(mode))
+        self.mode, self.points_nb, self.bottleneck_size = mode, points_nb, bottleneck_size
+        self.separate_encoder, self.use_residual, self.patches = separate_encoder, use_residual, patches
+        self.decoder = atlasutils.PointGenCon(bottleneck_size=3 + bottleneck_size, out_factor=out_factor,
+                                              use_tanh=use_tanh)
+        self.predict_trans, self.predict_scale = predict_trans, predict_scale
+        if predict_trans:
+            self.decode_trans = _head(bottleneck_size, 3)
+        if predict_scale:
+            self.decode_scale = _head(bottleneck_size, 1)
+            self.decode_scale[-1].bias.data.fill_(1)
+        verts, faces = multi_patch(inference_ico_divisions, patches)
+        self.register_buffer("test_verts", torch.from_numpy(verts.astype(np.float32)), persistent=False)
+        self.test_faces = faces
+        self.register_buffer("test_faces_dev", torch.from_numpy(faces.astype(np.int32)), persistent=False)
+
+    def _decode(self, grid, features):
+        return self.decoder.decode(features, grid)
+
+    def _assemble(self, verts, trans, scale, with_faces):
+        res = {}
+        if scale is not None:
+            scaled = scale.unsqueeze(1) * verts
+            if trans is not None:
+                points = scaled + trans.unsqueeze(1)
+        elif trans is not None:
+            points = verts + trans.unsqueeze(1)
+        if scale is None and trans is None:
+            res = {"objpoints3d": verts}
+        if trans is not None:
+            res = {"objpoints3d": points, "objtrans": trans, "objpointscentered3d": verts}
+        if with_faces:
+            res["objfaces"] = self.test_faces
+        if scale is not None:
+            res["objscale"] = scale
+        return res
+
+    def forward(self, img_features):
+        """Random points on the unit sphere (atlasbranch.py:78-108); non-deterministic by construction."""
+        trans = self.decode_trans(img_features) if self.predict_trans else None
+        B = img_features.shape[0]
+        grid = torch.randn((B, self.points_nb, 3), device=img_features.device, dtype=img_features.dtype)
+        grid = grid / grid.norm(dim=2, keepdim=True)
+        x = torch.cat((grid.transpose(2, 1), img_features.unsqueeze(2).expand(-1, -1, self.points_nb)), 1)
+        verts = self.decoder(x).transpose(2, 1)
+        return self._assemble(verts, trans, None, with_faces=False)
+
+    def forward_inference(self, img_features, separate_encoder_features=None):
+        trans = self.decode_trans(img_features) if self.predict_trans else None
+        scale = self.decode_scale(img_features) if self.predict_scale else None
+        dec_features = separate_encoder_features if self.separate_encoder else img_features
+        verts = self._decode(self.test_verts, dec_features)
+        if scale is not None and trans is None:
+            # the reference leaves 'results' unbound here (atlasbranch.py:133-149): same failure, named
+            raise UnboundLocalError("predict_scale without predict_trans is unsupported by the reference")
+        return self._assemble(verts, trans, scale, with_faces=True)
+
+
+def edge_loss(edges, faces):
+    f = torch.as_tensor(np.asarray(faces).astype(np.int64), device=edges.device) if not torch.is_tensor(faces) else faces.long()
+    a, b, c = edges[:, f[:, 0]], edges[:, f[:, 1]], edges[:, f[:, 2]]
+    lens = torch.cat([((a - c) ** 2).sum(2), ((c - b) ** 2).sum(2), ((b - a) ** 2).sum(2)], 1)
+    return (lens - lens.mean(1, keepdim=True)).abs().mean()
+
+
+class AtlasLoss:
+    def __init__(self, lambda_atlas=1, atlas_loss="chamfer", final_lambda_atlas=1, trans_weight=0, scale_weight=0,
+                 edge_regul_lambda=None, lambda_laplacian=0, laplacian_faces=None, laplacian_verts=None):
+        if atlas_loss != "chamfer":
+            raise ValueError("Removed support for earth mover distance !")
+        if lambda_laplacian:
+            raise NotImplementedError("Laplacian regulariser is a 'next' row (SURVEY §8f #2); the reference's "
+                                      "legacy autograd.Function raises on torch >= 1.5 anyway")
+        self.lambda_atlas, self.final_lambda_atlas = lambda_atlas, final_lambda_atlas
+        self.trans_weight, self.scale_weight = trans_weight, scale_weight
+        self.edge_regul_lambda, self.lambda_laplacian = edge_regul_lambda, lambda_laplacian
+        self.atlas_loss = atlas_loss
+        self.chamfer_loss = atlasutils.ChamferLoss()
+
+    def _sym(self, preds, gts):
+        l1, l2 = self.chamfer_loss(preds, gts)
+        return torch.mean(l1 + l2)
+
+    def compute_loss(self, preds, target):
+        out = {}
+        has_gt = TransQueries.objpoints3d in target
+        if (has_gt and (self.lambda_atlas or self.final_lambda_atlas)) or (
+                TransQueries.center3d in target and self.trans_weight):
+            gt = target[TransQueries.objpoints3d]
+            if "objtrans" in preds and has_gt and "objpointscentered3d" in preds:
+                centroids = gt.mean(1)
+                l_trans = torch_f.mse_loss(preds["objtrans"], centroids)
+                out["atlas_trans3d"] = l_trans
+                centred = gt - centroids.unsqueeze(1)
+                if "objscale" in preds:
+                    l_scale = torch_f.mse_loss(preds["objscale"], torch.norm(centred, 2, 2).max(1)[0].unsqueeze(1))
+                    out["atlas_scale3d"] = l_scale
+                else:
+                    l_scale = 0
+                sym = self._sym(preds["objpointscentered3d"], centred)  # always evaluated (App. C #4)
+                mesh = preds["objpointscentered3d"]
+                sym_final = self._sym(preds["objpoints3d"], gt)
+                out["final_{}_loss".format(self.atlas_loss)] = sym_final
+                final = (self.lambda_atlas * sym + self.final_lambda_atlas * sym_final
+                         + self.trans_weight * l_trans + self.scale_weight * l_scale)
+            else:
+                if "objpoints3d" in preds and self.lambda_atlas:
+                    sym = self._sym(preds["objpoints3d"], gt)
+                    final = self.lambda_atlas * sym
+                    mesh = preds["objpoints3d"]
+                else:
+                    # reference: UnboundLocalError at atlasbranch.py:285 (default CLI flags; App. C #3)
+                    raise UnboundLocalError(
+                        "atlas_lambda is 0/None and no translation head: the reference leaves final_loss unassigned; "
+                        "pass atlas_lambda > 0 or atlas_predict_trans")
+            if self.edge_regul_lambda is not None and self.edge_regul_lambda > 0:
+                l_edge = edge_loss(mesh, preds["objfaces"])
+                out["atlas_edge_regul"] = l_edge
+                final = final + self.edge_regul_lambda * l_edge
+        else:
+            sym = None
+            final = torch.zeros(1, device=preds["objpoints3d"].device)
+        out["atlas_objpoints3d"] = sym
+        return final, out

@@ -1,0 +1,120 @@
+"""MANO branch (pose/shape regressors + fused LBS kernel) and its loss.
+
+Mirror of ``mano_train/networks/branches/manobranch.py:11-324`` (reference): same constructor
+arguments, parameter names (``base_layer.{0,2,..}``, ``pose_reg``, ``shape_reg.0``) and result / loss
+dict keys.  The external ``manopth.ManoLayer`` pair and the boolean-mask split / re-assembly by hand
+side (:133-207, host syncs on a GPU) are replaced by ONE launch of ``csrc/mano_lbs.hip`` that picks
+the right/left model blob per sample from an int32 side vector.
+"""
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as torch_f
+
+from obman_train_amd import ops
+from obman_train_amd.mano_model import ManoModelBlob
+from obman_train_amd.mano_params import get_mano_pack
+from obman_train_amd.queries import BaseQueries, TransQueries
+
+
+class ManoBranch(nn.Module):
+    def __init__(self, ncomps=6, base_neurons=(1024, 512), center_idx=9, use_shape=False, use_trans=False,
+                 use_pca=True, mano_root="misc/mano", adapt_skeleton=True, dropout=0):
+        super().__init__()
+        if use_trans:
+            raise NotImplementedError("use_trans: HandNet always builds ManoBranch(use_trans=False) (handnet.py:134)")
+        if not use_pca:
+            raise NotImplementedError("rotation-matrix pose regression (mano_use_pca=False) needs the SVD projection "
+                                      "of manopth's rot6d path; not on any BASELINE config")
+        self.adapt_skeleton, self.use_trans, self.use_shape, self.use_pca = adapt_skeleton, use_trans, use_shape, use_pca
+        self.ncomps, self.center_idx = ncomps, center_idx
+        layers = []
+        for cin, cout in zip(base_neurons[:-1], base_neurons[1:]):
+            if dropout:
+                layers.append(nn.Dropout(p=dropout))
+            layers += [nn.Linear(cin, cout), nn.ReLU()]
+        self.base_layer = nn.Sequential(*layers)
+        self.pose_reg = nn.Linear(base_neurons[-1], ncomps + 3)
+        if use_shape:
+            self.shape_reg = nn.Sequential(nn.Linear(base_neurons[-1], 10))
+        self._models = {s: ManoModelBlob(get_mano_pack(mano_root, s)) for s in ("right", "left")}
+        if adapt_skeleton:
+            self.left_skeleton_reg = nn.Linear(21, 21, bias=False)
+            self.right_skeleton_reg = nn.Linear(21, 21, bias=False)
+            self.left_skeleton_reg.weight.data = torch.eye(21)
+            self.right_skeleton_reg.weight.data = torch.eye(21)
+        self.faces = self._models["right"].faces
+        self._side_cache = {}
+
+    def _side_tensor(self, sides, batch, device):
+        key = (tuple(sides[:batch]), str(device))
+        t = self._side_cache.get(key)
+        if t is None:
+            if len(self._side_cache) > 64:
+                self._side_cache.clear()
+            flags = [0 if s == "right" else 1 for s in sides[:batch]]
+            t = torch.tensor(flags, dtype=torch.int32, device=device) if any(flags) else None
+            self._side_cache[key] = t
+        return t
+
+    def forward(self, inp, sides, root_palm=False, shape=None, pose=None, use_stereoshape=False):
+        if use_stereoshape:
+            raise NotImplementedError("stereo shape prior: HandNet always passes use_stereoshape=False (handnet.py:273)")
+        base = self.base_layer(inp)
+        pose = self.pose_reg(base)
+        shape = self.shape_reg(base) if self.use_shape else None
+        B, dev = inp.shape[0], inp.device
+        side = self._side_tensor(list(sides), B, dev)
+        verts, joints = ops.mano_lbs(
+            pose, shape, self._models["right"].on(dev), self._models["left"].on(dev) if side is not None else None,
+            side, ncomps=self.ncomps, use_pca=self.use_pca, center_idx=self.center_idx, root_palm=root_palm)
+        if self.adapt_skeleton:
+            lefts = torch.ones(B, 1, 1, device=dev) if side is None else None
+            if side is None:  # every hand is a right hand
+                joints = self.right_skeleton_reg(joints.permute(0, 2, 1)).permute(0, 2, 1)
+            else:
+                is_left = side.bool().view(B, 1, 1)
+                jl = self.left_skeleton_reg(joints.permute(0, 2, 1)).permute(0, 2, 1)
+                jr = self.right_skeleton_reg(joints.permute(0, 2, 1)).permute(0, 2, 1)
+                joints = torch.where(is_left, jl, jr)
+            del lefts
+        return {"verts": verts, "joints": joints, "shape": shape, "pose": pose}
+
+
+class ManoLoss:
+    def __init__(self, lambda_verts=None, lambda_joints3d=None, lambda_shape=None, lambda_pose_reg=None,
+                 lambda_pca=None, center_idx=9, normalize_hand=False):
+        self.lambda_verts, self.lambda_joints3d, self.lambda_shape = lambda_verts, lambda_joints3d, lambda_shape
+        self.lambda_pose_reg, self.lambda_pca = lambda_pose_reg, lambda_pca
+        self.center_idx, self.normalize_hand = center_idx, normalize_hand
+
+    def compute_loss(self, preds, target):
+        dev = preds["verts"].device
+        final = torch.zeros(1, device=dev)
+        out = {}
+        if TransQueries.verts3d in target and self.lambda_verts:
+            l_verts = torch_f.mse_loss(preds["verts"], target[TransQueries.verts3d])
+            final += self.lambda_verts * l_verts
+        else:
+            l_verts = None
+        out["mano_verts3d"] = l_verts
+        if TransQueries.joints3d in target and self.lambda_joints3d:
+            l_joints = torch_f.mse_loss(preds["joints"], target[TransQueries.joints3d])
+            final += self.lambda_joints3d * l_joints
+            out["mano_joints3d"] = l_joints
+        if self.lambda_shape:
+            l_shape = torch_f.mse_loss(preds["shape"], torch.zeros_like(preds["shape"]))
+            final += self.lambda_shape * l_shape
+        else:
+            l_shape = None
+        out["mano_shape"] = l_shape
+        if self.lambda_pose_reg:
+            reg = preds["pose"][:, 3:]
+            l_pose = torch_f.mse_loss(reg, torch.zeros_like(reg))
+            final += self.lambda_pose_reg * l_pose
+            out["pose_reg"] = l_pose
+        if BaseQueries.hand_pcas in target and self.lambda_pca:
+            raise KeyError("pcas")  # the reference reads preds['pcas'], which ManoBranch never produces (App. C #14)
+        out["mano_pca"] = None
+        out["mano_total_loss"] = final
+        return final, out

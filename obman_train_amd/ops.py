@@ -8,6 +8,12 @@ import torch
 from . import _lib
 
 
+def require_rocm(device):
+    """The product path is HIP-only: refuse to run anywhere else instead of silently falling back."""
+    if device.type != "cuda":
+        raise _lib.ObmanHipError("obman_train_amd needs a ROCm device (model.cuda()); there is no CPU fallback")
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -171,3 +177,66 @@ def mano_lbs(pose, betas, blob_right, blob_left=None, side=None, ncomps=30, use_
     """ManoLayer.forward replacement: pose [B,3+ncomps], betas [B,10]|None -> (verts [B,778,3] mm,
     joints [B,21,3] mm).  ``side`` int32 [B] picks right(0)/left(1) model blob per sample."""
     return _ManoLBS.apply(pose, betas, blob_right, blob_left, side, ncomps, use_pca, center_idx, root_palm)
+
+
+def mesh_contains_hits(points, verts, faces):
+    """points [B,P,3], verts [B,Nv,3], faces [F,3] int32 (device) -> hits [B,P] int32 (ray/triangle
+    crossings along the reference's fixed direction; exterior <=> even).  No gradient."""
+    points, verts = _dev(points.detach(), "points"), _dev(verts.detach(), "verts")
+    faces = _dev(faces, "faces", torch.int32)
+    if points.dim() != 3 or verts.dim() != 3 or faces.dim() != 2 or faces.shape[1] != 3:
+        raise ValueError("expected points [B,P,3], verts [B,Nv,3], faces [F,3]")
+    B, P, Nv, F = points.shape[0], points.shape[1], verts.shape[1], faces.shape[0]
+    hits = torch.empty((B, P), dtype=torch.int32, device=points.device)
+    _lib.check(_lib.lib().obman_mesh_contains_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P, Nv, F,
+                                                  hits.data_ptr(), _stream()), "obman_mesh_contains_fwd")
+    return hits
+
+
+MODES = {"dist_sq": 0, "dist": 1, "dist_tanh": 2}
+TARGETS = {"all": 0, "obj": 1, "hand": 2}
+
+
+class _ContactTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zone_mode, contact_mode,
+                contact_thresh, collision_mode, collision_thresh, target):
+        hand, obj = _dev(hand, "hand"), _dev(obj, "obj")
+        B, V, N = hand.shape[0], hand.shape[1], obj.shape[1]
+        dev = hand.device
+        attr = torch.empty((B, V), dtype=torch.uint8, device=dev)
+        rep = torch.empty((B, V), dtype=torch.uint8, device=dev)
+        cpts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
+        partials = torch.empty((B, 8), dtype=torch.float32, device=dev)
+        out = torch.empty((8,), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().obman_contact_fwd(
+            hand.data_ptr(), obj.data_ptr(), idx21.data_ptr(), mins21.data_ptr(), hits.data_ptr(), B, V, N,
+            _ptr(zone_ids), _ptr(zone_off), int(n_zones), int(zone_mode), int(contact_mode), float(contact_thresh),
+            int(collision_mode), float(collision_thresh), attr.data_ptr(), rep.data_ptr(), cpts.data_ptr(),
+            partials.data_ptr(), out.data_ptr(), _stream()), "obman_contact_fwd")
+        ctx.save_for_backward(hand, obj, idx21, attr, rep, out)
+        ctx.cfg = (B, V, N, int(contact_mode), float(contact_thresh), int(collision_mode), float(collision_thresh),
+                   int(target))
+        ctx.mark_non_differentiable(attr, rep, cpts, out)
+        return out[0], out[1], out, attr, rep, cpts
+
+    @staticmethod
+    def backward(ctx, g_missed, g_penetr, *_unused):
+        hand, obj, idx21, attr, rep, out = ctx.saved_tensors
+        B, V, N, cmode, cth, kmode, kth, target = ctx.cfg
+        g_missed = g_missed.contiguous() if g_missed is not None else None
+        g_penetr = g_penetr.contiguous() if g_penetr is not None else None
+        grad_hand = torch.empty_like(hand) if ctx.needs_input_grad[0] else None
+        grad_obj = torch.empty_like(obj) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.lib().obman_contact_bwd(
+            hand.data_ptr(), obj.data_ptr(), idx21.data_ptr(), attr.data_ptr(), rep.data_ptr(), out.data_ptr(),
+            _ptr(g_missed), _ptr(g_penetr), B, V, N, cmode, cth, kmode, kth, target, _ptr(grad_hand), _ptr(grad_obj),
+            _stream()), "obman_contact_bwd")
+        return (grad_hand, grad_obj) + (None,) * 12
+
+
+def contact_tail(hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zone_mode, contact_mode,
+                 contact_thresh, collision_mode, collision_thresh, target):
+    """-> (missed_loss, penetr_loss, out[8], attraction_mask u8, repulsion_mask u8, contact_points)."""
+    return _ContactTail.apply(hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zone_mode, contact_mode,
+                              contact_thresh, collision_mode, collision_thresh, target)

@@ -1,0 +1,163 @@
+"""GPU parity: inside test (K4) and contact loss (K2+K4+K5) through the C-ABI vs the reference's
+golden vectors and the CPU oracle.  Hit counts / masks are integer work: bit-exact except where a
+ray grazes a triangle edge within fp32 round-off (both the reference and the kernel are then
+arbitrary); such points are identified with an fp64 margin and excluded."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import contact as ocontact
+from obman_train_amd.contactzones import hand_template, load_contacts
+from obman_train_amd.icosphere import icosphere, multi_patch
+from tests.golden.common import unpack_bits
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _blob(subdiv, B, seed, radius=40.0, patches=1):
+    rng = np.random.RandomState(seed)
+    v, f = multi_patch(subdiv, patches)
+    scale = radius * (1.0 + 0.3 * np.sin(4.0 * v[:, :1]) * np.cos(3.0 * v[:, 1:2]))
+    pts = v[None] * scale[None] * rng.uniform(0.6, 1.4, size=(B, 1, 3))
+    if patches > 1:  # spread the patches out so the union is not degenerate
+        n = v.shape[0] // patches
+        for p in range(patches):
+            pts[:, p * n:(p + 1) * n] += rng.normal(0, 25.0, size=(B, 1, 3))
+    return T(pts.astype(np.float32)), f.astype(np.int32)
+
+
+def _margin_ok(origins, verts, faces):
+    """fp64 mask of points whose ray does not graze any triangle border (|u|,|v|,|1-u-v|,|t| > 1e-4)."""
+    o = origins.double()
+    tri = verts.double()[:, T(faces.astype(np.int64))]
+    a, e1, e2 = tri[:, :, 0], tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0]
+    d = torch.tensor(ocontact.RAY_DIRECTION, dtype=torch.float64)
+    pvec = torch.cross(d.expand_as(e2), e2, dim=2)
+    det = (e1 * pvec).sum(2)
+    inv = 1.0 / det
+    tvec = o[:, :, None, :] - a[:, None]
+    u = (tvec * pvec[:, None]).sum(3) * inv[:, None]
+    q = torch.cross(tvec, e1[:, None].expand_as(tvec), dim=3)
+    v = (q * d).sum(3) * inv[:, None]
+    t = (q * e2[:, None]).sum(3) * inv[:, None]
+    near_plane_hit = (u > -1e-3) & (u < 1 + 1e-3) & (v > -1e-3) & (u + v < 1 + 1e-3) & (t > -1e-3)
+    graze = near_plane_hit & ((u.abs() < 1e-4) | (v.abs() < 1e-4) | ((1 - u - v).abs() < 1e-4) | (t.abs() < 1e-4))
+    return ~graze.any(2)
+
+
+def test_contains_matches_reference_golden(golden):
+    from obman_train_amd.networks.branches.contactutils import batch_mesh_contains_points, mesh_exterior
+
+    g = golden("contains")
+    ext, hits = mesh_exterior(T(g["origins"]).cuda(), T(g["obj_verts"]).cuda(), T(g["faces"]).cuda())
+    np.testing.assert_array_equal(ext.cpu().numpy(), g["exterior"])
+    tri = T(g["obj_verts"])[:, T(g["faces"].astype(np.int64))].cuda()
+    ext2 = batch_mesh_contains_points(T(g["origins"]).cuda(), tri)  # the reference's triangle signature
+    np.testing.assert_array_equal(ext2.cpu().numpy(), g["exterior"])
+
+
+@pytest.mark.parametrize("B,P,subdiv,patches", [(1, 1, 0, 1), (2, 100, 1, 1), (3, 778, 2, 1), (2, 1500, 2, 3), (2, 70, 3, 1)])
+def test_contains_matches_oracle(B, P, subdiv, patches):
+    from obman_train_amd import ops
+
+    verts, faces = _blob(subdiv, B, 3, patches=patches)
+    rng = np.random.RandomState(4)
+    origins = T(rng.normal(0, 35, size=(B, P, 3)).astype(np.float32))
+    hits = ops.mesh_contains_hits(origins.cuda(), verts.cuda(), T(faces).cuda()).cpu()
+    tri = verts[:, T(faces.astype(np.int64))]
+    want = ocontact.mesh_contains_points(origins, tri)
+    ok = _margin_ok(origins, verts, faces)
+    got = (hits & 1) == 0
+    assert ok.float().mean() > 0.98
+    np.testing.assert_array_equal(got[ok].numpy(), want[ok].numpy())
+    assert 0.02 < (~want).float().mean() < 0.98 or P == 1  # both classes present
+
+
+def test_contains_full_size_properties():
+    """bs 64 x 778 points x 1280 triangles (config 2) and a 25-patch mesh: far points are outside, the
+    centre of a star-shaped blob is inside, triangle order does not matter (integer counts), repeat
+    launches are identical (atomic merge of integer counts)."""
+    from obman_train_amd import ops
+
+    for subdiv, patches, B in ((3, 1, 64), (3, 25, 4)):
+        verts, faces = _blob(subdiv, B, 7, patches=1 if patches == 1 else patches)
+        P = 778
+        rng = np.random.RandomState(8)
+        origins = T(rng.normal(0, 30, size=(B, P, 3)).astype(np.float32))
+        origins[:, 0] = 1e4
+        if patches == 1:
+            origins[:, 1] = 0.0
+        fc = T(faces).cuda()
+        hits = ops.mesh_contains_hits(origins.cuda(), verts.cuda(), fc)
+        assert torch.all(hits[:, 0] == 0)
+        if patches == 1:
+            assert torch.all(hits[:, 1] % 2 == 1)
+        perm = torch.randperm(fc.shape[0]).cuda()
+        hits_p = ops.mesh_contains_hits(origins.cuda(), verts.cuda(), fc[perm].contiguous())
+        assert torch.equal(hits, hits_p)
+        assert torch.equal(hits, ops.mesh_contains_hits(origins.cuda(), verts.cuda(), fc))
+        # spot-check 2 samples against the oracle
+        tri = verts[:2][:, T(faces.astype(np.int64))]
+        want = ocontact.mesh_contains_points(origins[:2], tri)
+        ok = _margin_ok(origins[:2], verts[:2], faces)
+        np.testing.assert_array_equal(((hits[:2].cpu() & 1) == 0)[ok].numpy(), want[ok].numpy())
+
+
+def test_contact_loss_all_modes_match_reference_golden(golden):
+    from obman_train_amd.networks.branches.contactloss import compute_contact_loss
+
+    g = golden("contact")
+    hand_faces = hand_template()[1]
+    combos = [str(c).split("|") for c in g["combos"]]
+    for ci, (zone_mode, cmode, kmode, target) in enumerate(combos):
+        tag = "c%02d_" % ci
+        hand = T(g["hand"]).cuda().requires_grad_()
+        obj = T(g["obj"]).cuda().requires_grad_()
+        missed, penetr, info, metrics = compute_contact_loss(
+            hand, hand_faces, obj, g["faces"], contact_thresh=10, contact_mode=cmode, collision_thresh=20,
+            collision_mode=kmode, contact_target=target, contact_zones=zone_mode)
+        np.testing.assert_allclose(float(missed), float(g[tag + "missed"][0]), rtol=1e-4, err_msg=str(combos[ci]))
+        np.testing.assert_allclose(float(penetr), float(g[tag + "penetr"][0]), rtol=1e-4, err_msg=str(combos[ci]))
+        np.testing.assert_allclose(float(metrics["max_penetr"]), float(g[tag + "max_penetr"]), rtol=1e-4)
+        np.testing.assert_allclose(float(metrics["mean_penetr"]), float(g[tag + "mean_penetr"]), rtol=1e-4)
+        shape = tuple(info["repulsion_masks"].shape)
+        np.testing.assert_array_equal(info["attraction_masks"].cpu().numpy() != 0, unpack_bits(g[tag + "attr_mask"], shape))
+        np.testing.assert_array_equal(info["repulsion_masks"].cpu().numpy(), unpack_bits(g[tag + "rep_mask"], shape))
+        assert str(info["attraction_masks"].dtype) == str(g[tag + "attr_dtype"])
+        (missed.sum() + 2.0 * penetr.sum()).backward()
+        for got, want in ((hand.grad, g[tag + "grad_hand"]), (obj.grad, g[tag + "grad_obj"])):
+            got = got.cpu().numpy() if got is not None else np.zeros_like(want)
+            err = np.abs(got - want).max()
+            assert err <= 1e-3 * max(np.abs(want).max(), 1e-6), (combos[ci], err, np.abs(want).max())
+        if ci == 0:
+            np.testing.assert_allclose(info["min_dists"].cpu().numpy(), g["min_dists"], rtol=1e-4, atol=2e-3)
+            np.testing.assert_allclose(info["contact_points"].cpu().numpy(), g["contact_points"], rtol=1e-6)
+
+
+def test_meshiou_matches_reference_golden(golden):
+    from obman_train_amd.networks.branches.contactloss import meshiou
+
+    g = golden("contact")
+    ious, auc = meshiou(T(g["iou_gt_dists"]).cuda(), T(g["min_dists"]).cuda())
+    np.testing.assert_allclose(ious.cpu().numpy(), g["iou_batch"], rtol=1e-6)
+    np.testing.assert_allclose(float(auc), float(g["iou_auc"]), rtol=1e-6)
+
+
+def test_contact_empty_masks_give_zero_loss_and_zero_grad():
+    """Object far away: nothing penetrates (penetr mask empty), nothing within dist_sq threshold."""
+    from obman_train_amd.networks.branches.contactloss import compute_contact_loss
+
+    tv, tf = hand_template()
+    hand = (T(tv) * 1000).unsqueeze(0).repeat(2, 1, 1).cuda().requires_grad_()
+    v, f = icosphere(1)
+    obj = (T(v.astype(np.float32)) * 10 + 5000.0).unsqueeze(0).repeat(2, 1, 1).cuda().requires_grad_()
+    missed, penetr, info, metrics = compute_contact_loss(hand, tf, obj, f, contact_thresh=10, contact_mode="dist_sq",
+                                                         collision_thresh=20, collision_mode="dist_sq")
+    assert float(missed) == 0.0 and float(penetr) == 0.0 and float(metrics["max_penetr"]) == 0.0
+    (missed + penetr).backward()
+    assert torch.all(hand.grad == 0) and torch.all(obj.grad == 0)
+    with pytest.raises(ValueError):
+        compute_contact_loss(hand, tf, obj, f, contact_mode="nope")
+    with pytest.raises(ValueError):
+        compute_contact_loss(hand, tf, obj, f, contact_zones="palm")
