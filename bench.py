@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py - train images/sec of the mesh-loss hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = forward + backward + Adam step of HandNet on one synthetic bs-64 batch already resident
+in HBM (BASELINE.json configs[1]: ResNet18 + MANO(30 PCA) + 1-sphere AtlasNet(642) + Chamfer, fp32).
+Prints ONE JSON line (rank 0).  `roofline` = the Chamfer pair-min kernel, measured live with HIP events
+on the launch stream inside the timed loop; `cpu_baseline` = the CPU oracle's full train step on the
+host cores (rank 0, N=1 only), bounded to ~10-30 s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3      # fp32 vector peak (the bound that actually binds the pair-min kernel)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c3p1 | c3")
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, seconds, image_size):
+    """The CPU oracle's full train step (fwd + bwd + Adam), configs[0] shape: bs=4."""
+    from types import SimpleNamespace
+
+    from oracle import handnet as ohandnet
+    from oracle import mano as omano
+    from obman_train_amd.contactzones import load_contacts
+    from obman_train_amd.mano_params import synthetic_mano
+    from obman_train_amd.networks.bases import resnet
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.queries import BaseQueries, TransQueries
+    from obman_train_amd.synthetic import make_batch
+
+    import warnings
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    model = HandNet(**cfg)  # parameter container only; its forward is never called here
+    named = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = []
+    for k, v in named.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_()
+            params.append(v)
+    opt = torch.optim.Adam(params, lr=1e-4)
+    keys = SimpleNamespace(images=TransQueries.images, verts3d=TransQueries.verts3d, joints3d=TransQueries.joints3d,
+                           objpoints3d=TransQueries.objpoints3d, sides=BaseQueries.sides)
+    packs = {s: omano.pack_to_torch(synthetic_mano(s)) for s in ("right", "left")}
+    shell = resnet.resnet18()
+    bs = 4
+    sample = make_batch(bs, "cpu", seed=0, image_size=image_size)
+    zones = load_contacts()[1]
+
+    def step():
+        total, _, _ = ohandnet.handnet_forward(named, cfg, dict(sample), keys, packs, model.atlas_branch.test_verts,
+                                               model.atlas_branch.test_faces, zones=zones, resnet_shell=shell,
+                                               training=True)
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return {
+        "value": bs * n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": "%d train steps (fwd+bwd+Adam) of configs[0] (bs=%d, %dx%d) through oracle/ on the host CPU, %.1f s"
+                  % (n, bs, image_size, image_size, dt),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    import warnings
+    warnings.simplefilter("ignore")
+    torch.backends.cudnn.benchmark = True
+
+    from obman_train_amd import _lib
+    from obman_train_amd.dp import GradientBuckets, broadcast_parameters
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.queries import TransQueries
+    from obman_train_amd.synthetic import CONFIGS, make_batch
+    from obman_train_amd.trainer import make_optimizer, train_step
+
+    cfg = CONFIGS[args.config]
+    torch.manual_seed(0)
+    model = HandNet(**cfg).to(dev)
+    model.train()
+    broadcast_parameters(model)
+    opt = make_optimizer(model, "adam", lr=1e-4)
+    buckets = GradientBuckets(model.parameters()) if world > 1 else None
+    sample = make_batch(args.batch, dev, seed=rank, image_size=args.image_size)
+
+    for _ in range(args.warmup):
+        train_step(model, opt, sample, buckets)
+    _lib.prof_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total, _, _ = train_step(model, opt, sample, buckets)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss_val = float(total)
+    pm_ms, pm_n = _lib.prof_summary(1)
+    _lib.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    if rank == 0:
+        n_pred = model.atlas_branch.test_verts.shape[0]
+        n_gt = sample[TransQueries.objpoints3d].shape[1]
+        # Chamfer fwd algorithmic bytes 20*(N+M) per sample, ~10*N*M flop per sample
+        alg_bytes = 20.0 * (n_pred + n_gt) * args.batch
+        alg_flop = 10.0 * n_pred * n_gt * args.batch
+        avg_s = (pm_ms / max(pm_n, 1)) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9 if pm_n else None
+        roof = {
+            "kernel": "pairmin_fwd_kernel (Chamfer fwd, both directions, %d samples/launch)" % args.batch,
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+            "avg_launch_us": avg_s * 1e6, "launches": pm_n, "alg_bytes_per_launch": alg_bytes,
+            "valu": {"achieved_tflops": alg_flop / avg_s / 1e12 if pm_n else None, "peak_tflops": VALU_PEAK_TFLOPS,
+                     "frac": (alg_flop / avg_s / 1e12 / VALU_PEAK_TFLOPS) if pm_n else None,
+                     "note": "binding bound: intensity N*M/(2(N+M)) = %.0f flop/B >> 20 flop/B ridge"
+                             % (n_pred * n_gt / (2.0 * (n_pred + n_gt)))},
+        }
+        traffic_file = os.path.join(REPO, "profiles", "chamfer_traffic.json")
+        if os.path.exists(traffic_file):
+            with open(traffic_file) as fh:
+                roof["traffic"] = json.load(fh).get(args.config)
+        out = {
+            "metric": "train images/sec (fwd+bwd+Adam, bs=%d/GPU)" % args.batch,
+            "value": args.batch * world * args.steps / dt, "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: ResNet18 + MANO(30 PCA comps) LBS + 1-sphere AtlasNet(642 verts) "
+                                   "+ Chamfer vs 600 GT points%s, %dx%d RGB, fp32, Adam"
+                                   % (" + contact/penetration (%d patches)" % cfg.get("atlas_patches", 1)
+                                      if cfg.get("contact_lambda") else "", args.image_size, args.image_size),
+                       "name": args.config, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
+                       "parallelism": "dp%d" % world, "final_loss": loss_val},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,15 @@ int obman_contact_bwd(const float* hand, const float* obj, const int* idx21, con
                       int B, int V, int N, int contact_mode, float contact_thresh, int collision_mode,
                       float collision_thresh, int target, float* grad_hand, float* grad_obj, obman_stream_t stream);
 
+/* ---- measurement utility (not on the product path) ----------------------------------------------
+ * obman_prof_enable(1) makes the launchers bracket their main kernel with HIP events on the launch
+ * stream (pool of 8192 records, reset by every enable call); obman_prof_summary synchronises and
+ * returns the summed duration / launch count of one kernel id (1 pair-min fwd, 2 pair-min bwd,
+ * 3 inside test, 4/5 contact fwd/bwd, 6/7 MANO fwd/bwd, 8/9 decoder fwd/bwd).  Used by bench.py for
+ * the `roofline` object; off by default. */
+int obman_prof_enable(int on);
+int obman_prof_summary(int kernel_id, double* total_ms, long* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,8 @@ _SIGNATURES = {
     "obman_mesh_contains_fwd": (_c_int, "ppp" "iiii" "pp"),
     "obman_contact_fwd": (_c_int, "ppppp" "iii" "pp" "ii" "ifif" "ppppp" "p"),
     "obman_contact_bwd": (_c_int, "pppppppp" "iii" "ifif" "i" "pp" "p"),
+    "obman_prof_enable": (_c_int, "i"),
+    "obman_prof_summary": (_c_int, "ipp"),
     "obman_mano_model_floats": (_c_int, ""),
     "obman_mano_state_floats": (_c_int, ""),
     "obman_mano_lbs_fwd": (_c_int, "ppppp" "iiiii" "ppp" "p"),
@@ -70,3 +72,14 @@ def declared_symbols(header_path):
         text = fh.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(obman_[a-z0-9_]+)\s*\(", text)))
+
+
+def prof_enable(on=True):
+    check(lib().obman_prof_enable(1 if on else 0), "obman_prof_enable")
+
+
+def prof_summary(kernel_id):
+    """-> (total_ms, launches) of one kernel id since the last prof_enable()."""
+    tot, n = ctypes.c_double(0.0), ctypes.c_long(0)
+    check(lib().obman_prof_summary(int(kernel_id), ctypes.addressof(tot), ctypes.addressof(n)), "obman_prof_summary")
+    return tot.value, n.value

@@ -11,6 +11,7 @@
 // u>0,u<1,v>0,u+v<1, t>=tol, exterior <=> even hit count.
 // Bound: fp32 VALU; algorithmic bytes B*(P*12 + Nv*12 + F*12 + P*4).
 #include "common.h"
+#include "prof.h"
 #include "../../include/obman_hip.h"
 
 namespace {
@@ -127,6 +128,7 @@ extern "C" int obman_mesh_contains_fwd(const float* points, const float* verts, 
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid(ptiles * tsplit, B);
+  ObmanProfScope prof(OBMAN_K_CONTAINS, st);
   switch (ppt) {
     case 4: contains_kernel<4><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;
     case 2: contains_kernel<2><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;

@@ -10,6 +10,7 @@
 // rest shape: 2766 floats) is saved for the backward, which therefore never re-reads posedirs for
 // the forward product.  Bound: L2 bandwidth / latency, not HBM, not MFMA.
 #include "common.h"
+#include "prof.h"
 #include "../../include/obman_hip.h"
 
 namespace {
@@ -470,6 +471,7 @@ int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const 
   if (side && !model_left) return -4;
   if (B == 0) return 0;
   const int npose = 3 + (use_pca ? ncomps : 45);
+  ObmanProfScope prof(OBMAN_K_MANO_FWD, (hipStream_t)stream);
   mano_fwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(model_right, model_left, side, pose, betas, npose, ncomps, use_pca,
                                                        center_idx, root_palm, verts, joints, state);
   OBMAN_LAUNCH_CHECK();
@@ -484,6 +486,7 @@ int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const 
   if (side && !model_left) return -4;
   if (B == 0) return 0;
   const int npose = 3 + (use_pca ? ncomps : 45);
+  ObmanProfScope prof(OBMAN_K_MANO_BWD, (hipStream_t)stream);
   mano_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(model_right, model_left, side, state, g_verts, g_joints, npose, ncomps,
                                                        use_pca, center_idx, root_palm, g_pose, g_betas);
   OBMAN_LAUNCH_CHECK();

@@ -13,6 +13,7 @@
 //     atomicMin on (dist_bits << 32 | idx): order independent => deterministic, ties -> lowest idx.
 // Bound: fp32 VALU (~7.5 lane-ops/pair); algorithmic HBM bytes 20*(Nx+Ny) per sample.
 #include "common.h"
+#include "prof.h"
 #include "../../include/obman_hip.h"
 
 namespace {
@@ -244,10 +245,13 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   const int gx0 = min_x ? d0.qtiles * d0.rsplit : 0, gx1 = min_y ? d1.qtiles * d1.rsplit : 0;
   dim3 grid(gx0 > gx1 ? gx0 : gx1, B, 2);
   if (grid.x == 0) return 0;
-  switch (qpt) {
-    case 4: pairmin_fwd_kernel<4><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
-    case 2: pairmin_fwd_kernel<2><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
-    default: pairmin_fwd_kernel<1><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
+  {
+    ObmanProfScope prof(OBMAN_K_PAIRMIN_FWD, st);
+    switch (qpt) {
+      case 4: pairmin_fwd_kernel<4><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
+      case 2: pairmin_fwd_kernel<2><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
+      default: pairmin_fwd_kernel<1><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
+    }
   }
   OBMAN_LAUNCH_CHECK();
   if (d0.rsplit > 1) {
@@ -273,7 +277,10 @@ int launch_pairmin_bwd(const float* x, const float* y, int B, int Nx, int Ny, co
   const int n_max = (grad_x ? Nx : 0) > (grad_y ? Ny : 0) ? Nx : Ny;
   if (!grad_x && !grad_y) return 0;
   dim3 grid(obman_cdiv(n_max, 256), B, 2);
-  pairmin_bwd_kernel<<<grid, 256, 0, st>>>(s0, s1);
+  {
+    ObmanProfScope prof(OBMAN_K_PAIRMIN_BWD, st);
+    pairmin_bwd_kernel<<<grid, 256, 0, st>>>(s0, s1);
+  }
   OBMAN_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,16 @@
+#pragma once
+#include <hip/hip_runtime.h>
+
+// kernel ids for obman_prof_summary()
+enum {
+  OBMAN_K_PAIRMIN_FWD = 1, OBMAN_K_PAIRMIN_BWD = 2, OBMAN_K_CONTAINS = 3, OBMAN_K_CONTACT_FWD = 4,
+  OBMAN_K_CONTACT_BWD = 5, OBMAN_K_MANO_FWD = 6, OBMAN_K_MANO_BWD = 7, OBMAN_K_DECODER_FWD = 8,
+  OBMAN_K_DECODER_BWD = 9,
+};
+
+struct ObmanProfScope {
+  ObmanProfScope(int id, hipStream_t st);
+  ~ObmanProfScope();
+  int rec_;
+  hipStream_t st_;
+};
