@@ -1,0 +1,87 @@
+"""Multi-process data-parallel path on CPU (gloo, world_size 2): bucketed gradient all-reduce gives the
+mean over ranks of the per-shard gradients (= the DataParallel-replica semantics DESIGN.md defines),
+including parameters that never receive a gradient (like ``base_net.fc``) and several small buckets."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.body = nn.Sequential(nn.Linear(12, 32), nn.ReLU(), nn.Linear(32, 16), nn.ReLU(), nn.Linear(16, 3))
+        self.unused = nn.Linear(5, 5)  # never used in forward: no gradient, like base_net.fc
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _model():
+    torch.manual_seed(0)
+    return _Net()
+
+
+def _data():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(8, 12, generator=g), torch.randn(8, 3, generator=g)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from obman_train_amd.dp import GradientBuckets, broadcast_parameters
+
+    net = _model()
+    if rank == 1:  # desynchronise on purpose: broadcast must repair it
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    broadcast_parameters(net)
+    buckets = GradientBuckets(net.parameters(), bucket_bytes=256)
+    assert len(buckets.buckets) >= 3
+    x, y = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    for step in range(2):  # twice: bucket state must reset between steps
+        net.zero_grad(set_to_none=True)
+        loss = ((net(x[shard]) - y[shard]) ** 2).mean()
+        loss.backward()
+        buckets.finish()
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}
+    torch.save(grads, os.path.join(out_dir, "grads_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_matches_full_batch(tmp_path):
+    world, port = 2, _free_port()
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, start_method="spawn")
+    net = _model()
+    x, y = _data()
+    ((net(x) - y) ** 2).mean().backward()
+    want = {k: p.grad for k, p in net.named_parameters()}
+    for rank in range(world):
+        got = torch.load(os.path.join(str(tmp_path), "grads_%d.pt" % rank))
+        for k, g in want.items():
+            if g is None:
+                assert got[k] is None
+            else:
+                torch.testing.assert_close(got[k], g, rtol=1e-5, atol=1e-6)
+
+
+def test_single_process_is_a_noop():
+    from obman_train_amd.dp import GradientBuckets
+
+    net = _model()
+    b = GradientBuckets(net.parameters())
+    assert not b.enabled
+    b.finish()
