@@ -12,6 +12,8 @@
 //   * long reference sets with few queries are split over blocks (rsplit) and merged with a 64-bit
 //     atomicMin on (dist_bits << 32 | idx): order independent => deterministic, ties -> lowest idx.
 // Bound: fp32 VALU (~7.5 lane-ops/pair); algorithmic HBM bytes 20*(Nx+Ny) per sample.
+#include <cstdlib>
+
 #include "common.h"
 #include "prof.h"
 #include "../../include/obman_hip.h"
@@ -32,6 +34,11 @@ struct PmDir {
   int nq, nr, qtiles, rsplit, rchunk;
 };
 
+// Block = 4 waves.  All 4 waves hold the SAME 64*QPT queries (lane l owns queries l, l+64, ..) and each
+// wave sweeps its own quarter of the staged reference tile, so a query's serial chain is 4x shorter and
+// 4x more waves are in flight to hide the LDS latency (the r01a kernel ran ~1.2 waves/SIMD and was
+// latency-bound).  The four partial (min, group) pairs are merged through LDS lexicographically
+// (value, then lower group start => first index), then 64*QPT lanes resolve the exact index.
 template <int QPT>
 __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir d1) {
   const PmDir d = blockIdx.z == 0 ? d0 : d1;
@@ -39,31 +46,34 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
   const int tile = blockIdx.x;
   if (tile >= d.qtiles * d.rsplit) return;
   const int qt = tile % d.qtiles, rs = tile / d.qtiles;
-  const int b = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ qb = d.q + (size_t)b * d.nq * 3;
   const float* __restrict__ rb = d.r + (size_t)b * d.nr * 3;
 
   __shared__ float4 sref[PM_REF_TILE];
+  __shared__ float s_val[4][64 * QPT];
+  __shared__ int s_grp[4][64 * QPT];
 
   float qx[QPT], qy[QPT], qz[QPT], best[QPT];
   int bestj[QPT];
 #pragma unroll
   for (int k = 0; k < QPT; ++k) {
-    const int qi = qt * (PM_THREADS * QPT) + k * PM_THREADS + tid;
+    const int qi = qt * (64 * QPT) + k * 64 + lane;
     const int qc = qi < d.nq ? qi : d.nq - 1;  // clamp: idle lanes redo the last point, never stored
     qx[k] = qb[(size_t)qc * 3 + 0];
     qy[k] = qb[(size_t)qc * 3 + 1];
     qz[k] = qb[(size_t)qc * 3 + 2];
     best[k] = __builtin_inff();
-    bestj[k] = 0;
+    bestj[k] = 0x7fffffff;
   }
 
   const int rbeg = rs * d.rchunk;
   const int rend = min(d.nr, rbeg + d.rchunk);
   for (int base = rbeg; base < rend; base += PM_REF_TILE) {
     const int cnt = min(PM_REF_TILE, rend - base);
-    const int cnt4 = (cnt + 3) & ~3;
-    for (int i = tid; i < cnt4; i += PM_THREADS) {
+    const int slice = ((cnt + 15) >> 4) << 2;  // references per wave, multiple of 4
+    const int padded = slice * 4;
+    for (int i = tid; i < padded; i += PM_THREADS) {
       float4 v = make_float4(PM_BIG, PM_BIG, PM_BIG, 0.f);
       if (i < cnt) {
         const float* p = rb + (size_t)(base + i) * 3;
@@ -72,8 +82,9 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
       sref[i] = v;
     }
     __syncthreads();
+    const int jbeg = wave * slice, jend = jbeg + slice;
 #pragma unroll 2
-    for (int j = 0; j < cnt4; j += 4) {
+    for (int j = jbeg; j < jend; j += 4) {
       const float4 r0 = sref[j], r1 = sref[j + 1], r2 = sref[j + 2], r3 = sref[j + 3];
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
@@ -89,28 +100,43 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
     }
     __syncthreads();
   }
-
 #pragma unroll
   for (int k = 0; k < QPT; ++k) {
-    const int qi = qt * (PM_THREADS * QPT) + k * PM_THREADS + tid;
+    s_val[wave][k * 64 + lane] = best[k];
+    s_grp[wave][k * 64 + lane] = bestj[k];
+  }
+  __syncthreads();
+  for (int t = tid; t < 64 * QPT; t += PM_THREADS) {
+    const int qi = qt * (64 * QPT) + t;
     if (qi >= d.nq) continue;
-    int idx = bestj[k];
-    const int j0 = bestj[k];
+    float bv = s_val[0][t];
+    int bj = s_grp[0][t];
 #pragma unroll
-    for (int t = 3; t >= 0; --t) {  // descending so the FIRST matching index survives
-      const int j = j0 + t;
-      if (j < rend) {
-        const float* p = rb + (size_t)j * 3;
-        const float e = obman_dist2(qx[k], qy[k], qz[k], p[0], p[1], p[2]);
-        if (e == best[k]) idx = j;
-      }
+    for (int w = 1; w < 4; ++w) {
+      const float v = s_val[w][t];
+      const int j = s_grp[w][t];
+      if (v < bv || (v == bv && j < bj)) { bv = v; bj = j; }
     }
+    // exact index inside the winning 4-reference group, re-evaluated with the same instruction sequence
+    const float x = qb[(size_t)qi * 3], y = qb[(size_t)qi * 3 + 1], z = qb[(size_t)qi * 3 + 2];
+    if (bj == 0x7fffffff) bj = rbeg;  // NaN inputs: nothing ever compared smaller
+    int idx = bj;
+    float e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(bj + u, rend - 1);
+      const float* p = rb + (size_t)j * 3;
+      e[u] = obman_dist2(x, y, z, p[0], p[1], p[2]);
+    }
+#pragma unroll
+    for (int u = 3; u >= 0; --u)  // descending so the FIRST matching index survives
+      if (bj + u < rend && e[u] == bv) idx = bj + u;
     const size_t o = (size_t)b * d.nq + qi;
     if (d.rsplit == 1) {
-      d.omin[o] = best[k];
+      d.omin[o] = bv;
       if (d.oidx) d.oidx[o] = idx;
     } else {
-      const u64 packed = ((u64)__float_as_uint(best[k]) << 32) | (unsigned)idx;
+      const u64 packed = ((u64)__float_as_uint(bv) << 32) | (unsigned)idx;
       atomicMin(&d.ws[o], packed);
     }
   }
@@ -153,28 +179,23 @@ struct PmBwdSide {
 
 constexpr int PB_TILE = 1024;
 
+// Block = 4 waves over the same 64 own points; each wave scans a quarter of the other side's arg-mins
+// (owner scan, ascending), partial sums are added in fixed wave order => deterministic.
 __global__ __launch_bounds__(256) void pairmin_bwd_kernel(PmBwdSide s0, PmBwdSide s1) {
   const PmBwdSide s = blockIdx.z == 0 ? s0 : s1;
   if (s.grad == nullptr) return;
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int i = blockIdx.x * 256 + tid;
-  if (blockIdx.x * 256 >= s.n) return;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x * 64 >= s.n) return;
+  const int i = blockIdx.x * 64 + lane;
   const float* __restrict__ pb = s.p + (size_t)b * s.n * 3;
   const float* __restrict__ ob = s.o + (size_t)b * s.m * 3;
   const int ic = i < s.n ? i : s.n - 1;
   const float px = pb[(size_t)ic * 3], py = pb[(size_t)ic * 3 + 1], pz = pb[(size_t)ic * 3 + 2];
   float gx = 0.f, gy = 0.f, gz = 0.f;
-  if (s.g_own) {
-    const float w = s.per_sample ? s.g_own[b] / (float)s.n : s.g_own[(size_t)b * s.n + ic];
-    const int j = s.idx_own[(size_t)b * s.n + ic];
-    const float w2 = 2.f * w;
-    gx = w2 * (px - ob[(size_t)j * 3]);
-    gy = w2 * (py - ob[(size_t)j * 3 + 1]);
-    gz = w2 * (pz - ob[(size_t)j * 3 + 2]);
-  }
-  if (s.g_other) {  // owner scan: every own point collects the other points that chose it, ascending j
-    __shared__ float4 so[PB_TILE];
-    __shared__ int sidx[PB_TILE];
+  __shared__ float4 so[PB_TILE];
+  __shared__ int sidx[PB_TILE];
+  __shared__ float s_acc[3][3][64];
+  if (s.g_other) {
     const float gs = s.per_sample ? 2.f * s.g_other[b] / (float)s.m : 0.f;
     for (int base = 0; base < s.m; base += PB_TILE) {
       const int cnt = min(PB_TILE, s.m - base);
@@ -185,7 +206,10 @@ __global__ __launch_bounds__(256) void pairmin_bwd_kernel(PmBwdSide s0, PmBwdSid
         sidx[t] = s.idx_other[(size_t)b * s.m + j];
       }
       __syncthreads();
-      for (int t = 0; t < cnt; ++t) {
+      const int slice = (cnt + 3) >> 2;
+      const int tend = min(cnt, (wave + 1) * slice);
+#pragma unroll 4
+      for (int t = wave * slice; t < tend; ++t) {
         const float4 v = so[t];
         const float w = sidx[t] == i ? v.w : 0.f;
         gx = __fmaf_rn(w, px - v.x, gx);
@@ -194,24 +218,41 @@ __global__ __launch_bounds__(256) void pairmin_bwd_kernel(PmBwdSide s0, PmBwdSid
       }
       __syncthreads();
     }
+    if (wave > 0) { s_acc[wave - 1][0][lane] = gx; s_acc[wave - 1][1][lane] = gy; s_acc[wave - 1][2][lane] = gz; }
+    __syncthreads();
+    if (wave == 0) {
+      gx = ((gx + s_acc[0][0][lane]) + s_acc[1][0][lane]) + s_acc[2][0][lane];
+      gy = ((gy + s_acc[0][1][lane]) + s_acc[1][1][lane]) + s_acc[2][1][lane];
+      gz = ((gz + s_acc[0][2][lane]) + s_acc[1][2][lane]) + s_acc[2][2][lane];
+    }
   }
-  if (i < s.n) {
-    float* g = s.grad + ((size_t)b * s.n + i) * 3;
-    g[0] = gx;
-    g[1] = gy;
-    g[2] = gz;
+  if (wave != 0 || i >= s.n) return;
+  if (s.g_own) {
+    const float w = s.per_sample ? s.g_own[b] / (float)s.n : s.g_own[(size_t)b * s.n + i];
+    const int j = s.idx_own[(size_t)b * s.n + i];
+    const float w2 = 2.f * w;
+    gx = __fmaf_rn(w2, px - ob[(size_t)j * 3], gx);
+    gy = __fmaf_rn(w2, py - ob[(size_t)j * 3 + 1], gy);
+    gz = __fmaf_rn(w2, pz - ob[(size_t)j * 3 + 2], gz);
   }
+  float* g = s.grad + ((size_t)b * s.n + i) * 3;
+  g[0] = gx;
+  g[1] = gy;
+  g[2] = gz;
 }
 
 int choose_qpt(int B, int nq_max) {
-  // enough blocks to cover 256 CUs a few times over; otherwise favour LDS reuse (more queries per lane)
+  // a block covers 64*QPT queries.  More queries per lane = fewer LDS reads per pair (VALU-bound from
+  // QPT 2 up); keep >= 2 blocks per CU in flight.  OBMAN_PM_QPT overrides (tuning only).
+  static const int forced = [] { const char* e = getenv("OBMAN_PM_QPT"); return e ? atoi(e) : 0; }();
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
   for (int qpt = 4; qpt > 1; qpt >>= 1)
-    if ((long)B * obman_cdiv(nq_max, PM_THREADS * qpt) >= 1024) return qpt;
+    if ((long)B * obman_cdiv(nq_max, 64 * qpt) >= 512) return qpt;
   return 1;
 }
 
 void plan_dir(PmDir& d, int B, int qpt, bool have_ws) {
-  d.qtiles = obman_cdiv(d.nq, PM_THREADS * qpt);
+  d.qtiles = obman_cdiv(d.nq, 64 * qpt);
   d.rsplit = 1;
   d.rchunk = d.nr;
   if (have_ws && d.omin) {
@@ -276,7 +317,7 @@ int launch_pairmin_bwd(const float* x, const float* y, int B, int Nx, int Ny, co
   PmBwdSide s1{y, x, idx_y, idx_x, g_y, g_x, grad_y, Ny, Nx, per_sample};
   const int n_max = (grad_x ? Nx : 0) > (grad_y ? Ny : 0) ? Nx : Ny;
   if (!grad_x && !grad_y) return 0;
-  dim3 grid(obman_cdiv(n_max, 256), B, 2);
+  dim3 grid(obman_cdiv(n_max, 64), B, 2);
   {
     ObmanProfScope prof(OBMAN_K_PAIRMIN_BWD, st);
     pairmin_bwd_kernel<<<grid, 256, 0, st>>>(s0, s1);

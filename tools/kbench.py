@@ -24,21 +24,71 @@ def timeit(fn, iters=50, warmup=10):
     return st.elapsed_time(en) * 1e-3 / iters
 
 
+def kernel_us(fn, kid, iters=30, warmup=5):
+    """Average device duration (us) of kernel id ``kid`` (csrc/prof.h) over ``iters`` calls of ``fn``."""
+    from obman_train_amd import _lib
+
+    for _ in range(warmup):
+        fn()
+    _lib.prof_enable(True)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    ms, n = _lib.prof_summary(kid)
+    _lib.prof_enable(False)
+    return ms * 1e3 / max(n, 1)
+
+
 def bench_chamfer():
     from obman_train_amd import ops
 
-    for B, n_p, n_g in ((64, 642, 600), (64, 16050, 600), (64, 64050, 600), (64, 2562, 600)):
+    for B, n_p, n_g in ((64, 642, 600), (64, 2562, 600), (64, 16050, 600), (64, 64050, 600)):
         p = (torch.randn(B, n_p, 3, device="cuda") * 40).requires_grad_()
         g = torch.randn(B, n_g, 3, device="cuda") * 40
-        t_f = timeit(lambda: ops.chamfer(p, g))
+        t_f = kernel_us(lambda: ops.chamfer(p, g), 1) * 1e-6
         l1, l2 = ops.chamfer(p, g)
         loss = (l1 + l2).mean()
-        t_b = timeit(lambda: torch.autograd.grad(loss, p, retain_graph=True))
+        t_b = kernel_us(lambda: torch.autograd.grad(loss, p, retain_graph=True), 2) * 1e-6
         pairs = 2.0 * B * n_p * n_g  # both directions evaluate every pair once
         print(json.dumps(dict(
-            kernel="chamfer", B=B, n_pred=n_p, n_gt=n_g, fwd_us=t_f * 1e6, bwd_us=t_b * 1e6,
-            fwd_alg_GBps=20.0 * (n_p + n_g) * B / t_f / 1e9, fwd_Gpairs_per_s=pairs / t_f / 1e9,
-            fwd_valu_TFLOPs=pairs * 8 / t_f / 1e12)))
+            kernel="chamfer", qpt=os.environ.get("OBMAN_PM_QPT", "auto"), B=B, n_pred=n_p, n_gt=n_g,
+            fwd_us=round(t_f * 1e6, 2), bwd_us=round(t_b * 1e6, 2),
+            fwd_alg_GBps=round(20.0 * (n_p + n_g) * B / t_f / 1e9, 1), fwd_Tpairs_per_s=round(pairs / t_f / 1e12, 3),
+            fwd_valu_TFLOPs=round(pairs * 5 / t_f / 1e12, 1))), flush=True)
+
+
+def bench_mano():
+    from obman_train_amd import ops
+    from obman_train_amd.mano_model import ManoModelBlob
+    from obman_train_amd.mano_params import synthetic_mano
+
+    blob = ManoModelBlob(synthetic_mano("right")).on("cuda")
+    for B in (64, 512):
+        pose = (torch.randn(B, 33, device="cuda") * 0.5).requires_grad_()
+        betas = torch.randn(B, 10, device="cuda").requires_grad_()
+        t_f = kernel_us(lambda: ops.mano_lbs(pose, betas, blob), 6)
+        v, j = ops.mano_lbs(pose, betas, blob)
+        loss = v.sum() + j.sum()
+        t_b = kernel_us(lambda: torch.autograd.grad(loss, (pose, betas), retain_graph=True), 7)
+        print(json.dumps(dict(kernel="mano_lbs", B=B, fwd_us=round(t_f, 2), bwd_us=round(t_b, 2))), flush=True)
+
+
+def bench_contains():
+    import numpy as np
+
+    from obman_train_amd import ops
+    from obman_train_amd.icosphere import multi_patch
+
+    for B, patches in ((64, 1), (64, 25)):
+        v, f = multi_patch(3, patches)
+        verts = torch.from_numpy(v.astype(np.float32)).cuda().unsqueeze(0).repeat(B, 1, 1) * 40
+        verts = verts + torch.randn(B, 1, 3, device="cuda") * 5
+        faces = torch.from_numpy(f.astype(np.int32)).cuda()
+        pts = torch.randn(B, 778, 3, device="cuda") * 35
+        t = kernel_us(lambda: ops.mesh_contains_hits(pts, verts, faces), 3)
+        pairs = B * 778.0 * f.shape[0]
+        print(json.dumps(dict(kernel="contains", B=B, F=int(f.shape[0]), us=round(t, 2),
+                              Gpairs_per_s=round(pairs / t / 1e3, 1), valu_TFLOPs=round(pairs * 50 / t / 1e6, 1))), flush=True)
 
 
 if __name__ == "__main__":
@@ -46,3 +96,7 @@ if __name__ == "__main__":
     torch.zeros(1, device="cuda")
     if which in ("chamfer", "all"):
         bench_chamfer()
+    if which in ("mano", "all"):
+        bench_mano()
+    if which in ("contains", "all"):
+        bench_contains()
