@@ -16,6 +16,8 @@
 namespace {
 
 constexpr int NV = 778, NE = 2334, NJ = 16, NPM = 135;
+constexpr int MT = 1024;            // threads per block (16 waves): one sample per block, 4x the loads in flight of a 256-thread block
+constexpr int MW = MT / 64;
 // model blob layout (float offsets) - mirrored by obman_train_amd/mano_model.py
 constexpr int OFF_COMPS = 0;                  // [45][45] PCA basis rows
 constexpr int OFF_MEAN = OFF_COMPS + 2025;    // [45]
@@ -83,7 +85,7 @@ __device__ __forceinline__ void rodrigues_bwd(const float* a, const float* G, fl
   ga[2] = gnz * inv + gtheta * sz * inv;
 }
 
-__global__ __launch_bounds__(256) void mano_fwd_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
+__global__ __launch_bounds__(MT) void mano_fwd_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
                                                        const int* __restrict__ side, const float* __restrict__ pose,
                                                        const float* __restrict__ betas, int npose, int ncomps, int use_pca,
                                                        int center_idx, int root_palm, float* __restrict__ verts,
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(const float* __restrict__
     for (int k = 0; k < 3; ++k) s_Gt[k] = s_J[k];
   }
   // blend shapes: v_posed[e] = T[e] + sum_k S[k][e] beta[k] + sum_k P[k][e] pose_map[k]
-  for (int e = tid; e < NE; e += 256) {
+  for (int e = tid; e < NE; e += MT) {
     float acc = M[OFF_VT + e];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc = __fmaf_rn(M[OFF_SD + k * NE + e], s_beta[k], acc);
@@ -175,13 +177,13 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(const float* __restrict__
   }
   if (state) {
     float* st = state + (size_t)b * OBMAN_MANO_STATE_FLOATS;
-    for (int k = tid; k < 144; k += 256) { st[S_R + k] = s_R[k]; st[S_GR + k] = s_GR[k]; }
+    for (int k = tid; k < 144; k += MT) { st[S_R + k] = s_R[k]; st[S_GR + k] = s_GR[k]; }
     if (tid < 48) { st[S_J + tid] = s_J[tid]; st[S_GT + tid] = s_Gt[tid]; st[S_AA + tid] = s_aa[tid]; }
-    for (int e = tid; e < NE; e += 256) st[S_VP + e] = s_vp[e];
+    for (int e = tid; e < NE; e += MT) st[S_VP + e] = s_vp[e];
   }
   __syncthreads();
   // skinning: one vertex per lane
-  for (int v = tid; v < NV; v += 256) {
+  for (int v = tid; v < NV; v += MT) {
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = 0.f;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(const float* __restrict__
     cx = s_jc[src * 3]; cy = s_jc[src * 3 + 1]; cz = s_jc[src * 3 + 2];
   }
   float* vo = verts + (size_t)b * NE;
-  for (int e = tid; e < NE; e += 256) {
+  for (int e = tid; e < NE; e += MT) {
     const int c = e % 3;
     vo[e] = (s_vp[e] - (c == 0 ? cx : (c == 1 ? cy : cz))) * 1000.f;
   }
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void mano_bwd_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
+__global__ __launch_bounds__(MT) void mano_bwd_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
                                                        const int* __restrict__ side, const float* __restrict__ state,
                                                        const float* __restrict__ g_verts, const float* __restrict__ g_joints,
                                                        int npose, int ncomps, int use_pca, int center_idx, int root_palm,
@@ -242,18 +244,18 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(const float* __restrict__
   __shared__ float s_R[144], s_J[48], s_GR[144], s_Gt[48], s_aa[48];
   __shared__ float s_vp[NE], s_gv[NE];          // posed rest shape; grads of skinned verts, later of v_posed
   __shared__ float s_gj[63], s_cat[63];         // joint grads (21-order) and un-reordered
-  __shared__ float s_red[4][4];                 // centre reduction
-  __shared__ float s_part[4][NJ][12];           // per-wave partial joint-transform grads
+  __shared__ float s_red[MW][4];                 // centre reduction
+  __shared__ float s_part[MW][NJ][12];           // per-wave partial joint-transform grads
   __shared__ float s_gGR[144], s_gGt[48], s_gtrel[48], s_gJ[48], s_gR[144];
   __shared__ float s_root[5][16];               // per-finger contributions to the root (9 + 3 + 3)
   __shared__ float s_gpm[NPM + 10], s_gaa[48];
 
-  for (int k = tid; k < 144; k += 256) { s_R[k] = st[S_R + k]; s_GR[k] = st[S_GR + k]; }
+  for (int k = tid; k < 144; k += MT) { s_R[k] = st[S_R + k]; s_GR[k] = st[S_GR + k]; }
   if (tid < 48) { s_J[tid] = st[S_J + tid]; s_Gt[tid] = st[S_GT + tid]; s_aa[tid] = st[S_AA + tid]; }
-  for (int e = tid; e < NE; e += 256) s_vp[e] = st[S_VP + e];
+  for (int e = tid; e < NE; e += MT) s_vp[e] = st[S_VP + e];
   // phase 0: scale, centre
   float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int v = tid; v < NV; v += 256) {
+  for (int v = tid; v < NV; v += MT) {
     float gx = 0.f, gy = 0.f, gz = 0.f;
     if (g_verts) {
       const float* g = g_verts + (size_t)b * NE + v * 3;
@@ -269,7 +271,8 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(const float* __restrict__
   if (tid == 0) {
     if (center_idx >= 0) {
       for (int c = 0; c < 3; ++c) {
-        float tot = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+        float tot = 0.f;
+        for (int w = 0; w < MW; ++w) tot += s_red[w][c];
         for (int j = 0; j < 21; ++j) tot += s_gj[j * 3 + c];
         s_gj[center_idx * 3 + c] -= tot;
       }
@@ -293,50 +296,35 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(const float* __restrict__
   }
   __syncthreads();
   // phase 2: skinning backward.  verts[v] = sum_i w_vi (GR_i vp_v + trel_i)
-  float gvx[4], gvy[4], gvz[4], px[4], py[4], pz[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int v = tid + it * 256;
-    const bool ok = v < NV;
-    gvx[it] = ok ? s_gv[v * 3] : 0.f; gvy[it] = ok ? s_gv[v * 3 + 1] : 0.f; gvz[it] = ok ? s_gv[v * 3 + 2] : 0.f;
-    px[it] = ok ? s_vp[v * 3] : 0.f;  py[it] = ok ? s_vp[v * 3 + 1] : 0.f;  pz[it] = ok ? s_vp[v * 3 + 2] : 0.f;
-  }
+  static_assert(MT >= NV, "one vertex per lane");
+  const bool vok = tid < NV;
+  const float gvx = vok ? s_gv[tid * 3] : 0.f, gvy = vok ? s_gv[tid * 3 + 1] : 0.f, gvz = vok ? s_gv[tid * 3 + 2] : 0.f;
+  const float px = vok ? s_vp[tid * 3] : 0.f, py = vok ? s_vp[tid * 3 + 1] : 0.f, pz = vok ? s_vp[tid * 3 + 2] : 0.f;
   __syncthreads();  // every lane has its s_gv in registers: s_gv can now receive d(loss)/d(v_posed)
-  float gpx[4] = {0, 0, 0, 0}, gpy[4] = {0, 0, 0, 0}, gpz[4] = {0, 0, 0, 0};
+  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+#pragma unroll 4
   for (int i = 0; i < NJ; ++i) {
-    float acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     const float* G = &s_GR[i * 9];
+    const float wji = vok ? M[OFF_W + i * NV + tid] : 0.f;
+    const float wx = wji * gvx, wy = wji * gvy, wz = wji * gvz;
+    float acc[12] = {wx * px, wx * py, wx * pz, wy * px, wy * py, wy * pz, wz * px, wz * py, wz * pz, wx, wy, wz};
+    gpx += G[0] * wx + G[3] * wy + G[6] * wz;  // d/d(v_posed) = sum_i w GR_i^T gv
+    gpy += G[1] * wx + G[4] * wy + G[7] * wz;
+    gpz += G[2] * wx + G[5] * wy + G[8] * wz;
+    if (wave < (NV + 63) / 64) {  // waves beyond the last vertex contribute zeros
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int v = tid + it * 256;
-      const float w = v < NV ? M[OFF_W + i * NV + v] : 0.f;
-      const float wx = w * gvx[it], wy = w * gvy[it], wz = w * gvz[it];
-      acc[0] = __fmaf_rn(wx, px[it], acc[0]); acc[1] = __fmaf_rn(wx, py[it], acc[1]); acc[2] = __fmaf_rn(wx, pz[it], acc[2]);
-      acc[3] = __fmaf_rn(wy, px[it], acc[3]); acc[4] = __fmaf_rn(wy, py[it], acc[4]); acc[5] = __fmaf_rn(wy, pz[it], acc[5]);
-      acc[6] = __fmaf_rn(wz, px[it], acc[6]); acc[7] = __fmaf_rn(wz, py[it], acc[7]); acc[8] = __fmaf_rn(wz, pz[it], acc[8]);
-      acc[9] += wx; acc[10] += wy; acc[11] += wz;
-      // d/d(v_posed) = sum_i w GR_i^T gv
-      gpx[it] += G[0] * wx + G[3] * wy + G[6] * wz;
-      gpy[it] += G[1] * wx + G[4] * wy + G[7] * wz;
-      gpz[it] += G[2] * wx + G[5] * wy + G[8] * wz;
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const float r = obman_wave_sum(acc[k]);
-      if (lane == 0) s_part[wave][i][k] = r;
+      for (int k = 0; k < 12; ++k) {
+        const float r = obman_wave_sum(acc[k]);
+        if (lane == 0) s_part[wave][i][k] = r;
+      }
     }
   }
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int v = tid + it * 256;
-    if (v < NV) { s_gv[v * 3] = gpx[it]; s_gv[v * 3 + 1] = gpy[it]; s_gv[v * 3 + 2] = gpz[it]; }
-  }
+  if (vok) { s_gv[tid * 3] = gpx; s_gv[tid * 3 + 1] = gpy; s_gv[tid * 3 + 2] = gpz; }
   __syncthreads();
   if (tid < NJ * 12) {
     const int i = tid / 12, k = tid % 12;
-    const float r = (s_part[0][i][k] + s_part[1][i][k]) + (s_part[2][i][k] + s_part[3][i][k]);
+    float r = 0.f;
+    for (int w = 0; w < (NV + 63) / 64; ++w) r += s_part[w][i][k];
     if (k < 9) s_gGR[i * 9 + k] = r; else s_gtrel[i * 3 + k - 9] = r;
   }
   __syncthreads();
@@ -413,7 +401,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(const float* __restrict__
   __syncthreads();
   if (tid < 3) s_gJ[tid] += s_gGt[tid];
   // phase 6: d/d(pose_map[k]) = <P[k], g_vp>, d/d(beta[k]) = <S[k], g_vp> (+ joint path): one row per wave pass
-  for (int row = wave; row < NPM + 10; row += 4) {
+  for (int row = wave; row < NPM + 10; row += MW) {
     const float* basis = row < NPM ? M + OFF_PD + (size_t)row * NE : M + OFF_SD + (size_t)(row - NPM) * NE;
     float a0 = 0.f, a1 = 0.f;
     int e = lane;
@@ -472,7 +460,7 @@ int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const 
   if (B == 0) return 0;
   const int npose = 3 + (use_pca ? ncomps : 45);
   ObmanProfScope prof(OBMAN_K_MANO_FWD, (hipStream_t)stream);
-  mano_fwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(model_right, model_left, side, pose, betas, npose, ncomps, use_pca,
+  mano_fwd_kernel<<<B, MT, 0, (hipStream_t)stream>>>(model_right, model_left, side, pose, betas, npose, ncomps, use_pca,
                                                        center_idx, root_palm, verts, joints, state);
   OBMAN_LAUNCH_CHECK();
   return 0;
@@ -487,7 +475,7 @@ int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const 
   if (B == 0) return 0;
   const int npose = 3 + (use_pca ? ncomps : 45);
   ObmanProfScope prof(OBMAN_K_MANO_BWD, (hipStream_t)stream);
-  mano_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(model_right, model_left, side, state, g_verts, g_joints, npose, ncomps,
+  mano_bwd_kernel<<<B, MT, 0, (hipStream_t)stream>>>(model_right, model_left, side, state, g_verts, g_joints, npose, ncomps,
                                                        use_pca, center_idx, root_palm, g_pose, g_betas);
   OBMAN_LAUNCH_CHECK();
   return 0;

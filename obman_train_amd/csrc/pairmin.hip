@@ -31,7 +31,7 @@ struct PmDir {
   float* omin;     // [B,nq] or null (direction skipped)
   int* oidx;       // [B,nq] or null
   u64* ws;         // packed scratch when rsplit > 1
-  int nq, nr, qtiles, rsplit, rchunk;
+  int nq, nr, qtiles, rsplit, rchunk, tile;
 };
 
 // Block = 4 waves.  All 4 waves hold the SAME 64*QPT queries (lane l owns queries l, l+64, ..) and each
@@ -50,9 +50,11 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
   const float* __restrict__ qb = d.q + (size_t)b * d.nq * 3;
   const float* __restrict__ rb = d.r + (size_t)b * d.nr * 3;
 
-  __shared__ float4 sref[PM_REF_TILE];
-  __shared__ float s_val[4][64 * QPT];
-  __shared__ int s_grp[4][64 * QPT];
+  // dynamic LDS sized to the reference tile actually used (642 refs -> 10 KiB: 8 blocks / 32 waves per CU)
+  extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+  float4* sref = reinterpret_cast<float4*>(pm_smem);
+  float(*s_val)[64 * QPT] = reinterpret_cast<float(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4));
+  int(*s_grp)[64 * QPT] = reinterpret_cast<int(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4) + 4 * 64 * QPT * sizeof(float));
 
   float qx[QPT], qy[QPT], qz[QPT], best[QPT];
   int bestj[QPT];
@@ -69,8 +71,9 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
 
   const int rbeg = rs * d.rchunk;
   const int rend = min(d.nr, rbeg + d.rchunk);
-  for (int base = rbeg; base < rend; base += PM_REF_TILE) {
-    const int cnt = min(PM_REF_TILE, rend - base);
+  const bool single = rend - rbeg <= d.tile;  // whole reference range stays in LDS: resolve indices from it
+  for (int base = rbeg; base < rend; base += d.tile) {
+    const int cnt = min(d.tile, rend - base);
     const int slice = ((cnt + 15) >> 4) << 2;  // references per wave, multiple of 4
     const int padded = slice * 4;
     for (int i = tid; i < padded; i += PM_THREADS) {
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
 #pragma unroll 2
     for (int j = jbeg; j < jend; j += 4) {
       const float4 r0 = sref[j], r1 = sref[j + 1], r2 = sref[j + 2], r3 = sref[j + 3];
+      asm volatile("" ::"v"(r0.w), "v"(r1.w), "v"(r2.w), "v"(r3.w));  // keep the reads ds_read_b128 (b96 is 2x the LDS cycles)
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
         const float e0 = obman_dist2(qx[k], qy[k], qz[k], r0.x, r0.y, r0.z);
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
         bestj[k] = better ? base + j : bestj[k];
       }
     }
-    __syncthreads();
+    if (!single) __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < QPT; ++k) {
@@ -125,8 +129,13 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = min(bj + u, rend - 1);
-      const float* p = rb + (size_t)j * 3;
-      e[u] = obman_dist2(x, y, z, p[0], p[1], p[2]);
+      if (single) {
+        const float4 r = sref[j - rbeg];
+        e[u] = obman_dist2(x, y, z, r.x, r.y, r.z);
+      } else {
+        const float* p = rb + (size_t)j * 3;
+        e[u] = obman_dist2(x, y, z, p[0], p[1], p[2]);
+      }
     }
 #pragma unroll
     for (int u = 3; u >= 0; --u)  // descending so the FIRST matching index survives
@@ -255,6 +264,7 @@ void plan_dir(PmDir& d, int B, int qpt, bool have_ws) {
   d.qtiles = obman_cdiv(d.nq, 64 * qpt);
   d.rsplit = 1;
   d.rchunk = d.nr;
+  d.tile = PM_REF_TILE;
   if (have_ws && d.omin) {
     const long blocks = (long)B * d.qtiles;
     if (blocks < 512 && d.nr >= 4 * PM_REF_TILE) {
@@ -272,8 +282,8 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   if (B < 0 || Nx < 0 || Ny < 0) return -1;
   if (B == 0) return 0;
   if (Nx == 0 || Ny == 0) return -2;  // torch.min over an empty dim raises in the reference
-  PmDir d0{x, y, min_x, idx_x, nullptr, Nx, Ny, 0, 1, Ny};
-  PmDir d1{y, x, min_y, idx_y, nullptr, Ny, Nx, 0, 1, Nx};
+  PmDir d0{x, y, min_x, idx_x, nullptr, Nx, Ny, 0, 1, Ny, PM_REF_TILE};
+  PmDir d1{y, x, min_y, idx_y, nullptr, Ny, Nx, 0, 1, Nx, PM_REF_TILE};
   const int nq_max = (min_x ? Nx : 0) > (min_y ? Ny : 0) ? Nx : Ny;
   const int qpt = choose_qpt(B, nq_max);
   const bool have_ws = ws && ws_bytes >= (long)sizeof(u64) * B * ((long)Nx + Ny);
@@ -286,12 +296,18 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   const int gx0 = min_x ? d0.qtiles * d0.rsplit : 0, gx1 = min_y ? d1.qtiles * d1.rsplit : 0;
   dim3 grid(gx0 > gx1 ? gx0 : gx1, B, 2);
   if (grid.x == 0) return 0;
+  // one LDS tile size for both directions: the longest per-block reference range, rounded to 16, capped
+  const int need0 = min_x ? d0.rchunk : 0, need1 = min_y ? d1.rchunk : 0;
+  int tile = ((((need0 > need1 ? need0 : need1) + 15) / 16) * 16);
+  if (tile > PM_REF_TILE) tile = PM_REF_TILE;
+  d0.tile = d1.tile = tile;
+  const size_t smem = (size_t)tile * sizeof(float4) + (size_t)8 * 64 * qpt * sizeof(float);
   {
     ObmanProfScope prof(OBMAN_K_PAIRMIN_FWD, st);
     switch (qpt) {
-      case 4: pairmin_fwd_kernel<4><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
-      case 2: pairmin_fwd_kernel<2><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
-      default: pairmin_fwd_kernel<1><<<grid, PM_THREADS, 0, st>>>(d0, d1); break;
+      case 4: pairmin_fwd_kernel<4><<<grid, PM_THREADS, smem, st>>>(d0, d1); break;
+      case 2: pairmin_fwd_kernel<2><<<grid, PM_THREADS, smem, st>>>(d0, d1); break;
+      default: pairmin_fwd_kernel<1><<<grid, PM_THREADS, smem, st>>>(d0, d1); break;
     }
   }
   OBMAN_LAUNCH_CHECK();

@@ -28,7 +28,8 @@ def make_optimizer(model, name="adam", lr=1e-4, momentum=0.9, weight_decay=0.0):
     """traineval.py:104-127 (defaults nets3dopts.py:249-273)."""
     params = [p for p in model.parameters() if p.requires_grad]
     if name == "adam":
-        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
+        fused = all(p.is_cuda for p in params)  # one multi-tensor kernel instead of ~10 foreach launches per step
+        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
     if name == "rms":
         return torch.optim.RMSprop(params, lr=lr, weight_decay=weight_decay)
     if name == "sgd":
