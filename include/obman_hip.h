@@ -109,6 +109,36 @@ int obman_contact_bwd(const float* hand, const float* obj, const int* idx21, con
                       int B, int V, int N, int contact_mode, float contact_thresh, int collision_mode,
                       float collision_thresh, int target, float* grad_hand, float* grad_obj, obman_stream_t stream);
 
+/* ---- K6: AtlasNet PointGenCon decoder (fp32 MFMA) ---------------------------------------------------
+ * Replaces atlasbranch.py:117-132 (grid/feature repeat + concat) + PointGenCon.forward (atlasutils.py:65-75):
+ * 4 pointwise convs C1 -> C1 -> C1/2 -> C1/4 -> 3 with BatchNorm1d + ReLU after the first three, x out_factor.
+ * C1 = 3 + feature size (515).  grid [N,3] is the shared sphere template, feat [B,C1-3]; weights are the conv
+ * weights [Cout,Cin] (kernel size 1 squeezed), BN gamma/beta/running stats per layer.  training != 0: batch
+ * statistics (running stats updated in place with `momentum`); else running statistics.  out [B,N,3].
+ * ws: obman_pointgen_ws_floats(p, 0) floats, written by fwd and read by bwd; ws2: ..._ws_floats(p, 1) scratch. */
+typedef struct {
+  int B, N, C1, training;
+  float eps, momentum, out_factor;
+  const float *grid, *feat;
+  const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+  const float* bn_w[3];
+  const float* bn_b[3];
+  float* bn_rm[3];
+  float* bn_rv[3];
+} obman_pointgen_params;
+
+typedef struct {  /* gradient outputs of obman_pointgen_bwd, same shapes as the parameters; feat may be NULL */
+  float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+  float* bn_w[3];
+  float* bn_b[3];
+  float* feat;
+} obman_pointgen_grads;
+
+long obman_pointgen_ws_floats(const obman_pointgen_params* p, int backward);
+int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, obman_stream_t stream);
+int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const float* ws, float* ws2,
+                       const obman_pointgen_grads* g, obman_stream_t stream);
+
 /* ---- measurement utility (not on the product path) ----------------------------------------------
  * obman_prof_enable(1) makes the launchers bracket their main kernel with HIP events on the launch
  * stream (pool of 8192 records, reset by every enable call); obman_prof_summary synchronises and

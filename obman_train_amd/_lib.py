@@ -22,6 +22,9 @@ _SIGNATURES = {
     "obman_mesh_contains_fwd": (_c_int, "ppp" "iiii" "pp"),
     "obman_contact_fwd": (_c_int, "ppppp" "iii" "pp" "ii" "ifif" "ppppp" "p"),
     "obman_contact_bwd": (_c_int, "pppppppp" "iii" "ifif" "i" "pp" "p"),
+    "obman_pointgen_ws_floats": (_c_long, "pi"),
+    "obman_pointgen_fwd": (_c_int, "pppp"),
+    "obman_pointgen_bwd": (_c_int, "pppppp"),
     "obman_prof_enable": (_c_int, "i"),
     "obman_prof_summary": (_c_int, "ipp"),
     "obman_mano_model_floats": (_c_int, ""),
@@ -31,6 +34,20 @@ _SIGNATURES = {
 }
 _KIND = {"p": _c_void_p, "i": _c_int, "l": _c_long, "f": _c_float}
 _lib = None
+_fp = ctypes.c_void_p
+
+
+class PointGenParams(ctypes.Structure):  # obman_pointgen_params
+    _fields_ = [("B", _c_int), ("N", _c_int), ("C1", _c_int), ("training", _c_int),
+                ("eps", _c_float), ("momentum", _c_float), ("out_factor", _c_float),
+                ("grid", _fp), ("feat", _fp),
+                ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("w4", _fp), ("b4", _fp),
+                ("bn_w", _fp * 3), ("bn_b", _fp * 3), ("bn_rm", _fp * 3), ("bn_rv", _fp * 3)]
+
+
+class PointGenGrads(ctypes.Structure):  # obman_pointgen_grads
+    _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("w4", _fp), ("b4", _fp),
+                ("bn_w", _fp * 3), ("bn_b", _fp * 3), ("feat", _fp)]
 
 
 class ObmanHipError(RuntimeError):

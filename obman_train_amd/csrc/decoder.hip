@@ -1,0 +1,835 @@
+// K6 - AtlasNet PointGenCon decoder (atlasutils.py:42-75 + atlasbranch.py:117-132), gfx950, fp32 MFMA.
+//
+//   x[b,:,n] = (grid[n] (3) | feature[b] (C1-3))          -> never materialised (84 MB at bs 64)
+//   h1 = W1 x + b1 = G[n,:] + F[b,:]                       -> two small factors, BN-1 batch statistics in
+//                                                             closed form (mean and variance over the product
+//                                                             set B x N are sums of the two factors' moments)
+//   a1 = relu(bn1(h1))                                      -> generated ON THE FLY inside GEMM-2's A-tile loader
+//   h2 = W2 a1 + b2   (R x 515 x 257, R = B*N rows)         -> v_mfma_f32_32x32x2_f32, fp64 column moments in the
+//   a2 = relu(bn2(h2))                                         epilogue (BN-2 needs batch statistics)
+//   h3 = W3 a2 + b3   (R x 257 x 128)                       -> A-tile loader applies BN-2 + ReLU on load
+//   out = 200 * (W4 relu(bn3(h3)) + b4)   (K=128, N=3)      -> VALU row kernel
+//
+// Backward mirrors this: every BN/ReLU backward is folded into the operand loaders of the data-gradient
+// GEMMs (rows x Cout x Cin) and weight-gradient GEMMs (contraction over the R rows, split-K, fixed-order
+// reduction => deterministic); only h2, h3 (forward) and the masked gradients gy2, gy1 are materialised.
+// fp32 in / fp32 accumulate MFMA (exact fp32 fma chains): 157 TF peak = the fp32 vector rate, but it
+// leaves the VALU free for the fused loaders/epilogues.  Tile: 128 x 64 x 32, 4 waves (2x2), each wave
+// 64 x 32 = two 32x32 accumulators; LDS tiles k-major with +1 padding (conflict-free b32 reads/writes).
+#include "common.h"
+#include "prof.h"
+#include "../../include/obman_hip.h"
+
+namespace dec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BM = 128, BN = 64, BK = 32, NT = 256;
+
+__host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
+
+// ------------------------------------------------------------------------------------------------ A operands
+struct AGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k]),  r = b*N + n  (Gx, Fx are x-hat factors)
+  const float *Gx, *Fx, *gamma, *beta;
+  int N, ld, R, K;
+  struct Row { int g, f; };
+  __device__ Row row(int r) const {
+    if (r >= R) return Row{-1, -1};
+    const int b = r / N;
+    return Row{(r - b * N) * ld, b * ld};
+  }
+  __device__ float load(const Row& w, int k) const {
+    if (w.g < 0 || k >= K) return 0.f;
+    return fmaxf(__fmaf_rn(gamma[k], Gx[w.g + k] + Fx[w.f + k], beta[k]), 0.f);
+  }
+};
+struct ABnRelu {  // a[r,k] = relu(s[k] * H[r,k] + t[k])
+  const float *H, *s, *t;
+  int ld, R, K;
+  struct Row { long o; };
+  __device__ Row row(int r) const { return Row{r < R ? (long)r * ld : -1}; }
+  __device__ float load(const Row& w, int k) const {
+    if (w.o < 0 || k >= K) return 0.f;
+    return fmaxf(__fmaf_rn(s[k], H[w.o + k], t[k]), 0.f);
+  }
+};
+struct APlain {  // a[r,k] = X[r,k]
+  const float* X;
+  int ld, R, K;
+  struct Row { long o; };
+  __device__ Row row(int r) const { return Row{r < R ? (long)r * ld : -1}; }
+  __device__ float load(const Row& w, int k) const { return (w.o < 0 || k >= K) ? 0.f : X[w.o + k]; }
+};
+// d(loss)/d(h) of a BatchNorm'd layer from the masked upstream gradient gy = d/d(y) * (y>0):
+//   train: gh = k1 * (gy - k2 - xhat * k3),  k1 = gamma*rstd, k2 = mean_r(gy), k3 = mean_r(gy*xhat)
+//   eval : gh = k1 * gy                       (k2 = k3 = 0)
+struct AGradH {  // gy materialised
+  const float *GY, *H, *mean, *rstd, *k1, *k2, *k3;
+  int ld, R, K;
+  struct Row { long o; };
+  __device__ Row row(int r) const { return Row{r < R ? (long)r * ld : -1}; }
+  __device__ float load(const Row& w, int k) const {
+    if (w.o < 0 || k >= K) return 0.f;
+    const float xh = (H[w.o + k] - mean[k]) * rstd[k];
+    return k1[k] * (GY[w.o + k] - k2[k] - xh * k3[k]);
+  }
+};
+struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o] = f*(g[r,:].W4[:,o]) * (y3 > 0)
+  const float *G, *W4, *H, *s, *t, *mean, *rstd, *k1, *k2, *k3;
+  float f;
+  int ld, R, K;
+  struct Row { long o; float g0, g1, g2; };
+  __device__ Row row(int r) const {
+    if (r >= R) return Row{-1, 0.f, 0.f, 0.f};
+    return Row{(long)r * ld, f * G[(long)r * 3], f * G[(long)r * 3 + 1], f * G[(long)r * 3 + 2]};
+  }
+  __device__ float load(const Row& w, int k) const {
+    if (w.o < 0 || k >= K) return 0.f;
+    const float h = H[w.o + k];
+    const float gy = __fmaf_rn(s[k], h, t[k]) > 0.f ? (w.g0 * W4[k] + w.g1 * W4[K + k] + w.g2 * W4[2 * K + k]) : 0.f;
+    const float xh = (h - mean[k]) * rstd[k];
+    return k1[k] * (gy - k2[k] - xh * k3[k]);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ epilogues
+struct EpiStore {  // C[r, n] = acc + bias[n]; optional fp64 column moments (sum, sum of squares) per row-block
+  float* C;
+  const float* bias;
+  double* moments;  // [row_blocks][Nc][2] or null
+  int ldc, R, Nc;
+};
+struct EpiMaskStats {  // C = acc * (y > 0); per row-block column sums S1 = sum(C), S2 = sum(C * xhat)
+  float* C;
+  double* sums;  // [row_blocks][Nc][2]
+  int ldc, R, Nc;
+  int mode;      // 0: y = s*H+t, xhat = (H-mean)*rstd ; 1: xhat = Gx[n]+Fx[b], y = gamma*xhat+beta
+  const float *H, *s, *t, *mean, *rstd;   // mode 0 (ld = ldc)
+  const float *Gx, *Fx, *gamma, *beta;    // mode 1 (ld = ldc)
+  int N;
+};
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// LDS tiles (k-major, +1 pad): As[buf][k][m], Bs[buf][k][n]
+struct Tiles {
+  float As[2][BK][BM + 1];
+  float Bs[2][BK][BN + 1];
+};
+
+// C[R x Nc] = Aop[R x K] * B, B given either as W[n][k] (B_NK, ldb = row stride of W) or W[k][n] (B_KN).
+template <class AOp, bool B_NK, class Epi>
+__global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __restrict__ Bw, int ldb, int K, int Nc, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Tiles& T = *reinterpret_cast<Tiles*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+
+  // A staging: element e = tid + 256 p, k = e % 32, m = e / 32  (16 rows per thread, fixed k)
+  const int ak = tid & 31, am0 = tid >> 5;
+  typename AOp::Row rows[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) rows[p] = aop.row(bm0 + am0 + 8 * p);
+  float ra[16], rb[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) ra[p] = aop.load(rows[p], k0 + ak);
+    if (B_NK) {  // W[n][k]: consecutive lanes along k
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int n = bn0 + (tid >> 5) + 8 * p, k = k0 + ak;
+        rb[p] = (n < Nc && k < K) ? Bw[(size_t)n * ldb + k] : 0.f;
+      }
+    } else {  // W[k][n]: consecutive lanes along n
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int n = bn0 + (tid & 63), k = k0 + (tid >> 6) + 4 * p;
+        rb[p] = (n < Nc && k < K) ? Bw[(size_t)k * ldb + n] : 0.f;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) T.As[buf][ak][am0 + 8 * p] = ra[p];
+    if (B_NK) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) T.Bs[buf][ak][(tid >> 5) + 8 * p] = rb[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) T.Bs[buf][(tid >> 6) + 4 * p][tid & 63] = rb[p];
+    }
+  };
+
+  f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+  const int nk = (K + BK - 1) / BK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) fetch((kt + 1) * BK);
+    const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float b = T.Bs[cur][kk + kh][bcol];
+      const float a0 = T.As[cur][kk + kh][arow];
+      const float a1 = T.As[cur][kk + kh][arow + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
+    if (kt + 1 < nk) stash(cur ^ 1);
+    __syncthreads();
+  }
+  epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, tid, smem);
+}
+
+// ---- epilogue bodies (members defined here to keep the kernel readable)
+struct EpiStoreImpl : EpiStore {
+  __device__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
+    const int col = c0 + (lane & 31);
+    const float bv = (bias && col < Nc) ? bias[col] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = r0 + t * 32 + acc_row(reg, lane);
+        const float v = (t == 0 ? a0[reg] : a1[reg]) + bv;
+        if (r < R && col < Nc) {
+          C[(size_t)r * ldc + col] = v;
+          s1 += (double)v;
+          s2 += (double)v * (double)v;
+        }
+      }
+    }
+    if (moments) {
+      // combine lane l and l^32 (same column, other rows), then the two M-waves through LDS
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      double* red = reinterpret_cast<double*>(smem);  // tiles are dead after the last barrier
+      __syncthreads();
+      if (wm == 1 && lane < 32) { red[(wn * 32 + lane) * 2] = s1; red[(wn * 32 + lane) * 2 + 1] = s2; }
+      __syncthreads();
+      if (wm == 0 && lane < 32 && col < Nc) {
+        double* dst = moments + ((size_t)blockIdx.x * Nc + col) * 2;
+        dst[0] = s1 + red[(wn * 32 + lane) * 2];
+        dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
+      }
+    }
+  }
+};
+
+struct EpiMaskStatsImpl : EpiMaskStats {
+  __device__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
+    const int col = c0 + (lane & 31);
+    const bool cok = col < Nc;
+    double s1 = 0.0, s2 = 0.0;
+    float c_s = 0.f, c_t = 0.f, c_m = 0.f, c_r = 0.f;
+    if (cok) {
+      if (mode == 0) { c_s = s[col]; c_t = t[col]; c_m = mean[col]; c_r = rstd[col]; }
+      else { c_s = gamma[col]; c_t = beta[col]; }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = r0 + tt * 32 + acc_row(reg, lane);
+        if (r < R && cok) {
+          float xh, y;
+          if (mode == 0) {
+            const float h = H[(size_t)r * ldc + col];
+            y = __fmaf_rn(c_s, h, c_t);
+            xh = (h - c_m) * c_r;
+          } else {
+            const int b = r / N, n = r - b * N;
+            xh = Gx[(size_t)n * ldc + col] + Fx[(size_t)b * ldc + col];
+            y = __fmaf_rn(c_s, xh, c_t);
+          }
+          const float v = y > 0.f ? (tt == 0 ? a0[reg] : a1[reg]) : 0.f;
+          C[(size_t)r * ldc + col] = v;
+          s1 += (double)v;
+          s2 += (double)v * (double)xh;
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    double* red = reinterpret_cast<double*>(smem);
+    __syncthreads();
+    if (wm == 1 && lane < 32) { red[(wn * 32 + lane) * 2] = s1; red[(wn * 32 + lane) * 2 + 1] = s2; }
+    __syncthreads();
+    if (wm == 0 && lane < 32 && cok) {
+      double* dst = sums + ((size_t)blockIdx.x * Nc + col) * 2;
+      dst[0] = s1 + red[(wn * 32 + lane) * 2];
+      dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+// C[M x Nc] (+)= sum_r Aop[r, m] * Bop[r, n] over a chunk of rows; partial results per row-chunk (split-K), summed
+// afterwards in chunk order (deterministic).  Tiles: the contraction index is the row r.
+template <class AOp, class BOp>
+__global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, int Nc, int R, int rows_per_chunk, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Tiles& T = *reinterpret_cast<Tiles*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int mt = (M + BM - 1) / BM;
+  const int bm0 = (blockIdx.x % mt) * BM, bn0 = (blockIdx.x / mt) * BN;
+  const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
+  // staging: A tile [32 rows][128 m]: consecutive lanes along m (contiguous in the source row)
+  float ra[16], rb[8];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int r = r0 + (tid >> 7) + 2 * p, m = bm0 + (tid & 127);
+      const typename AOp::Row w = aop.row(r < rend ? r : 0x7fffffff);
+      ra[p] = aop.load(w, m);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int r = r0 + (tid >> 6) + 4 * p, n = bn0 + (tid & 63);
+      const typename BOp::Row w = bop.row(r < rend ? r : 0x7fffffff);
+      rb[p] = bop.load(w, n);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) T.As[buf][(tid >> 7) + 2 * p][tid & 127] = ra[p];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) T.Bs[buf][(tid >> 6) + 4 * p][tid & 63] = rb[p];
+  };
+  f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+  const int nk = (rend - rbeg + BK - 1) / BK;
+  if (nk > 0) {
+    fetch(rbeg);
+    stash(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) fetch(rbeg + (kt + 1) * BK);
+    const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float b = T.Bs[cur][kk + kh][bcol];
+      const float a0 = T.As[cur][kk + kh][arow];
+      const float a1 = T.As[cur][kk + kh][arow + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
+    if (kt + 1 < nk) stash(cur ^ 1);
+    __syncthreads();
+  }
+  float* dst = part + (size_t)blockIdx.y * M * Nc;
+  const int col = bn0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = bm0 + wm * 64 + t * 32 + acc_row(reg, lane);
+      if (m < M && col < Nc) dst[(size_t)m * Nc + col] = t == 0 ? acc0[reg] : acc1[reg];
+    }
+}
+
+// out[i] = scale * sum_c part[c][i]  (fixed chunk order)
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ part, int chunks, long n, float scale, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
+  out[i] = scale * s;
+}
+
+}  // namespace dec
+
+// ================================================================================================ small kernels
+namespace dec {
+
+constexpr int PREP_COLS = 8;
+
+// Layer 1 in factored form + closed-form BN-1 statistics.  One block = PREP_COLS output channels.
+//   G[n,c] = W1[c,0:3].grid[n],  F[b,c] = b1[c] + W1[c,3:].feat[b]
+//   train: mean = mean_n G + mean_b F, var = var_n G + var_b F (biased; exact for the B x N product set)
+//   Gx = rstd*(G - gm), Fx = rstd*(F - fm)  with gm + fm = mean  =>  xhat1[b,n,c] = Gx[n,c] + Fx[b,c]
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                                   const float* __restrict__ grid, const float* __restrict__ feat, int B, int N,
+                                                   int C1, int ld1, int training, float eps, float momentum,
+                                                   float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ Gx,
+                                                   float* __restrict__ Fx, float* __restrict__ mean1, float* __restrict__ rstd1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Cf = C1 - 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sW = reinterpret_cast<float*>(smem);          // [PREP_COLS][C1]
+  float* sF = sW + PREP_COLS * C1;                      // [PREP_COLS][B]
+  float* sStat = sF + PREP_COLS * B;                    // [PREP_COLS][4]: gm, fm, rstd
+  // G[n,c] (3 MACs) is recomputed wherever needed instead of being staged: N reaches 64 050 (25 x 2562)
+  auto Gval = [&](int j, int n) {
+    return sW[j * C1] * grid[n * 3] + sW[j * C1 + 1] * grid[n * 3 + 1] + sW[j * C1 + 2] * grid[n * 3 + 2];
+  };
+  const int c0 = blockIdx.x * PREP_COLS;
+  for (int i = tid; i < PREP_COLS * C1; i += 256) {
+    const int c = c0 + i / C1;
+    sW[i] = c < C1 ? W1[(size_t)c * C1 + i % C1] : 0.f;
+  }
+  __syncthreads();
+  for (int b = wave; b < B; b += 4) {  // one wave per sample: lanes stride over the feature
+    float acc[PREP_COLS];
+#pragma unroll
+    for (int j = 0; j < PREP_COLS; ++j) acc[j] = 0.f;
+    for (int k = lane; k < Cf; k += 64) {
+      const float f = feat[(size_t)b * Cf + k];
+#pragma unroll
+      for (int j = 0; j < PREP_COLS; ++j) acc[j] = __fmaf_rn(f, sW[j * C1 + 3 + k], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < PREP_COLS; ++j) {
+      const float r = obman_wave_sum(acc[j]);
+      if (lane == 0) sF[j * B + b] = r + ((c0 + j < C1) ? b1[c0 + j] : 0.f);
+    }
+  }
+  __syncthreads();
+  // per-channel statistics: wave j/2.. handles channels; fp64 accumulation
+  for (int j = wave; j < PREP_COLS; j += 4) {
+    const int c = c0 + j;
+    double sg = 0, sgg = 0, sf = 0, sff = 0;
+    for (int n = lane; n < N; n += 64) { const double v = Gval(j, n); sg += v; sgg += v * v; }
+    for (int b = lane; b < B; b += 64) { const double v = sF[j * B + b]; sf += v; sff += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sg += __shfl_xor(sg, off, 64); sgg += __shfl_xor(sgg, off, 64);
+      sf += __shfl_xor(sf, off, 64); sff += __shfl_xor(sff, off, 64);
+    }
+    if (lane == 0 && c < C1) {
+      float gm, fm, var;
+      if (training) {
+        const double mg = sg / N, mf = sf / B;
+        const double v = (sgg / N - mg * mg) + (sff / B - mf * mf);
+        gm = (float)mg; fm = (float)mf; var = (float)(v > 0 ? v : 0);
+        if (rmean) {
+          const double R = (double)B * N;
+          rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)(mg + mf);
+          rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(v * (R / (R > 1 ? R - 1 : 1)));
+        }
+      } else {
+        gm = rmean[c]; fm = 0.f; var = rvar[c];
+      }
+      const float rs = 1.f / sqrtf(var + eps);
+      sStat[j * 4] = gm; sStat[j * 4 + 1] = fm; sStat[j * 4 + 2] = rs;
+      mean1[c] = gm + fm;
+      rstd1[c] = rs;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < PREP_COLS * N; i += 256) {
+    const int n = i / PREP_COLS, j = i % PREP_COLS;  // consecutive lanes -> consecutive channels (32-byte segments)
+    if (c0 + j < C1) Gx[(size_t)n * ld1 + c0 + j] = (Gval(j, n) - sStat[j * 4]) * sStat[j * 4 + 2];
+  }
+  for (int i = tid; i < PREP_COLS * B; i += 256) {
+    const int b = i / PREP_COLS, j = i % PREP_COLS;
+    if (c0 + j < C1) Fx[(size_t)b * ld1 + c0 + j] = (sF[j * B + b] - sStat[j * 4 + 1]) * sStat[j * 4 + 2];
+  }
+}
+
+// moments [blocks][C][2] (sum, sum sq over each row block) -> mean/rstd, affine (s,t) of y = s*h + t, running stats
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ moments, int blocks, long R, int C, int training,
+                                                          float eps, float momentum, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ s, float* __restrict__ t) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float m, v;
+  if (training) {
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < blocks; ++b) { s1 += moments[((size_t)b * C + c) * 2]; s2 += moments[((size_t)b * C + c) * 2 + 1]; }
+    const double mu = s1 / R;
+    double var = s2 / R - mu * mu;
+    if (var < 0) var = 0;
+    m = (float)mu; v = (float)var;
+    if (rmean) {
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * ((double)R / (R > 1 ? R - 1 : 1)));
+    }
+  } else {
+    m = rmean[c]; v = rvar[c];
+  }
+  const float rs = 1.f / sqrtf(v + eps);
+  mean[c] = m; rstd[c] = rs;
+  s[c] = gamma[c] * rs;
+  t[c] = beta[c] - m * gamma[c] * rs;
+}
+
+// out[r, 0:3] = f * (b4 + W4 . relu(s3*h3[r]+t3)); 32 lanes per row, float4 per lane (C3 <= 128), 2 rows per wave pass
+__global__ __launch_bounds__(256) void l4_fwd_kernel(const float* __restrict__ H3, int ld3, const float* __restrict__ s3,
+                                                     const float* __restrict__ t3, const float* __restrict__ W4,
+                                                     const float* __restrict__ b4, float f, long R, int C3, float* __restrict__ out) {
+  const int tid = threadIdx.x, sub = tid & 31;
+  const long r0 = ((long)blockIdx.x * 256 + tid) >> 5;
+  const long stride = ((long)gridDim.x * 256) >> 5;
+  for (long r = r0; r < R; r += stride) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = sub; c < C3; c += 32) {
+      const float a = fmaxf(__fmaf_rn(s3[c], H3[(size_t)r * ld3 + c], t3[c]), 0.f);
+      a0 = __fmaf_rn(a, W4[c], a0);
+      a1 = __fmaf_rn(a, W4[C3 + c], a1);
+      a2 = __fmaf_rn(a, W4[2 * C3 + c], a2);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64);
+    }
+    if (sub == 0) {
+      out[r * 3] = f * (a0 + b4[0]);
+      out[r * 3 + 1] = f * (a1 + b4[1]);
+      out[r * 3 + 2] = f * (a2 + b4[2]);
+    }
+  }
+}
+
+// Layer-4 backward over a chunk of rows: thread = channel c.  Partials: sums[blk][C3][2] (S1,S2 fp64),
+// gw[blk][3*C3 + 4] (gW4 rows then gb4).
+__global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G, const float* __restrict__ H3, int ld3,
+                                                     const float* __restrict__ s3, const float* __restrict__ t3,
+                                                     const float* __restrict__ mean3, const float* __restrict__ rstd3,
+                                                     const float* __restrict__ W4, float f, long R, int C3, int rows_per_blk,
+                                                     double* __restrict__ sums, float* __restrict__ gw) {
+  const int c = threadIdx.x;
+  const long rbeg = (long)blockIdx.x * rows_per_blk, rend = min(R, rbeg + rows_per_blk);
+  const bool ok = c < C3;
+  const float cs = ok ? s3[c] : 0.f, ct = ok ? t3[c] : 0.f, cm = ok ? mean3[c] : 0.f, cr = ok ? rstd3[c] : 0.f;
+  const float w0 = ok ? W4[c] : 0.f, w1 = ok ? W4[C3 + c] : 0.f, w2 = ok ? W4[2 * C3 + c] : 0.f;
+  double S1 = 0, S2 = 0;
+  float g0a = 0.f, g1a = 0.f, g2a = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (long r = rbeg; r < rend; ++r) {
+    const float g0 = f * G[r * 3], g1 = f * G[r * 3 + 1], g2 = f * G[r * 3 + 2];
+    const float h = ok ? H3[(size_t)r * ld3 + c] : 0.f;
+    const float y = __fmaf_rn(cs, h, ct);
+    const float a = fmaxf(y, 0.f);
+    const float gy = y > 0.f ? (g0 * w0 + g1 * w1 + g2 * w2) : 0.f;
+    S1 += (double)gy;
+    S2 += (double)gy * (double)((h - cm) * cr);
+    g0a = __fmaf_rn(g0, a, g0a); g1a = __fmaf_rn(g1, a, g1a); g2a = __fmaf_rn(g2, a, g2a);
+    b0 += g0; b1 += g1; b2 += g2;
+  }
+  if (ok) {
+    sums[((size_t)blockIdx.x * C3 + c) * 2] = S1;
+    sums[((size_t)blockIdx.x * C3 + c) * 2 + 1] = S2;
+    float* dst = gw + (size_t)blockIdx.x * (3 * C3 + 4);
+    dst[c] = g0a; dst[C3 + c] = g1a; dst[2 * C3 + c] = g2a;
+    if (c == 0) { dst[3 * C3] = b0; dst[3 * C3 + 1] = b1; dst[3 * C3 + 2] = b2; }
+  }
+}
+
+// sums [blocks][C][2] -> g_gamma = S2, g_beta = S1, gh coefficients k1 = gamma*rstd, k2 = S1/R, k3 = S2/R (0 in eval),
+// conv-bias gradient gb = sum_r gh = (train ? 0 : k1*S1)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ sums, int blocks, long R, int C, int training,
+                                                              const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                              float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                              float* __restrict__ g_bias, float* __restrict__ k1,
+                                                              float* __restrict__ k2, float* __restrict__ k3) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = 0; b < blocks; ++b) { s1 += sums[((size_t)b * C + c) * 2]; s2 += sums[((size_t)b * C + c) * 2 + 1]; }
+  g_gamma[c] = (float)s2;
+  g_beta[c] = (float)s1;
+  const float kk = gamma[c] * rstd[c];
+  k1[c] = kk;
+  k2[c] = training ? (float)(s1 / R) : 0.f;
+  k3[c] = training ? (float)(s2 / R) : 0.f;
+  if (g_bias) g_bias[c] = training ? 0.f : kk * (float)s1;
+}
+
+// partial layer-4 weight gradients [blocks][3*C3+4] -> gW4 [3][C3], gb4 [3]
+__global__ __launch_bounds__(256) void l4_bwd_finalize_kernel(const float* __restrict__ gw, int blocks, int C3, float* __restrict__ gW4,
+                                                              float* __restrict__ gb4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * C3 + 3) return;
+  double s = 0;
+  for (int b = 0; b < blocks; ++b) s += gw[(size_t)b * (3 * C3 + 4) + i];
+  if (i < 3 * C3) gW4[i] = (float)s; else gb4[i - 3 * C3] = (float)s;
+}
+
+// P[b,c] = sum_n GY1[b,n,c] (blockIdx.y = 0) ; Q[n,c] = sum_b GY1[b,n,c] (blockIdx.y = 1); thread = channel
+__global__ __launch_bounds__(256) void l1_reduce_kernel(const float* __restrict__ GY1, int ld1, int B, int N, int C1,
+                                                        float* __restrict__ P, float* __restrict__ Q) {
+  const int c = blockIdx.z * 256 + threadIdx.x;
+  if (c >= C1) return;
+  if (blockIdx.y == 0) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    float a0 = 0.f, a1 = 0.f;
+    int n = 0;
+    for (; n + 1 < N; n += 2) {
+      a0 += GY1[((size_t)b * N + n) * ld1 + c];
+      a1 += GY1[((size_t)b * N + n + 1) * ld1 + c];
+    }
+    if (n < N) a0 += GY1[((size_t)b * N + n) * ld1 + c];
+    P[(size_t)b * ld1 + c] = a0 + a1;
+  } else {
+    const int n = blockIdx.x;
+    if (n >= N) return;
+    float a0 = 0.f, a1 = 0.f;
+    int b = 0;
+    for (; b + 1 < B; b += 2) {
+      a0 += GY1[((size_t)b * N + n) * ld1 + c];
+      a1 += GY1[((size_t)(b + 1) * N + n) * ld1 + c];
+    }
+    if (b < B) a0 += GY1[((size_t)b * N + n) * ld1 + c];
+    Q[(size_t)n * ld1 + c] = a0 + a1;
+  }
+}
+
+// BN-1 backward in factored form.  Thread = channel.  Produces g_gamma1, g_beta1, dF [B,ld1], dG [N,ld1],
+// g_b1 = sum_b dF, and gW1[:, 0:3] = dG^T grid.
+__global__ __launch_bounds__(256) void l1_finalize_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                          const float* __restrict__ Gx, const float* __restrict__ Fx, int ld1,
+                                                          int B, int N, int C1, int training, const float* __restrict__ gamma,
+                                                          const float* __restrict__ rstd1, const float* __restrict__ grid,
+                                                          float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                          float* __restrict__ g_b1, float* __restrict__ gW1, float* __restrict__ dF,
+                                                          float* __restrict__ dG) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C1) return;
+  double s1 = 0, s2 = 0, sgx = 0, sfx = 0;
+  for (int b = 0; b < B; ++b) {
+    const double p = P[(size_t)b * ld1 + c], fx = Fx[(size_t)b * ld1 + c];
+    s1 += p; s2 += p * fx; sfx += fx;
+  }
+  for (int n = 0; n < N; ++n) {
+    const double gx = Gx[(size_t)n * ld1 + c];
+    s2 += gx * (double)Q[(size_t)n * ld1 + c];
+    sgx += gx;
+  }
+  const double R = (double)B * N;
+  g_gamma[c] = (float)s2;
+  g_beta[c] = (float)s1;
+  const float k1 = gamma[c] * rstd1[c];
+  const float k2 = training ? (float)(s1 / R) : 0.f, k3 = training ? (float)(s2 / R) : 0.f;
+  float gb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float v = k1 * (P[(size_t)b * ld1 + c] - N * k2 - k3 * ((float)sgx + N * Fx[(size_t)b * ld1 + c]));
+    dF[(size_t)b * ld1 + c] = v;
+    gb += v;
+  }
+  g_b1[c] = gb;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float v = k1 * (Q[(size_t)n * ld1 + c] - B * k2 - k3 * (B * Gx[(size_t)n * ld1 + c] + (float)sfx));
+    dG[(size_t)n * ld1 + c] = v;
+    w0 = __fmaf_rn(v, grid[n * 3], w0); w1 = __fmaf_rn(v, grid[n * 3 + 1], w1); w2 = __fmaf_rn(v, grid[n * 3 + 2], w2);
+  }
+  gW1[(size_t)c * C1] = w0; gW1[(size_t)c * C1 + 1] = w1; gW1[(size_t)c * C1 + 2] = w2;
+}
+
+// out[m*ldo + off + n] = sum_c part[c][m][n]   (fixed chunk order)
+__global__ __launch_bounds__(256) void reduce_tn_kernel(const float* __restrict__ part, int chunks, int M, int Nc, int ldo, int off,
+                                                        float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * Nc) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * M * Nc + i];
+  out[(size_t)(i / Nc) * ldo + off + (i % Nc)] = s;
+}
+
+}  // namespace dec
+
+// ================================================================================================ orchestration
+namespace {
+using namespace dec;
+
+struct Dims {
+  int B, N, C1, C2, C3, ld1, ld2, ld3, rb;  // rb = row blocks of the rows-GEMMs
+  long R;
+};
+Dims dims_of(const obman_pointgen_params* p) {
+  Dims d;
+  d.B = p->B; d.N = p->N; d.C1 = p->C1; d.C2 = p->C1 / 2; d.C3 = p->C1 / 4;
+  d.ld1 = pad16(d.C1); d.ld2 = pad16(d.C2); d.ld3 = pad16(d.C3);
+  d.R = (long)d.B * d.N;
+  d.rb = (int)((d.R + BM - 1) / BM);
+  return d;
+}
+constexpr int L4_ROWS = 128;
+constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gradient GEMMs
+
+// forward workspace (kept for the backward), float offsets
+struct FwdWs {
+  long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, total;
+};
+FwdWs fwd_ws(const Dims& d) {
+  FwdWs w; long o = 0;
+  auto take = [&](long n) { long at = o; o += (n + 15) / 16 * 16; return at; };
+  w.Gx = take((long)d.N * d.ld1); w.Fx = take((long)d.B * d.ld1); w.mean1 = take(d.ld1); w.rstd1 = take(d.ld1);
+  w.H2 = take(d.R * d.ld2); w.mean2 = take(d.ld2); w.rstd2 = take(d.ld2); w.s2 = take(d.ld2); w.t2 = take(d.ld2);
+  w.H3 = take(d.R * d.ld3); w.mean3 = take(d.ld3); w.rstd3 = take(d.ld3); w.s3 = take(d.ld3); w.t3 = take(d.ld3);
+  w.moments = take((long)d.rb * d.C2 * 2 * 2);  // doubles
+  w.total = o;
+  return w;
+}
+struct BwdWs {
+  long GY2, GY1, sums, k, l4p, P, Q, dF, dG, tn, total;
+  int chunks;
+};
+BwdWs bwd_ws(const Dims& d) {
+  BwdWs w; long o = 0;
+  auto take = [&](long n) { long at = o; o += (n + 15) / 16 * 16; return at; };
+  w.chunks = (int)((d.R + TN_CHUNK_ROWS - 1) / TN_CHUNK_ROWS);
+  const int l4b = (int)((d.R + L4_ROWS - 1) / L4_ROWS);
+  w.GY2 = take(d.R * d.ld2); w.GY1 = take(d.R * d.ld1);
+  w.sums = take((long)(d.rb > l4b ? d.rb : l4b) * d.C1 * 2 * 2);
+  w.k = take(3 * d.ld1);
+  w.l4p = take((long)l4b * (3 * d.C3 + 4));
+  w.P = take((long)d.B * d.ld1); w.Q = take((long)d.N * d.ld1); w.dF = take((long)d.B * d.ld1); w.dG = take((long)d.N * d.ld1);
+  w.tn = take((long)w.chunks * d.C1 * d.C2);
+  w.total = o;
+  return w;
+}
+
+template <class AOp, bool B_NK, class Epi>
+int launch_rows(const AOp& a, const float* W, int ldb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
+  dim3 grid((unsigned)((R + BM - 1) / BM), (unsigned)((Nc + BN - 1) / BN));
+  gemm_rows_kernel<AOp, B_NK, Epi><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+template <class AOp, class BOp>
+int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int chunk_rows, float* part, float* out, int ldo, int off, hipStream_t st) {
+  const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
+  dim3 grid((unsigned)(((M + BM - 1) / BM) * ((Nc + BN - 1) / BN)), (unsigned)chunks);
+  gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part);
+  OBMAN_LAUNCH_CHECK();
+  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+bool params_ok(const obman_pointgen_params* p) {
+  return p && p->B > 0 && p->N > 0 && p->C1 >= 8 && p->C1 / 4 <= 128 && p->grid && p->feat && p->w1 && p->w2 && p->w3 && p->w4;
+}
+
+}  // namespace
+
+extern "C" {
+
+long obman_pointgen_ws_floats(const obman_pointgen_params* p, int backward) {
+  if (!params_ok(p)) return -1;
+  const Dims d = dims_of(p);
+  return backward ? bwd_ws(d).total : fwd_ws(d).total;
+}
+
+int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, obman_stream_t stream) {
+  if (!params_ok(p) || !out || !ws) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const Dims d = dims_of(p);
+  const FwdWs w = fwd_ws(d);
+  const int tr = p->training;
+  ObmanProfScope prof(OBMAN_K_DECODER_FWD, st);
+  {
+    const size_t sm = sizeof(float) * ((size_t)PREP_COLS * (d.C1 + d.B) + PREP_COLS * 4);
+    prep_kernel<<<obman_cdiv(d.C1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
+                                                               p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
+                                                               ws + w.mean1, ws + w.rstd1);
+    OBMAN_LAUNCH_CHECK();
+  }
+  double* moments = reinterpret_cast<double*>(ws + w.moments);
+  {  // h2 = W2 relu(bn1(h1)) + b2
+    AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1};
+    EpiStoreImpl e;
+    e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
+    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
+    if (rc) return rc;
+    bn_finalize_kernel<<<obman_cdiv(d.C2, 256), 256, 0, st>>>(moments, d.rb, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
+                                                               p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
+    OBMAN_LAUNCH_CHECK();
+  }
+  {  // h3 = W3 relu(bn2(h2)) + b3
+    ABnRelu a{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, (int)d.R, d.C2};
+    EpiStoreImpl e;
+    e.C = ws + w.H3; e.bias = p->b3; e.moments = tr ? moments : nullptr; e.ldc = d.ld3; e.R = (int)d.R; e.Nc = d.C3;
+    int rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
+    if (rc) return rc;
+    bn_finalize_kernel<<<obman_cdiv(d.C3, 256), 256, 0, st>>>(moments, d.rb, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
+                                                               p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
+    OBMAN_LAUNCH_CHECK();
+  }
+  l4_fwd_kernel<<<2048, 256, 0, st>>>(ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
+int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const float* ws, float* ws2,
+                       const obman_pointgen_grads* g, obman_stream_t stream) {
+  if (!params_ok(p) || !g_out || !ws || !ws2 || !g) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const Dims d = dims_of(p);
+  const FwdWs w = fwd_ws(d);
+  const BwdWs v = bwd_ws(d);
+  const int tr = p->training;
+  const int R = (int)d.R;
+  ObmanProfScope prof(OBMAN_K_DECODER_BWD, st);
+  double* sums = reinterpret_cast<double*>(ws2 + v.sums);
+  float *k1 = ws2 + v.k, *k2 = k1 + d.ld1, *k3 = k2 + d.ld1;
+  const float f = p->out_factor;
+  // ---- layer 4 + BN-3 statistics
+  const int l4b = obman_cdiv(d.R, L4_ROWS);
+  l4_bwd_kernel<<<l4b, 128, 0, st>>>(g_out, ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3,
+                                      L4_ROWS, sums, ws2 + v.l4p);
+  OBMAN_LAUNCH_CHECK();
+  l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 256), 256, 0, st>>>(ws2 + v.l4p, l4b, d.C3, g->w4, g->b4);
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 256), 256, 0, st>>>(sums, l4b, d.R, d.C3, tr, p->bn_w[2], ws + w.rstd3, g->bn_w[2], g->bn_b[2],
+                                                                 g->b3, k1, k2, k3);
+  OBMAN_LAUNCH_CHECK();
+  AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, k1, k2, k3, f, d.ld3, R, d.C3};
+  int rc;
+  {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
+    ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
+    rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st);
+    if (rc) return rc;
+  }
+  {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
+    EpiMaskStatsImpl e;
+    e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
+    e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
+    e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N;
+    rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st);
+    if (rc) return rc;
+  }
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 256), 256, 0, st>>>(sums, d.rb, d.R, d.C2, tr, p->bn_w[1], ws + w.rstd2, g->bn_w[1], g->bn_b[1],
+                                                                 g->b2, k1, k2, k3);
+  OBMAN_LAUNCH_CHECK();
+  AGradH gh2{ws2 + v.GY2, ws + w.H2, ws + w.mean2, ws + w.rstd2, k1, k2, k3, d.ld2, R, d.C2};
+  AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1};
+  rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st);  // gW2[o,c]
+  if (rc) return rc;
+  {  // gy1 = (gh2 W2) * (y1 > 0)
+    EpiMaskStatsImpl e;
+    e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
+    e.H = e.s = e.t = e.mean = e.rstd = nullptr;
+    e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N;
+    rc = launch_rows<AGradH, false, EpiMaskStatsImpl>(gh2, p->w2, d.C1, d.C2, d.C1, d.R, e, st);
+    if (rc) return rc;
+  }
+  // ---- layer 1 in factored form
+  l1_reduce_kernel<<<dim3(d.B > d.N ? d.B : d.N, 2, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, ws2 + v.P,
+                                                                                            ws2 + v.Q);
+  OBMAN_LAUNCH_CHECK();
+  l1_finalize_kernel<<<obman_cdiv(d.C1, 256), 256, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
+                                                             ws + w.rstd1, p->grid, g->bn_w[0], g->bn_b[0], g->b1, g->w1, ws2 + v.dF, ws2 + v.dG);
+  OBMAN_LAUNCH_CHECK();
+  const int Cf = d.C1 - 3;
+  {  // gW1[c, 3+k] = sum_b dF[b,c] feat[b,k]
+    APlain adf{ws2 + v.dF, d.ld1, d.B, d.C1};
+    APlain afe{p->feat, Cf, d.B, Cf};
+    rc = launch_tn<APlain, APlain>(adf, afe, d.C1, Cf, d.B, TN_CHUNK_ROWS, ws2 + v.tn, g->w1, d.C1, 3, st);
+    if (rc) return rc;
+  }
+  if (g->feat) {  // g_feat[b,k] = sum_c dF[b,c] W1[c,3+k]
+    APlain adf{ws2 + v.dF, d.ld1, d.B, d.C1};
+    EpiStoreImpl e;
+    e.C = g->feat; e.bias = nullptr; e.moments = nullptr; e.ldc = Cf; e.R = d.B; e.Nc = Cf;
+    rc = launch_rows<APlain, false, EpiStoreImpl>(adf, p->w1 + 3, d.C1, d.C1, Cf, d.B, e, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

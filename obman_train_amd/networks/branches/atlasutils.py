@@ -53,24 +53,6 @@ class PointGenCon(nn.Module):
         return self._tail(torch_f.relu(self.bn1(self.conv1(x))))
 
     def decode(self, features, grid):
-        """features [B,C-3], grid [N,3] (shared template) -> points [B,N,3] (already transposed)."""
-        w1 = self.conv1.weight.squeeze(2)
-        g = grid @ w1[:, :3].t()                                    # [N,C]
-        f = torch.addmm(self.conv1.bias, features, w1[:, 3:].t())   # [B,C]
-        bn = self.bn1
-        if bn.training or bn.running_mean is None:
-            mean = g.mean(0) + f.mean(0)
-            var = g.var(0, unbiased=False) + f.var(0, unbiased=False)
-            if bn.training and bn.running_mean is not None:
-                with torch.no_grad():
-                    n = g.shape[0] * f.shape[0]
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
-                    bn.num_batches_tracked += 1
-        else:
-            mean, var = bn.running_mean, bn.running_var
-        scale = bn.weight * torch.rsqrt(var + bn.eps)
-        shift = bn.bias - mean * scale
-        h = torch_f.relu((g * scale).t().unsqueeze(0) + (f * scale + shift).unsqueeze(2))  # [B,C,N]
-        return self._tail(h).transpose(2, 1)
+        """features [B,C-3], grid [N,3] (shared template) -> points [B,N,3] (already transposed):
+        one call into the fused fp32-MFMA decoder (``csrc/decoder.hip``), forward and backward."""
+        return ops.pointgen_decode(self, features, grid)

@@ -240,3 +240,90 @@ def contact_tail(hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zo
     """-> (missed_loss, penetr_loss, out[8], attraction_mask u8, repulsion_mask u8, contact_points)."""
     return _ContactTail.apply(hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zone_mode, contact_mode,
                               contact_thresh, collision_mode, collision_thresh, target)
+
+
+import ctypes as _ct
+
+
+class _PointGen(torch.autograd.Function):
+    """PointGenCon over (template grid x per-sample feature) without the [B,C,N] concat (csrc/decoder.hip)."""
+
+    @staticmethod
+    def forward(ctx, feat, grid, w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3, running, cfg):
+        training, eps, momentum, out_factor = cfg
+        feat, grid = _dev(feat, "features"), _dev(grid, "grid")
+        tensors = [_dev(t, "decoder parameter") for t in (w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3)]
+        B, N, C1 = feat.shape[0], grid.shape[0], w1.shape[0]
+        if feat.shape[1] != C1 - 3 or grid.shape[1] != 3:
+            raise ValueError("features must be [B,%d] and grid [N,3]" % (C1 - 3))
+        p = _lib.PointGenParams()
+        p.B, p.N, p.C1, p.training = B, N, C1, int(training)
+        p.eps, p.momentum, p.out_factor = float(eps), float(momentum), float(out_factor)
+        p.grid, p.feat = grid.data_ptr(), feat.data_ptr()
+        for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4"), tensors[:8]):
+            setattr(p, name, t.data_ptr())
+        for k in range(3):
+            p.bn_w[k], p.bn_b[k] = tensors[8 + 2 * k].data_ptr(), tensors[9 + 2 * k].data_ptr()
+            rm, rv = running[k]
+            p.bn_rm[k] = rm.data_ptr() if rm is not None else None
+            p.bn_rv[k] = rv.data_ptr() if rv is not None else None
+        lib = _lib.lib()
+        n_ws = lib.obman_pointgen_ws_floats(_ct.addressof(p), 0)
+        if n_ws <= 0:
+            raise _lib.ObmanHipError("obman_pointgen_ws_floats: unsupported decoder shape (C1=%d)" % C1)
+        ws = torch.empty(n_ws, dtype=torch.float32, device=feat.device)
+        out = torch.empty((B, N, 3), dtype=torch.float32, device=feat.device)
+        _lib.check(lib.obman_pointgen_fwd(_ct.addressof(p), out.data_ptr(), ws.data_ptr(), _stream()), "obman_pointgen_fwd")
+        ctx.save_for_backward(feat, grid, ws, *tensors)
+        ctx.params = p  # holds raw pointers of tensors kept alive by save_for_backward / the module buffers
+        ctx.running = running
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        feat, grid, ws = ctx.saved_tensors[:3]
+        tensors = ctx.saved_tensors[3:]
+        p = ctx.params
+        lib = _lib.lib()
+        g_out = g_out.contiguous()
+        ws2 = torch.empty(lib.obman_pointgen_ws_floats(_ct.addressof(p), 1), dtype=torch.float32, device=feat.device)
+        grads = [torch.empty_like(t) for t in tensors]
+        g_feat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+        g = _lib.PointGenGrads()
+        for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4"), grads[:8]):
+            setattr(g, name, t.data_ptr())
+        for k in range(3):
+            g.bn_w[k], g.bn_b[k] = grads[8 + 2 * k].data_ptr(), grads[9 + 2 * k].data_ptr()
+        g.feat = _ptr(g_feat)
+        _lib.check(lib.obman_pointgen_bwd(_ct.addressof(p), g_out.data_ptr(), ws.data_ptr(), ws2.data_ptr(),
+                                          _ct.addressof(g), _stream()), "obman_pointgen_bwd")
+        return (g_feat, None, *grads, None, None)
+
+
+def pointgen_decode(decoder, features, grid):
+    """decoder: PointGenCon-like module (conv1..4, bn1..3, out_factor); features [B,C], grid [N,3] -> [B,N,3]."""
+    bns = (decoder.bn1, decoder.bn2, decoder.bn3)
+    training = decoder.training or any(bn.running_mean is None for bn in bns)
+    running = []
+    momentum = 0.0
+    for bn in bns:
+        running.append((bn.running_mean, bn.running_var) if bn.running_mean is not None else (None, None))
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked + 1)
+        else:
+            momentum = bn.momentum
+    if getattr(decoder, "use_tanh", False):
+        raise NotImplementedError("use_tanh: traineval.py:54 always passes atlas_use_tanh=False")
+    convs = (decoder.conv1, decoder.conv2, decoder.conv3, decoder.conv4)
+    args = []
+    for c in convs:
+        args += [c.weight.view(c.weight.shape[0], c.weight.shape[1]), c.bias]
+    for bn in bns:
+        args += [bn.weight, bn.bias]
+    out = _PointGen.apply(features, grid, *args, tuple(running), (training, bns[0].eps, momentum, decoder.out_factor))
+    if decoder.training:
+        with torch.no_grad():
+            for bn in bns:
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+    return out

@@ -1,0 +1,115 @@
+"""GPU parity: fused fp32-MFMA PointGenCon decoder (C-ABI obman_pointgen_fwd/bwd) vs the oracle restatement of
+atlasbranch.py:117-132 + atlasutils.py:65-75 (materialised concat, conv1d, batch_norm).  fp32 MFMA is an exact fp32 fma
+chain; differences come from summation order only: outputs rtol 2e-4 of the output scale, gradients 2e-3 of the largest entry."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import atlas as oatlas
+from obman_train_amd.icosphere import icosphere
+from tests.golden.common import load_seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder(c1, seed):
+    from obman_train_amd.networks.branches.atlasutils import PointGenCon
+
+    dec = load_seeded(PointGenCon(bottleneck_size=c1, out_factor=200), seed)
+    with torch.no_grad():
+        dec.conv4.weight.mul_(0.3)
+    return dec
+
+
+def _oracle(dec, feats, grid, training):
+    params = {"decoder." + k: v.detach().clone() for k, v in list(dec.named_parameters()) + list(dec.named_buffers())}
+    for k, v in params.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_()
+    f = feats.clone().requires_grad_()
+    B, N = f.shape[0], grid.shape[0]
+    x = torch.cat((grid.t().unsqueeze(0).expand(B, -1, -1), f.unsqueeze(2).expand(-1, -1, N)), 1)
+    out = oatlas.pointgen(params, x, training=training, out_factor=dec.out_factor).transpose(2, 1)
+    return out, f, params
+
+
+@pytest.mark.parametrize("c1,B,subdiv,training", [(35, 3, 1, True), (35, 2, 1, False), (515, 4, 3, True), (515, 2, 2, False),
+                                                  (131, 5, 2, True)])
+def test_decoder_forward_backward_matches_oracle(c1, B, subdiv, training):
+    from obman_train_amd import ops
+
+    dec = _decoder(c1, 7)
+    dec.train(training)
+    grid = torch.from_numpy(icosphere(subdiv)[0].astype(np.float32))
+    rng = np.random.RandomState(8)
+    feats = torch.from_numpy(rng.normal(0, 1, size=(B, c1 - 3)).astype(np.float32))
+    cot = torch.from_numpy(rng.normal(0, 1, size=(B, grid.shape[0], 3)).astype(np.float32))
+    want, f_o, params = _oracle(dec, feats, grid, training)
+    (want * cot).sum().backward()
+
+    dec_g = _decoder(c1, 7).cuda()
+    dec_g.train(training)
+    f_g = feats.cuda().requires_grad_()
+    got = ops.pointgen_decode(dec_g, f_g, grid.cuda())
+    (got * cot.cuda()).sum().backward()
+    scale = want.abs().max().item()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-4, atol=2e-4 * scale)
+
+    def check(name, g, w):
+        err = (g.cpu() - w).abs().max().item()
+        ref = w.abs().max().item()
+        assert err <= 2e-3 * ref + 1e-5, (name, err, ref)
+
+    check("features", f_g.grad, f_o.grad)
+    for name, prm in dec_g.named_parameters():
+        w = params["decoder." + name].grad
+        if name.startswith("conv") and name.endswith("bias") and training and name != "conv4.bias":
+            # bias before a train-mode BatchNorm has an exactly-zero gradient; autograd returns round-off noise
+            assert prm.grad.abs().max().item() <= 1e-3 * (dec_g.conv4.weight.grad.abs().max().item())
+            continue
+        check(name, prm.grad, w.reshape(prm.grad.shape))
+    if training:  # running statistics follow torch's momentum update (unbiased variance)
+        for k in (1, 2, 3):
+            bn = getattr(dec_g, "bn%d" % k)
+            np.testing.assert_allclose(bn.running_mean.cpu().numpy(), params["decoder.bn%d.running_mean" % k].numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(bn.running_var.cpu().numpy(), params["decoder.bn%d.running_var" % k].numpy(), rtol=1e-4, atol=1e-5)
+            assert int(bn.num_batches_tracked) == 1
+
+
+def test_decoder_matches_reference_golden_pointgen(golden):
+    """The reference's own PointGenCon output (tests/golden/pointgen.npz) for an input that IS a grid x feature
+    product cannot be formed from an arbitrary x; instead check the generic forward(x) entry point of the mirror
+    (stock conv1d path) against the golden, and decode() against forward() on a product input."""
+    from obman_train_amd.networks.branches.atlasutils import PointGenCon
+
+    g = golden("pointgen")
+    dec = load_seeded(PointGenCon(bottleneck_size=35, out_factor=200), int(g["seed"])).cuda().train()
+    y = dec(torch.from_numpy(g["x"]).cuda())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y_train"], rtol=1e-4, atol=1e-3)
+    dec2 = load_seeded(PointGenCon(bottleneck_size=35, out_factor=200), int(g["seed"])).cuda().train()
+    grid = torch.from_numpy(icosphere(1)[0].astype(np.float32)).cuda()
+    feats = torch.randn(3, 32, device="cuda")
+    x = torch.cat((grid.t().unsqueeze(0).expand(3, -1, -1), feats.unsqueeze(2).expand(-1, -1, 42)), 1)
+    dec3 = load_seeded(PointGenCon(bottleneck_size=35, out_factor=200), int(g["seed"])).cuda().train()
+    np.testing.assert_allclose(dec2.decode(feats, grid).detach().cpu().numpy(), dec3(x).transpose(2, 1).detach().cpu().numpy(),
+                               rtol=2e-4, atol=2e-2)
+
+
+def test_decoder_multi_patch_and_determinism():
+    from obman_train_amd import ops
+    from obman_train_amd.icosphere import multi_patch
+
+    dec = _decoder(515, 9).cuda().train()
+    grid = torch.from_numpy(multi_patch(2, 3)[0].astype(np.float32)).cuda()  # 3 patches x 162 vertices
+    feats = torch.randn(6, 512, device="cuda").requires_grad_()
+    outs = []
+    for _ in range(2):
+        dec.zero_grad()
+        feats.grad = None
+        out = ops.pointgen_decode(dec, feats, grid)
+        out.square().mean().backward()
+        outs.append((out.detach().clone(), feats.grad.clone(), dec.conv2.weight.grad.clone()))
+    assert outs[0][0].shape == (6, 486, 3)
+    # BN running stats moved between the two calls but batch statistics are used in train mode: identical results
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
