@@ -680,7 +680,10 @@ BwdWs bwd_ws(const Dims& d) {
   w.k = take(3 * d.ld1);
   w.l4p = take((long)l4b * (3 * d.C3 + 4));
   w.P = take((long)d.B * d.ld1); w.Q = take((long)d.N * d.ld1); w.dF = take((long)d.B * d.ld1); w.dG = take((long)d.N * d.ld1);
-  w.tn = take((long)w.chunks * d.C1 * d.C2);
+  {  // split-K partials of the largest weight-gradient product; gW1 = dF^T feat is one chunk of C1 x (C1-3)
+    const long a = (long)w.chunks * d.C1 * d.C2, b = (long)d.C1 * d.C1;
+    w.tn = take(a > b ? a : b);
+  }
   w.total = o;
   return w;
 }
