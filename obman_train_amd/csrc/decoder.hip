@@ -28,36 +28,58 @@ constexpr int BM = 128, BN = 64, BK = 32, NT = 256;
 __host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 
 // ------------------------------------------------------------------------------------------------ A operands
+// Every operand is generated in two phases so that the global loads of tile t+1 are in flight while the MFMAs
+// of tile t run: raw() issues branch-free loads (indices clamped, never predicated), fin() applies the fused
+// BN / ReLU / BN-backward arithmetic AFTER the MFMA loop.  kc() fetches the per-channel constants.
+__device__ __forceinline__ void split_row(int r, int N, int bhint, int& b, int& n) {
+  b = bhint;
+  n = r - b * N;
+  while (n >= N) { n -= N; ++b; }
+}
+
 struct AGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k]),  r = b*N + n  (Gx, Fx are x-hat factors)
   const float *Gx, *Fx, *gamma, *beta;
   int N, ld, R, K;
-  struct Row { int g, f; };
-  __device__ Row row(int r) const {
-    if (r >= R) return Row{-1, -1};
-    const int b = r / N;
-    return Row{(r - b * N) * ld, b * ld};
+  struct Row { int g, f; bool ok; };
+  struct KC { float ga, be; bool ok; };
+  struct Raw { float a, b; };
+  __device__ Row row(int r, int bhint) const {
+    const bool ok = r < R;
+    int b, n;
+    split_row(ok ? r : R - 1, N, ok ? bhint : (R - 1) / N, b, n);
+    return Row{n * ld, b * ld, ok};
   }
-  __device__ float load(const Row& w, int k) const {
-    if (w.g < 0 || k >= K) return 0.f;
-    return fmaxf(__fmaf_rn(gamma[k], Gx[w.g + k] + Fx[w.f + k], beta[k]), 0.f);
+  __device__ KC kc(int k) const { const bool ok = k < K; const int c = ok ? k : 0; return KC{gamma[c], beta[c], ok}; }
+  __device__ Raw raw(const Row& w, int k) const { const int c = k < K ? k : 0; return Raw{Gx[w.g + c], Fx[w.f + c]}; }
+  __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
+    const float v = fmaxf(__fmaf_rn(c.ga, x.a + x.b, c.be), 0.f);
+    return (w.ok && c.ok) ? v : 0.f;
   }
 };
 struct ABnRelu {  // a[r,k] = relu(s[k] * H[r,k] + t[k])
   const float *H, *s, *t;
   int ld, R, K;
-  struct Row { long o; };
-  __device__ Row row(int r) const { return Row{r < R ? (long)r * ld : -1}; }
-  __device__ float load(const Row& w, int k) const {
-    if (w.o < 0 || k >= K) return 0.f;
-    return fmaxf(__fmaf_rn(s[k], H[w.o + k], t[k]), 0.f);
+  struct Row { long o; bool ok; };
+  struct KC { float s, t; bool ok; };
+  struct Raw { float h; };
+  __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
+  __device__ KC kc(int k) const { const bool ok = k < K; const int c = ok ? k : 0; return KC{s[c], t[c], ok}; }
+  __device__ Raw raw(const Row& w, int k) const { return Raw{H[w.o + (k < K ? k : 0)]}; }
+  __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
+    const float v = fmaxf(__fmaf_rn(c.s, x.h, c.t), 0.f);
+    return (w.ok && c.ok) ? v : 0.f;
   }
 };
 struct APlain {  // a[r,k] = X[r,k]
   const float* X;
   int ld, R, K;
-  struct Row { long o; };
-  __device__ Row row(int r) const { return Row{r < R ? (long)r * ld : -1}; }
-  __device__ float load(const Row& w, int k) const { return (w.o < 0 || k >= K) ? 0.f : X[w.o + k]; }
+  struct Row { long o; bool ok; };
+  struct KC { bool ok; };
+  struct Raw { float x; };
+  __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
+  __device__ KC kc(int k) const { return KC{k < K}; }
+  __device__ Raw raw(const Row& w, int k) const { return Raw{X[w.o + (k < K ? k : 0)]}; }
+  __device__ float fin(const Row& w, const KC& c, const Raw& x) const { return (w.ok && c.ok) ? x.x : 0.f; }
 };
 // d(loss)/d(h) of a BatchNorm'd layer from the masked upstream gradient gy = d/d(y) * (y>0):
 //   train: gh = k1 * (gy - k2 - xhat * k3),  k1 = gamma*rstd, k2 = mean_r(gy), k3 = mean_r(gy*xhat)
@@ -65,29 +87,41 @@ struct APlain {  // a[r,k] = X[r,k]
 struct AGradH {  // gy materialised
   const float *GY, *H, *mean, *rstd, *k1, *k2, *k3;
   int ld, R, K;
-  struct Row { long o; };
-  __device__ Row row(int r) const { return Row{r < R ? (long)r * ld : -1}; }
-  __device__ float load(const Row& w, int k) const {
-    if (w.o < 0 || k >= K) return 0.f;
-    const float xh = (H[w.o + k] - mean[k]) * rstd[k];
-    return k1[k] * (GY[w.o + k] - k2[k] - xh * k3[k]);
+  struct Row { long o; bool ok; };
+  struct KC { float m, rs, k1, k2, k3; bool ok; };
+  struct Raw { float gy, h; };
+  __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
+  __device__ KC kc(int k) const {
+    const bool ok = k < K; const int c = ok ? k : 0;
+    return KC{mean[c], rstd[c], k1[c], k2[c], k3[c], ok};
+  }
+  __device__ Raw raw(const Row& w, int k) const { const int c = k < K ? k : 0; return Raw{GY[w.o + c], H[w.o + c]}; }
+  __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
+    const float v = c.k1 * (x.gy - c.k2 - (x.h - c.m) * c.rs * c.k3);
+    return (w.ok && c.ok) ? v : 0.f;
   }
 };
 struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o] = f*(g[r,:].W4[:,o]) * (y3 > 0)
   const float *G, *W4, *H, *s, *t, *mean, *rstd, *k1, *k2, *k3;
   float f;
   int ld, R, K;
-  struct Row { long o; float g0, g1, g2; };
-  __device__ Row row(int r) const {
-    if (r >= R) return Row{-1, 0.f, 0.f, 0.f};
-    return Row{(long)r * ld, f * G[(long)r * 3], f * G[(long)r * 3 + 1], f * G[(long)r * 3 + 2]};
+  struct Row { long o; float g0, g1, g2; bool ok; };
+  struct KC { float s, t, m, rs, k1, k2, k3, w0, w1, w2; bool ok; };
+  struct Raw { float h; };
+  __device__ Row row(int r, int) const {
+    const bool ok = r < R;
+    const long rr = ok ? r : 0;
+    return Row{rr * ld, f * G[rr * 3], f * G[rr * 3 + 1], f * G[rr * 3 + 2], ok};
   }
-  __device__ float load(const Row& w, int k) const {
-    if (w.o < 0 || k >= K) return 0.f;
-    const float h = H[w.o + k];
-    const float gy = __fmaf_rn(s[k], h, t[k]) > 0.f ? (w.g0 * W4[k] + w.g1 * W4[K + k] + w.g2 * W4[2 * K + k]) : 0.f;
-    const float xh = (h - mean[k]) * rstd[k];
-    return k1[k] * (gy - k2[k] - xh * k3[k]);
+  __device__ KC kc(int k) const {
+    const bool ok = k < K; const int c = ok ? k : 0;
+    return KC{s[c], t[c], mean[c], rstd[c], k1[c], k2[c], k3[c], W4[c], W4[K + c], W4[2 * K + c], ok};
+  }
+  __device__ Raw raw(const Row& w, int k) const { return Raw{H[w.o + (k < K ? k : 0)]}; }
+  __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
+    const float gy = __fmaf_rn(c.s, x.h, c.t) > 0.f ? (w.g0 * c.w0 + w.g1 * c.w1 + w.g2 * c.w2) : 0.f;
+    const float v = c.k1 * (gy - c.k2 - (x.h - c.m) * c.rs * c.k3);
+    return (w.ok && c.ok) ? v : 0.f;
   }
 };
 
@@ -108,6 +142,9 @@ struct EpiMaskStats {  // C = acc * (y > 0); per row-block column sums S1 = sum(
   int N;
 };
 
+template <class A> __device__ __forceinline__ int rows_N(const A&) { return 1 << 30; }
+__device__ __forceinline__ int rows_N(const AGridFeat& a) { return a.N; }
+
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // LDS tiles (k-major, +1 pad): As[buf][k][m], Bs[buf][k][n]
@@ -124,45 +161,57 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
 
-  // A staging: element e = tid + 256 p, k = e % 32, m = e / 32  (16 rows per thread, fixed k)
+  // A staging: element e = tid + 256 p, k = e % 32, m = e / 32  (16 rows per thread, fixed k per tile)
   const int ak = tid & 31, am0 = tid >> 5;
   typename AOp::Row rows[16];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) rows[p] = aop.row(bm0 + am0 + 8 * p);
-  float ra[16], rb[8];
-  auto fetch = [&](int k0) {
+  for (int p = 0; p < 16; ++p) {
+    const int r = bm0 + am0 + 8 * p;
+    rows[p] = aop.row(r, (r < aop.R ? r : aop.R - 1) / rows_N(aop));
+  }
+  typename AOp::Raw ra[16];
+  typename AOp::KC kcur;
+  float rb[8];
+  auto fetch = [&](int k0) {  // loads only: nothing here consumes a loaded value
+    kcur = aop.kc(k0 + ak);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) ra[p] = aop.load(rows[p], k0 + ak);
+    for (int p = 0; p < 16; ++p) ra[p] = aop.raw(rows[p], k0 + ak);
     if (B_NK) {  // W[n][k]: consecutive lanes along k
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int n = bn0 + (tid >> 5) + 8 * p, k = k0 + ak;
-        rb[p] = (n < Nc && k < K) ? Bw[(size_t)n * ldb + k] : 0.f;
+        rb[p] = Bw[(size_t)(n < Nc ? n : 0) * ldb + (k < K ? k : 0)];
       }
     } else {  // W[k][n]: consecutive lanes along n
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int n = bn0 + (tid & 63), k = k0 + (tid >> 6) + 4 * p;
-        rb[p] = (n < Nc && k < K) ? Bw[(size_t)k * ldb + n] : 0.f;
+        rb[p] = Bw[(size_t)(k < K ? k : 0) * ldb + (n < Nc ? n : 0)];
       }
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, int k0) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) T.As[buf][ak][am0 + 8 * p] = ra[p];
+    for (int p = 0; p < 16; ++p) T.As[buf][ak][am0 + 8 * p] = aop.fin(rows[p], kcur, ra[p]);
     if (B_NK) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) T.Bs[buf][ak][(tid >> 5) + 8 * p] = rb[p];
+      for (int p = 0; p < 8; ++p) {
+        const int n = bn0 + (tid >> 5) + 8 * p, k = k0 + ak;
+        T.Bs[buf][ak][(tid >> 5) + 8 * p] = (n < Nc && k < K) ? rb[p] : 0.f;
+      }
     } else {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) T.Bs[buf][(tid >> 6) + 4 * p][tid & 63] = rb[p];
+      for (int p = 0; p < 8; ++p) {
+        const int n = bn0 + (tid & 63), k = k0 + (tid >> 6) + 4 * p;
+        T.Bs[buf][(tid >> 6) + 4 * p][tid & 63] = (n < Nc && k < K) ? rb[p] : 0.f;
+      }
     }
   };
 
   f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
   const int nk = (K + BK - 1) / BK;
   fetch(0);
-  stash(0);
+  stash(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -176,7 +225,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
     }
-    if (kt + 1 < nk) stash(cur ^ 1);
+    if (kt + 1 < nk) stash(cur ^ 1, (kt + 1) * BK);
     __syncthreads();
   }
   epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, tid, smem);
@@ -276,27 +325,34 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
   const int mt = (M + BM - 1) / BM;
   const int bm0 = (blockIdx.x % mt) * BM, bn0 = (blockIdx.x / mt) * BN;
   const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
-  // staging: A tile [32 rows][128 m]: consecutive lanes along m (contiguous in the source row)
-  float ra[16], rb[8];
+  // staging: A tile [32 rows][128 m], B tile [32 rows][64 n]: consecutive lanes along m / n (contiguous in the source
+  // row).  The channel of a thread is fixed for the whole sweep: its constants are loaded once.
+  const typename AOp::KC kca = aop.kc(bm0 + (tid & 127));
+  const typename BOp::KC kcb = bop.kc(bn0 + (tid & 63));
+  typename AOp::Raw ra[16];
+  typename BOp::Raw rb[8];
+  typename AOp::Row rowa[16];
+  typename BOp::Row rowb[8];
   auto fetch = [&](int r0) {
+    const int bha = r0 / rows_N(aop), bhb = r0 / rows_N(bop);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      const int r = r0 + (tid >> 7) + 2 * p, m = bm0 + (tid & 127);
-      const typename AOp::Row w = aop.row(r < rend ? r : 0x7fffffff);
-      ra[p] = aop.load(w, m);
+      const int r = r0 + (tid >> 7) + 2 * p;
+      rowa[p] = aop.row(r < rend ? r : 0x7ffffff0, bha);
+      ra[p] = aop.raw(rowa[p], bm0 + (tid & 127));
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int r = r0 + (tid >> 6) + 4 * p, n = bn0 + (tid & 63);
-      const typename BOp::Row w = bop.row(r < rend ? r : 0x7fffffff);
-      rb[p] = bop.load(w, n);
+      const int r = r0 + (tid >> 6) + 4 * p;
+      rowb[p] = bop.row(r < rend ? r : 0x7ffffff0, bhb);
+      rb[p] = bop.raw(rowb[p], bn0 + (tid & 63));
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) T.As[buf][(tid >> 7) + 2 * p][tid & 127] = ra[p];
+    for (int p = 0; p < 16; ++p) T.As[buf][(tid >> 7) + 2 * p][tid & 127] = aop.fin(rowa[p], kca, ra[p]);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) T.Bs[buf][(tid >> 6) + 4 * p][tid & 63] = rb[p];
+    for (int p = 0; p < 8; ++p) T.Bs[buf][(tid >> 6) + 4 * p][tid & 63] = bop.fin(rowb[p], kcb, rb[p]);
   };
   f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
   const int nk = (rend - rbeg + BK - 1) / BK;
@@ -429,29 +485,38 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1,
   }
 }
 
-// moments [blocks][C][2] (sum, sum sq over each row block) -> mean/rstd, affine (s,t) of y = s*h + t, running stats
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// moments [blocks][C][2] (sum, sum sq over each row block) -> mean/rstd, affine (s,t) of y = s*h + t, running stats.
+// One wave per channel: lanes stride over the row blocks (fixed lane->block mapping + xor tree => deterministic).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ moments, int blocks, long R, int C, int training,
                                                           float eps, float momentum, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ s, float* __restrict__ t) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   float m, v;
   if (training) {
     double s1 = 0, s2 = 0;
-    for (int b = 0; b < blocks; ++b) { s1 += moments[((size_t)b * C + c) * 2]; s2 += moments[((size_t)b * C + c) * 2 + 1]; }
+    for (int b = lane; b < blocks; b += 64) { s1 += moments[((size_t)b * C + c) * 2]; s2 += moments[((size_t)b * C + c) * 2 + 1]; }
+    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
     const double mu = s1 / R;
     double var = s2 / R - mu * mu;
     if (var < 0) var = 0;
     m = (float)mu; v = (float)var;
-    if (rmean) {
+    if (rmean && lane == 0) {
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * ((double)R / (R > 1 ? R - 1 : 1)));
     }
   } else {
     m = rmean[c]; v = rvar[c];
   }
+  if (lane != 0) return;
   const float rs = 1.f / sqrtf(v + eps);
   mean[c] = m; rstd[c] = rs;
   s[c] = gamma[c] * rs;
@@ -520,16 +585,18 @@ __global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G
 }
 
 // sums [blocks][C][2] -> g_gamma = S2, g_beta = S1, gh coefficients k1 = gamma*rstd, k2 = S1/R, k3 = S2/R (0 in eval),
-// conv-bias gradient gb = sum_r gh = (train ? 0 : k1*S1)
+// conv-bias gradient gb = sum_r gh = (train ? 0 : k1*S1).  One wave per channel.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ sums, int blocks, long R, int C, int training,
                                                               const float* __restrict__ gamma, const float* __restrict__ rstd,
                                                               float* __restrict__ g_gamma, float* __restrict__ g_beta,
                                                               float* __restrict__ g_bias, float* __restrict__ k1,
                                                               float* __restrict__ k2, float* __restrict__ k3) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double s1 = 0, s2 = 0;
-  for (int b = 0; b < blocks; ++b) { s1 += sums[((size_t)b * C + c) * 2]; s2 += sums[((size_t)b * C + c) * 2 + 1]; }
+  for (int b = lane; b < blocks; b += 64) { s1 += sums[((size_t)b * C + c) * 2]; s2 += sums[((size_t)b * C + c) * 2 + 1]; }
+  s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+  if (lane != 0) return;
   g_gamma[c] = (float)s2;
   g_beta[c] = (float)s1;
   const float kk = gamma[c] * rstd[c];
@@ -539,13 +606,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   if (g_bias) g_bias[c] = training ? 0.f : kk * (float)s1;
 }
 
-// partial layer-4 weight gradients [blocks][3*C3+4] -> gW4 [3][C3], gb4 [3]
+// partial layer-4 weight gradients [blocks][3*C3+4] -> gW4 [3][C3], gb4 [3].  One wave per output element.
 __global__ __launch_bounds__(256) void l4_bwd_finalize_kernel(const float* __restrict__ gw, int blocks, int C3, float* __restrict__ gW4,
                                                               float* __restrict__ gb4) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= 3 * C3 + 3) return;
   double s = 0;
-  for (int b = 0; b < blocks; ++b) s += gw[(size_t)b * (3 * C3 + 4) + i];
+  for (int b = lane; b < blocks; b += 64) s += gw[(size_t)b * (3 * C3 + 4) + i];
+  s = wave_sum_f64(s);
+  if (lane != 0) return;
   if (i < 3 * C3) gW4[i] = (float)s; else gb4[i - 3 * C3] = (float)s;
 }
 
@@ -579,46 +648,63 @@ __global__ __launch_bounds__(256) void l1_reduce_kernel(const float* __restrict_
   }
 }
 
-// BN-1 backward in factored form.  Thread = channel.  Produces g_gamma1, g_beta1, dF [B,ld1], dG [N,ld1],
-// g_b1 = sum_b dF, and gW1[:, 0:3] = dG^T grid.
-__global__ __launch_bounds__(256) void l1_finalize_kernel(const float* __restrict__ P, const float* __restrict__ Q,
-                                                          const float* __restrict__ Gx, const float* __restrict__ Fx, int ld1,
-                                                          int B, int N, int C1, int training, const float* __restrict__ gamma,
-                                                          const float* __restrict__ rstd1, const float* __restrict__ grid,
-                                                          float* __restrict__ g_gamma, float* __restrict__ g_beta,
-                                                          float* __restrict__ g_b1, float* __restrict__ gW1, float* __restrict__ dF,
-                                                          float* __restrict__ dG) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C1) return;
+// BN-1 backward in factored form.  Block = 64 channels x 16 row groups (coalesced along channels; the rows of P/Fx
+// (B) and Q/Gx (N) are split over the 16 groups and merged through LDS in group order => deterministic).
+// Produces g_gamma1, g_beta1, dF [B,ld1], dG [N,ld1], g_b1 = sum_b dF, and gW1[:, 0:3] = dG^T grid.
+__global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                           const float* __restrict__ Gx, const float* __restrict__ Fx, int ld1,
+                                                           int B, int N, int C1, int training, const float* __restrict__ gamma,
+                                                           const float* __restrict__ rstd1, const float* __restrict__ grid,
+                                                           float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                           float* __restrict__ g_b1, float* __restrict__ gW1, float* __restrict__ dF,
+                                                           float* __restrict__ dG) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;  // rg = row group 0..15 (= wave)
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < C1;
+  __shared__ double red[16][4][64];
+  __shared__ float redf[16][4][64];
   double s1 = 0, s2 = 0, sgx = 0, sfx = 0;
-  for (int b = 0; b < B; ++b) {
-    const double p = P[(size_t)b * ld1 + c], fx = Fx[(size_t)b * ld1 + c];
-    s1 += p; s2 += p * fx; sfx += fx;
+  if (ok) {
+    for (int b = rg; b < B; b += 16) {
+      const double p = P[(size_t)b * ld1 + c], fx = Fx[(size_t)b * ld1 + c];
+      s1 += p; s2 += p * fx; sfx += fx;
+    }
+    for (int n = rg; n < N; n += 16) {
+      const double gx = Gx[(size_t)n * ld1 + c];
+      s2 += gx * (double)Q[(size_t)n * ld1 + c];
+      sgx += gx;
+    }
   }
-  for (int n = 0; n < N; ++n) {
-    const double gx = Gx[(size_t)n * ld1 + c];
-    s2 += gx * (double)Q[(size_t)n * ld1 + c];
-    sgx += gx;
-  }
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2; red[rg][2][cl] = sgx; red[rg][3][cl] = sfx;
+  __syncthreads();
+  s1 = s2 = sgx = sfx = 0;
+  for (int g = 0; g < 16; ++g) { s1 += red[g][0][cl]; s2 += red[g][1][cl]; sgx += red[g][2][cl]; sfx += red[g][3][cl]; }
   const double R = (double)B * N;
-  g_gamma[c] = (float)s2;
-  g_beta[c] = (float)s1;
-  const float k1 = gamma[c] * rstd1[c];
+  const float k1 = ok ? gamma[c] * rstd1[c] : 0.f;
   const float k2 = training ? (float)(s1 / R) : 0.f, k3 = training ? (float)(s2 / R) : 0.f;
-  float gb = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float v = k1 * (P[(size_t)b * ld1 + c] - N * k2 - k3 * ((float)sgx + N * Fx[(size_t)b * ld1 + c]));
-    dF[(size_t)b * ld1 + c] = v;
-    gb += v;
+  float gb = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  if (ok) {
+    for (int b = rg; b < B; b += 16) {
+      const float v = k1 * (P[(size_t)b * ld1 + c] - N * k2 - k3 * ((float)sgx + N * Fx[(size_t)b * ld1 + c]));
+      dF[(size_t)b * ld1 + c] = v;
+      gb += v;
+    }
+    for (int n = rg; n < N; n += 16) {
+      const float v = k1 * (Q[(size_t)n * ld1 + c] - B * k2 - k3 * (B * Gx[(size_t)n * ld1 + c] + (float)sfx));
+      dG[(size_t)n * ld1 + c] = v;
+      w0 = __fmaf_rn(v, grid[n * 3], w0); w1 = __fmaf_rn(v, grid[n * 3 + 1], w1); w2 = __fmaf_rn(v, grid[n * 3 + 2], w2);
+    }
   }
-  g_b1[c] = gb;
-  float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float v = k1 * (Q[(size_t)n * ld1 + c] - B * k2 - k3 * (B * Gx[(size_t)n * ld1 + c] + (float)sfx));
-    dG[(size_t)n * ld1 + c] = v;
-    w0 = __fmaf_rn(v, grid[n * 3], w0); w1 = __fmaf_rn(v, grid[n * 3 + 1], w1); w2 = __fmaf_rn(v, grid[n * 3 + 2], w2);
+  redf[rg][0][cl] = gb; redf[rg][1][cl] = w0; redf[rg][2][cl] = w1; redf[rg][3][cl] = w2;
+  __syncthreads();
+  if (rg == 0 && ok) {
+    gb = w0 = w1 = w2 = 0.f;
+    for (int g = 0; g < 16; ++g) { gb += redf[g][0][cl]; w0 += redf[g][1][cl]; w1 += redf[g][2][cl]; w2 += redf[g][3][cl]; }
+    g_gamma[c] = (float)s2;
+    g_beta[c] = (float)s1;
+    g_b1[c] = gb;
+    gW1[(size_t)c * C1] = w0; gW1[(size_t)c * C1 + 1] = w1; gW1[(size_t)c * C1 + 2] = w2;
   }
-  gW1[(size_t)c * C1] = w0; gW1[(size_t)c * C1 + 1] = w1; gW1[(size_t)c * C1 + 2] = w2;
 }
 
 // out[m*ldo + off + n] = sum_c part[c][m][n]   (fixed chunk order)
@@ -666,6 +752,15 @@ FwdWs fwd_ws(const Dims& d) {
   w.total = o;
   return w;
 }
+// rows per split-K chunk: enough chunks that tiles x chunks covers the chip ~4x, never below 128 rows
+int tn_chunk_rows(int M, int Nc, long R) {
+  const long tiles = (long)((M + BM - 1) / BM) * ((Nc + BN - 1) / BN);
+  long want = (1024 + tiles - 1) / tiles;                 // chunks wanted
+  long rows = (R + want - 1) / want;
+  rows = (rows + BK - 1) / BK * BK;
+  if (rows < 128) rows = 128;
+  return (int)rows;
+}
 struct BwdWs {
   long GY2, GY1, sums, k, l4p, P, Q, dF, dG, tn, total;
   int chunks;
@@ -680,9 +775,15 @@ BwdWs bwd_ws(const Dims& d) {
   w.k = take(3 * d.ld1);
   w.l4p = take((long)l4b * (3 * d.C3 + 4));
   w.P = take((long)d.B * d.ld1); w.Q = take((long)d.N * d.ld1); w.dF = take((long)d.B * d.ld1); w.dG = take((long)d.N * d.ld1);
-  {  // split-K partials of the largest weight-gradient product; gW1 = dF^T feat is one chunk of C1 x (C1-3)
-    const long a = (long)w.chunks * d.C1 * d.C2, b = (long)d.C1 * d.C1;
-    w.tn = take(a > b ? a : b);
+  {  // split-K partials: the largest of the three weight-gradient products
+    auto need = [&](int M, int Nc, long R) {
+      const int rows = tn_chunk_rows(M, Nc, R);
+      return ((R + rows - 1) / rows) * (long)M * Nc;
+    };
+    long a = need(d.C3, d.C2, d.R), b = need(d.C2, d.C1, d.R), c = need(d.C1, d.C1 - 3, d.B);
+    if (b > a) a = b;
+    if (c > a) a = c;
+    w.tn = take(a);
   }
   w.total = o;
   return w;
@@ -696,7 +797,8 @@ int launch_rows(const AOp& a, const float* W, int ldb, int K, int Nc, long R, co
   return 0;
 }
 template <class AOp, class BOp>
-int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int chunk_rows, float* part, float* out, int ldo, int off, hipStream_t st) {
+int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* part, float* out, int ldo, int off, hipStream_t st) {
+  const int chunk_rows = tn_chunk_rows(M, Nc, R);
   const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
   dim3 grid((unsigned)(((M + BM - 1) / BM) * ((Nc + BN - 1) / BN)), (unsigned)chunks);
   gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part);
@@ -740,7 +842,7 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
     e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
     int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
     if (rc) return rc;
-    bn_finalize_kernel<<<obman_cdiv(d.C2, 256), 256, 0, st>>>(moments, d.rb, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
+    bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(moments, d.rb, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
                                                                p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
     OBMAN_LAUNCH_CHECK();
   }
@@ -750,7 +852,7 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
     e.C = ws + w.H3; e.bias = p->b3; e.moments = tr ? moments : nullptr; e.ldc = d.ld3; e.R = (int)d.R; e.Nc = d.C3;
     int rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
     if (rc) return rc;
-    bn_finalize_kernel<<<obman_cdiv(d.C3, 256), 256, 0, st>>>(moments, d.rb, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
+    bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(moments, d.rb, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
     OBMAN_LAUNCH_CHECK();
   }
@@ -777,8 +879,8 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
   l4_bwd_kernel<<<l4b, 128, 0, st>>>(g_out, ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3,
                                       L4_ROWS, sums, ws2 + v.l4p);
   OBMAN_LAUNCH_CHECK();
-  l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 256), 256, 0, st>>>(ws2 + v.l4p, l4b, d.C3, g->w4, g->b4);
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 256), 256, 0, st>>>(sums, l4b, d.R, d.C3, tr, p->bn_w[2], ws + w.rstd3, g->bn_w[2], g->bn_b[2],
+  l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 4), 256, 0, st>>>(ws2 + v.l4p, l4b, d.C3, g->w4, g->b4);
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sums, l4b, d.R, d.C3, tr, p->bn_w[2], ws + w.rstd3, g->bn_w[2], g->bn_b[2],
                                                                  g->b3, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
   AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, k1, k2, k3, f, d.ld3, R, d.C3};
@@ -796,7 +898,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st);
     if (rc) return rc;
   }
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 256), 256, 0, st>>>(sums, d.rb, d.R, d.C2, tr, p->bn_w[1], ws + w.rstd2, g->bn_w[1], g->bn_b[1],
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sums, d.rb, d.R, d.C2, tr, p->bn_w[1], ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
   AGradH gh2{ws2 + v.GY2, ws + w.H2, ws + w.mean2, ws + w.rstd2, k1, k2, k3, d.ld2, R, d.C2};
@@ -815,7 +917,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
   l1_reduce_kernel<<<dim3(d.B > d.N ? d.B : d.N, 2, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, ws2 + v.P,
                                                                                             ws2 + v.Q);
   OBMAN_LAUNCH_CHECK();
-  l1_finalize_kernel<<<obman_cdiv(d.C1, 256), 256, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
+  l1_finalize_kernel<<<obman_cdiv(d.C1, 64), 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
                                                              ws + w.rstd1, p->grid, g->bn_w[0], g->bn_b[0], g->b1, g->w1, ws2 + v.dF, ws2 + v.dG);
   OBMAN_LAUNCH_CHECK();
   const int Cf = d.C1 - 3;

@@ -91,6 +91,28 @@ def bench_contains():
                               Gpairs_per_s=round(pairs / t / 1e3, 1), valu_TFLOPs=round(pairs * 50 / t / 1e6, 1))), flush=True)
 
 
+def bench_decoder():
+    import numpy as np
+
+    from obman_train_amd import ops
+    from obman_train_amd.icosphere import multi_patch
+    from obman_train_amd.networks.branches.atlasutils import PointGenCon
+
+    for B, patches in ((64, 1),):
+        dec = PointGenCon(bottleneck_size=515).cuda().train()
+        grid = torch.from_numpy(multi_patch(3, patches)[0].astype(np.float32)).cuda()
+        feats = torch.randn(B, 512, device="cuda").requires_grad_()
+        t_f = kernel_us(lambda: ops.pointgen_decode(dec, feats, grid), 8, iters=10, warmup=3)
+        out = ops.pointgen_decode(dec, feats, grid)
+        loss = out.square().mean()
+        params = [feats] + list(dec.parameters())
+        t_b = kernel_us(lambda: torch.autograd.grad(loss, params, retain_graph=True), 9, iters=10, warmup=3)
+        R = B * grid.shape[0]
+        flop_f = 2.0 * R * (515 * 257 + 257 * 128 + 128 * 3)
+        print(json.dumps(dict(kernel="decoder", B=B, N=int(grid.shape[0]), fwd_us=round(t_f, 1), bwd_us=round(t_b, 1),
+                              fwd_TFLOPs=round(flop_f / t_f / 1e6, 1), bwd_TFLOPs=round(2 * flop_f / t_b / 1e6, 1))), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.zeros(1, device="cuda")
@@ -100,3 +122,5 @@ if __name__ == "__main__":
         bench_mano()
     if which in ("contains", "all"):
         bench_contains()
+    if which in ("decoder", "all"):
+        bench_decoder()
