@@ -101,6 +101,10 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         if x.is_cuda:
+            if not getattr(self, "_nhwc_weights", False):
+                # keep the filters in NHWC too, once: otherwise every conv call re-lays them out (52 copies / step)
+                self.to(memory_format=torch.channels_last)
+                self._nhwc_weights = True
             x = x.contiguous(memory_format=torch.channels_last)
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
