@@ -139,6 +139,17 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
 int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const float* ws, float* ws2,
                        const obman_pointgen_grads* g, obman_stream_t stream);
 
+/* ---- fused BatchNorm2d (+ skip add) (+ ReLU), NHWC fp32 --------------------------------------------
+ * Replaces bn -> relu and bn -> (+residual) -> relu of the ResNet blocks (bases/resnet.py:38-52,77-96) - separate
+ * memory-bound passes in eager PyTorch.  x, skip, y, dy, dx, dskip are [R, C] row-major (R = B*H*W of a
+ * channels_last tensor), C % 64 == 0.  stats [4*C] = mean | rstd | scale | shift (fwd -> bwd).
+ * ws: obman_bnact_ws_floats(R, C) floats of scratch. */
+long obman_bnact_ws_floats(long R, int C);
+int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const float* beta, float* rmean, float* rvar, long R, int C,
+                    int training, float eps, float momentum, int relu, float* y, float* stats, float* ws, obman_stream_t stream);
+int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats, long R, int C, int training,
+                    int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream);
+
 /* ---- measurement utility (not on the product path) ----------------------------------------------
  * obman_prof_enable(1) makes the launchers bracket their main kernel with HIP events on the launch
  * stream (pool of 8192 records, reset by every enable call); obman_prof_summary synchronises and

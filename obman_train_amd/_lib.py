@@ -25,6 +25,9 @@ _SIGNATURES = {
     "obman_pointgen_ws_floats": (_c_long, "pi"),
     "obman_pointgen_fwd": (_c_int, "pppp"),
     "obman_pointgen_bwd": (_c_int, "pppppp"),
+    "obman_bnact_ws_floats": (_c_long, "li"),
+    "obman_bnact_fwd": (_c_int, "pppppp" "li" "iffi" "ppp" "p"),
+    "obman_bnact_bwd": (_c_int, "ppppp" "li" "iii" "ppppp" "p"),
     "obman_prof_enable": (_c_int, "i"),
     "obman_prof_summary": (_c_int, "ipp"),
     "obman_mano_model_floats": (_c_int, ""),

@@ -1,0 +1,249 @@
+// Fused BatchNorm2d (+ residual add) (+ ReLU), NHWC fp32, forward and backward, for the ResNet encoder
+// (resnet.py:25-52 BasicBlock: conv -> bn -> relu -> conv -> bn -> (+skip) -> relu).
+//
+// Eager PyTorch runs this as separate memory-bound passes (MIOpen BN statistics + normalise, clamp, add; in the
+// backward threshold_backward + two BN kernels): ~3.4 ms of a 13 ms step (profiles/r01b).  Here:
+//   fwd : stats pass (read x)            + apply pass (read x [, skip], write y)
+//   bwd : sums pass (read dy, x [, y])   + apply pass (read dy|dz, x, write dx)   [dz materialised only when a skip
+//         connection needs it as its own gradient]
+// The ReLU mask of the non-residual case is recomputed from x (s*x+t > 0), so y is never read back.
+// Layout: rows = B*H*W, C channels contiguous (torch channels_last).  Block = 16 row-lanes x 16 float4 columns
+// (64 channels); a wave reads 4 rows x 256 contiguous bytes.  Per-block partial moments are fp64; one wave per
+// channel merges them in fixed order (deterministic).  Bound: HBM bandwidth.
+#include "common.h"
+#include "../../include/obman_hip.h"
+
+namespace bnact {
+
+constexpr int CT = 64;  // channels per block column
+
+struct Geo { long R; int C, rows_per_blk, nblk; };
+
+__device__ __forceinline__ double wsum64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// accumulate two per-channel quantities over a chunk of rows; partial[blk][C][2]
+template <int MODE>  // 0: (x, x^2)   1: (dz, dz*xhat) mask from s*x+t   2: same, mask from y, optional dz store   3: no relu
+__global__ __launch_bounds__(256) void sums_kernel(const float* __restrict__ X, const float* __restrict__ DY, const float* __restrict__ Y,
+                                                   const float* __restrict__ sc, const float* __restrict__ sh,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd, Geo g,
+                                                   float* __restrict__ DZ, double* __restrict__ partial) {
+  const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+  const int c = blockIdx.y * CT + cl * 4;
+  const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);
+  float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
+  float4 vs = make_float4(0, 0, 0, 0), vt = vs, vm = vs, vr = vs;
+  if (MODE != 0) {
+    vm = *reinterpret_cast<const float4*>(mean + c);
+    vr = *reinterpret_cast<const float4*>(rstd + c);
+    if (MODE == 1) { vs = *reinterpret_cast<const float4*>(sc + c); vt = *reinterpret_cast<const float4*>(sh + c); }
+  }
+  for (long r = r0 + rl; r < r1; r += 16) {
+    const size_t o = (size_t)r * g.C + c;
+    const float4 x = *reinterpret_cast<const float4*>(X + o);
+    if (MODE == 0) {
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+      b.x = __fmaf_rn(x.x, x.x, b.x); b.y = __fmaf_rn(x.y, x.y, b.y); b.z = __fmaf_rn(x.z, x.z, b.z); b.w = __fmaf_rn(x.w, x.w, b.w);
+    } else {
+      float4 d = *reinterpret_cast<const float4*>(DY + o);
+      if (MODE == 1) {
+        d.x = __fmaf_rn(vs.x, x.x, vt.x) > 0.f ? d.x : 0.f; d.y = __fmaf_rn(vs.y, x.y, vt.y) > 0.f ? d.y : 0.f;
+        d.z = __fmaf_rn(vs.z, x.z, vt.z) > 0.f ? d.z : 0.f; d.w = __fmaf_rn(vs.w, x.w, vt.w) > 0.f ? d.w : 0.f;
+      } else if (MODE == 2) {
+        const float4 y = *reinterpret_cast<const float4*>(Y + o);
+        d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f; d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
+        if (DZ) *reinterpret_cast<float4*>(DZ + o) = d;
+      }
+      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+      b.x = __fmaf_rn(d.x, (x.x - vm.x) * vr.x, b.x); b.y = __fmaf_rn(d.y, (x.y - vm.y) * vr.y, b.y);
+      b.z = __fmaf_rn(d.z, (x.z - vm.z) * vr.z, b.z); b.w = __fmaf_rn(d.w, (x.w - vm.w) * vr.w, b.w);
+    }
+  }
+  __shared__ float red[16][CT][2];
+  red[rl][cl * 4 + 0][0] = a.x; red[rl][cl * 4 + 1][0] = a.y; red[rl][cl * 4 + 2][0] = a.z; red[rl][cl * 4 + 3][0] = a.w;
+  red[rl][cl * 4 + 0][1] = b.x; red[rl][cl * 4 + 1][1] = b.y; red[rl][cl * 4 + 2][1] = b.z; red[rl][cl * 4 + 3][1] = b.w;
+  __syncthreads();
+  if (tid < CT * 2) {
+    const int ch = tid >> 1, q = tid & 1;
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += (double)red[k][ch][q];
+    partial[((size_t)blockIdx.x * g.C + blockIdx.y * CT + ch) * 2 + q] = s;
+  }
+}
+
+// forward statistics -> mean, rstd, affine (s, t), running-stat update.  One wave per channel.
+__global__ __launch_bounds__(256) void fwd_finalize_kernel(const double* __restrict__ partial, int nblk, long R, int C, int training,
+                                                           float eps, float momentum, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ sc, float* __restrict__ sh) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float m, v;
+  if (training) {
+    double s1 = 0, s2 = 0;
+    for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * C + c) * 2]; s2 += partial[((size_t)b * C + c) * 2 + 1]; }
+    s1 = wsum64(s1); s2 = wsum64(s2);
+    const double mu = s1 / R;
+    double var = s2 / R - mu * mu;
+    if (var < 0) var = 0;
+    m = (float)mu; v = (float)var;
+    if (rmean && lane == 0) {
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * ((double)R / (R > 1 ? R - 1 : 1)));
+    }
+  } else {
+    m = rmean[c]; v = rvar[c];
+  }
+  if (lane != 0) return;
+  const float rs = 1.f / sqrtf(v + eps);
+  mean[c] = m; rstd[c] = rs;
+  sc[c] = gamma[c] * rs;
+  sh[c] = beta[c] - m * gamma[c] * rs;
+}
+
+// y = act(s*x + t [+ skip])
+__global__ __launch_bounds__(256) void fwd_apply_kernel(const float* __restrict__ X, const float* __restrict__ S, const float* __restrict__ sc,
+                                                        const float* __restrict__ sh, Geo g, int relu, float* __restrict__ Y) {
+  const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+  const int c = blockIdx.y * CT + cl * 4;
+  const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);
+  const float4 vs = *reinterpret_cast<const float4*>(sc + c), vt = *reinterpret_cast<const float4*>(sh + c);
+  for (long r = r0 + rl; r < r1; r += 16) {
+    const size_t o = (size_t)r * g.C + c;
+    const float4 x = *reinterpret_cast<const float4*>(X + o);
+    float4 y = make_float4(__fmaf_rn(vs.x, x.x, vt.x), __fmaf_rn(vs.y, x.y, vt.y), __fmaf_rn(vs.z, x.z, vt.z), __fmaf_rn(vs.w, x.w, vt.w));
+    if (S) {
+      const float4 k = *reinterpret_cast<const float4*>(S + o);
+      y.x += k.x; y.y += k.y; y.z += k.z; y.w += k.w;
+    }
+    if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    *reinterpret_cast<float4*>(Y + o) = y;
+  }
+}
+
+// backward sums -> d_gamma, d_beta and the coefficients of dx = k1 * (dz - k2 - xhat * k3)
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restrict__ partial, int nblk, long R, int C, int training,
+                                                           const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * C + c) * 2]; s2 += partial[((size_t)b * C + c) * 2 + 1]; }
+  s1 = wsum64(s1); s2 = wsum64(s2);
+  if (lane != 0) return;
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+  k[c] = gamma[c] * rstd[c];
+  k[C + c] = training ? (float)(s1 / R) : 0.f;
+  k[2 * C + c] = training ? (float)(s2 / R) : 0.f;
+}
+
+// dx = k1 * (dz - k2 - xhat*k3); dz = DZ (materialised) or dy masked by s*x+t > 0 (relu) or dy (no relu)
+template <int MODE>  // 1: mask from x   2: dz given   3: no relu
+__global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ sc,
+                                                        const float* __restrict__ sh, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ k, Geo g,
+                                                        float* __restrict__ DX) {
+  const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+  const int c = blockIdx.y * CT + cl * 4;
+  const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);
+  const float4 vm = *reinterpret_cast<const float4*>(mean + c), vr = *reinterpret_cast<const float4*>(rstd + c);
+  const float4 k1 = *reinterpret_cast<const float4*>(k + c), k2 = *reinterpret_cast<const float4*>(k + g.C + c),
+               k3 = *reinterpret_cast<const float4*>(k + 2 * g.C + c);
+  float4 vs = make_float4(0, 0, 0, 0), vt = vs;
+  if (MODE == 1) { vs = *reinterpret_cast<const float4*>(sc + c); vt = *reinterpret_cast<const float4*>(sh + c); }
+  for (long r = r0 + rl; r < r1; r += 16) {
+    const size_t o = (size_t)r * g.C + c;
+    const float4 x = *reinterpret_cast<const float4*>(X + o);
+    float4 d = *reinterpret_cast<const float4*>(D + o);
+    if (MODE == 1) {
+      d.x = __fmaf_rn(vs.x, x.x, vt.x) > 0.f ? d.x : 0.f; d.y = __fmaf_rn(vs.y, x.y, vt.y) > 0.f ? d.y : 0.f;
+      d.z = __fmaf_rn(vs.z, x.z, vt.z) > 0.f ? d.z : 0.f; d.w = __fmaf_rn(vs.w, x.w, vt.w) > 0.f ? d.w : 0.f;
+    }
+    float4 o4;
+    o4.x = k1.x * (d.x - k2.x - (x.x - vm.x) * vr.x * k3.x);
+    o4.y = k1.y * (d.y - k2.y - (x.y - vm.y) * vr.y * k3.y);
+    o4.z = k1.z * (d.z - k2.z - (x.z - vm.z) * vr.z * k3.z);
+    o4.w = k1.w * (d.w - k2.w - (x.w - vm.w) * vr.w * k3.w);
+    *reinterpret_cast<float4*>(DX + o) = o4;
+  }
+}
+
+Geo geo(long R, int C) {
+  Geo g; g.R = R; g.C = C;
+  const long col_blocks = C / CT;
+  long want = 4096 / col_blocks;  // ~4096 blocks in total
+  if (want < 1) want = 1;
+  long rows = (R + want - 1) / want;
+  rows = (rows + 15) / 16 * 16;
+  if (rows < 64) rows = 64;
+  g.rows_per_blk = (int)rows;
+  g.nblk = (int)((R + rows - 1) / rows);
+  return g;
+}
+
+}  // namespace bnact
+
+extern "C" {
+
+long obman_bnact_ws_floats(long R, int C) {
+  if (R <= 0 || C <= 0 || C % bnact::CT) return -1;
+  const bnact::Geo g = bnact::geo(R, C);
+  return (long)g.nblk * C * 2 * 2 + 3L * C + 16;  // fp64 partials + backward coefficients
+}
+
+/* stats: [mean C | rstd C | scale C | shift C] written by fwd and read by bwd */
+int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const float* beta, float* rmean, float* rvar, long R, int C,
+                    int training, float eps, float momentum, int relu, float* y, float* stats, float* ws, obman_stream_t stream) {
+  if (!x || !y || !stats || !ws || !gamma || !beta || R <= 0 || C <= 0 || C % bnact::CT) return -1;
+  if (!training && (!rmean || !rvar)) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const bnact::Geo g = bnact::geo(R, C);
+  dim3 grid(g.nblk, C / bnact::CT);
+  double* partial = reinterpret_cast<double*>(ws);
+  float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
+  if (training) {
+    bnact::sums_kernel<0><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
+    OBMAN_LAUNCH_CHECK();
+  }
+  bnact::fwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, eps, momentum, gamma, beta, rmean, rvar, mean,
+                                                                rstd, sc, sh);
+  OBMAN_LAUNCH_CHECK();
+  bnact::fwd_apply_kernel<<<grid, 256, 0, st>>>(x, skip, sc, sh, g, relu, y);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
+/* dy -> dx, dgamma, dbeta [, dskip].  y is needed only with a skip connection (mask of the post-add ReLU).  dskip (the
+ * gradient flowing into the skip branch = masked dy) is written when non-NULL; it doubles as the dz scratch, so it is
+ * required whenever relu && has_skip. */
+int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats, long R, int C, int training,
+                    int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream) {
+  if (!x || !dy || !stats || !ws || !dx || !dgamma || !dbeta || R <= 0 || C % bnact::CT) return -1;
+  if (relu && has_skip && (!y || !dskip)) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const bnact::Geo g = bnact::geo(R, C);
+  dim3 grid(g.nblk, C / bnact::CT);
+  double* partial = reinterpret_cast<double*>(ws);
+  float* k = ws + (size_t)g.nblk * C * 2 * 2;  // 3*C coefficients live behind the partials
+  const float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
+  const int mode = !relu ? 3 : (has_skip ? 2 : 1);
+  if (mode == 1) bnact::sums_kernel<1><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
+  else if (mode == 2) bnact::sums_kernel<2><<<grid, 256, 0, st>>>(x, dy, y, sc, sh, mean, rstd, g, dskip, partial);
+  else bnact::sums_kernel<3><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
+  OBMAN_LAUNCH_CHECK();
+  bnact::bwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, gamma, rstd, dgamma, dbeta, k);
+  OBMAN_LAUNCH_CHECK();
+  if (mode == 1) bnact::bwd_apply_kernel<1><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
+  else if (mode == 2) bnact::bwd_apply_kernel<2><<<grid, 256, 0, st>>>(x, dskip, sc, sh, mean, rstd, k, g, dx);
+  else bnact::bwd_apply_kernel<3><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

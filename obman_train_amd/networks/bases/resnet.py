@@ -18,6 +18,8 @@ import warnings
 import torch
 from torch import nn
 
+from obman_train_amd import ops
+
 __all__ = ["ResNet", "resnet18", "resnet50"]
 
 
@@ -38,10 +40,12 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        skip = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return self.relu(y + skip)
+        if self.downsample is None:
+            skip = x
+        else:
+            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        y = ops.bn_act(self.bn1, self.conv1(x))
+        return ops.bn_act(self.bn2, self.conv2(y), skip=skip)
 
 
 class Bottleneck(nn.Module):
@@ -59,11 +63,13 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        skip = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + skip)
+        if self.downsample is None:
+            skip = x
+        else:
+            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        y = ops.bn_act(self.bn1, self.conv1(x))
+        y = ops.bn_act(self.bn2, self.conv2(y))
+        return ops.bn_act(self.bn3, self.conv3(y), skip=skip)
 
 
 class ResNet(nn.Module):
@@ -106,7 +112,7 @@ class ResNet(nn.Module):
                 self.to(memory_format=torch.channels_last)
                 self._nhwc_weights = True
             x = x.contiguous(memory_format=torch.channels_last)
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(ops.bn_act(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = x.mean(3).mean(2)
         x = x.view(x.size(0), -1)

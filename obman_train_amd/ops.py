@@ -327,3 +327,66 @@ def pointgen_decode(decoder, features, grid):
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
     return out
+
+
+def _is_nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+class _BNAct(torch.autograd.Function):
+    """BatchNorm2d (+ skip) (+ ReLU) on a channels_last fp32 tensor (csrc/bnact.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, rmean, rvar, training, eps, momentum, relu):
+        B, C, H, W = x.shape
+        R = B * H * W
+        lib = _lib.lib()
+        y = torch.empty_like(x)  # preserves channels_last
+        stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.obman_bnact_ws_floats(R, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.obman_bnact_fwd(x.data_ptr(), _ptr(skip), weight.data_ptr(), bias.data_ptr(), _ptr(rmean), _ptr(rvar), R, C,
+                                       int(training), float(eps), float(momentum), int(relu), y.data_ptr(), stats.data_ptr(),
+                                       ws.data_ptr(), _stream()), "obman_bnact_fwd")
+        ctx.save_for_backward(x, y if (relu and skip is not None) else None, weight, stats)
+        ctx.cfg = (R, C, int(training), int(relu), skip is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, stats = ctx.saved_tensors
+        R, C, training, relu, has_skip = ctx.cfg
+        lib = _lib.lib()
+        if not _is_nhwc(dy):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(weight)
+        dbeta = torch.empty_like(weight)
+        dskip = torch.empty_like(x) if (has_skip and relu) else None
+        ws = torch.empty(lib.obman_bnact_ws_floats(R, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.obman_bnact_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), weight.data_ptr(), stats.data_ptr(), R, C, training, relu,
+                                       int(has_skip), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dskip), ws.data_ptr(),
+                                       _stream()), "obman_bnact_bwd")
+        if has_skip and not relu:
+            dskip = dy
+        return dx, dskip, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act(bn, x, skip=None, relu=True):
+    """``relu(bn(x) [+ skip])`` for an ``nn.BatchNorm2d`` module ``bn``.  Fused HIP path for channels_last fp32 ROCm tensors
+    whose channel count is a multiple of 64 (every ResNet-18/50 stage); anything else takes the stock PyTorch ops."""
+    fused = (x.is_cuda and x.dtype == torch.float32 and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
+             and (skip is None or (_is_nhwc(skip) and skip.dtype == torch.float32 and skip.shape == x.shape)))
+    training = bn.training or bn.running_mean is None
+    if not fused:
+        y = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
+                                           0.0 if bn.momentum is None else bn.momentum, bn.eps)
+        if skip is not None:
+            y = y + skip
+        return torch.relu(y) if relu else y
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    if bn.momentum is None:
+        momentum = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
+    else:
+        momentum = bn.momentum
+    return _BNAct.apply(x, skip, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum, relu)
