@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void sums_kernel(const float* __restrict__ X, 
     double s = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += (double)red[k][ch][q];
-    partial[((size_t)blockIdx.x * g.C + blockIdx.y * CT + ch) * 2 + q] = s;
+    partial[((size_t)(blockIdx.y * CT + ch) * g.nblk + blockIdx.x) * 2 + q] = s;  // channel-major: the finalize wave reads contiguously
   }
 }
 
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void fwd_finalize_kernel(const double* __restr
   float m, v;
   if (training) {
     double s1 = 0, s2 = 0;
-    for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * C + c) * 2]; s2 += partial[((size_t)b * C + c) * 2 + 1]; }
+    for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)c * nblk + b) * 2]; s2 += partial[((size_t)c * nblk + b) * 2 + 1]; }
     s1 = wsum64(s1); s2 = wsum64(s2);
     const double mu = s1 / R;
     double var = s2 / R - mu * mu;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restr
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double s1 = 0, s2 = 0;
-  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)b * C + c) * 2]; s2 += partial[((size_t)b * C + c) * 2 + 1]; }
+  for (int b = lane; b < nblk; b += 64) { s1 += partial[((size_t)c * nblk + b) * 2]; s2 += partial[((size_t)c * nblk + b) * 2 + 1]; }
   s1 = wsum64(s1); s2 = wsum64(s2);
   if (lane != 0) return;
   dgamma[c] = (float)s2;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
 Geo geo(long R, int C) {
   Geo g; g.R = R; g.C = C;
   const long col_blocks = C / CT;
-  long want = 4096 / col_blocks;  // ~4096 blocks in total
+  long want = 2048 / col_blocks;  // ~2048 blocks in total (8 per CU); fewer partials for the finalize wave
   if (want < 1) want = 1;
   long rows = (R + want - 1) / want;
   rows = (rows + 15) / 16 * 16;

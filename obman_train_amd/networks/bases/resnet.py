@@ -29,6 +29,7 @@ def _conv(cin, cout, k, stride=1):
 
 class BasicBlock(nn.Module):
     expansion = 1
+    _count = True  # False while ResNet.forward bumps every num_batches_tracked in one foreach launch
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
@@ -43,13 +44,14 @@ class BasicBlock(nn.Module):
         if self.downsample is None:
             skip = x
         else:
-            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False)
-        y = ops.bn_act(self.bn1, self.conv1(x))
-        return ops.bn_act(self.bn2, self.conv2(y), skip=skip)
+            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False, count=self._count)
+        y = ops.bn_act(self.bn1, self.conv1(x), count=self._count)
+        return ops.bn_act(self.bn2, self.conv2(y), skip=skip, count=self._count)
 
 
 class Bottleneck(nn.Module):
     expansion = 4
+    _count = True
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
@@ -66,10 +68,10 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             skip = x
         else:
-            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False)
-        y = ops.bn_act(self.bn1, self.conv1(x))
-        y = ops.bn_act(self.bn2, self.conv2(y))
-        return ops.bn_act(self.bn3, self.conv3(y), skip=skip)
+            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False, count=self._count)
+        y = ops.bn_act(self.bn1, self.conv1(x), count=self._count)
+        y = ops.bn_act(self.bn2, self.conv2(y), count=self._count)
+        return ops.bn_act(self.bn3, self.conv3(y), skip=skip, count=self._count)
 
 
 class ResNet(nn.Module):
@@ -112,8 +114,23 @@ class ResNet(nn.Module):
                 self.to(memory_format=torch.channels_last)
                 self._nhwc_weights = True
             x = x.contiguous(memory_format=torch.channels_last)
-        x = self.maxpool(ops.bn_act(self.bn1, self.conv1(x)))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        batched = x.is_cuda and self.training
+        if batched:  # one multi-tensor add instead of one tiny kernel per BatchNorm layer
+            if not hasattr(self, "_nbt") or self._nbt[0] is not self.bn1.num_batches_tracked:  # rebuilt after .to()/.cuda()
+                self._nbt = [m.num_batches_tracked for m in self.modules()
+                             if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+                self._blocks = [m for m in self.modules() if isinstance(m, (BasicBlock, Bottleneck))]
+            with torch.no_grad():
+                torch._foreach_add_(self._nbt, 1)
+            for blk in self._blocks:
+                blk._count = False
+        try:
+            x = self.maxpool(ops.bn_act(self.bn1, self.conv1(x), count=not batched))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        finally:
+            if batched:
+                for blk in self._blocks:
+                    blk._count = True
         x = x.mean(3).mean(2)
         x = x.view(x.size(0), -1)
         if self.features:

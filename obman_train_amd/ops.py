@@ -371,7 +371,7 @@ class _BNAct(torch.autograd.Function):
         return dx, dskip, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_act(bn, x, skip=None, relu=True):
+def bn_act(bn, x, skip=None, relu=True, count=True):
     """``relu(bn(x) [+ skip])`` for an ``nn.BatchNorm2d`` module ``bn``.  Fused HIP path for channels_last fp32 ROCm tensors
     whose channel count is a multiple of 64 (every ResNet-18/50 stage); anything else takes the stock PyTorch ops."""
     fused = (x.is_cuda and x.dtype == torch.float32 and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
@@ -383,8 +383,8 @@ def bn_act(bn, x, skip=None, relu=True):
         if skip is not None:
             y = y + skip
         return torch.relu(y) if relu else y
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if count and bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1  # callers with many layers pass count=False and bump all counters in one launch
     if bn.momentum is None:
         momentum = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
     else:
