@@ -10,6 +10,8 @@
 // Layout: rows = B*H*W, C channels contiguous (torch channels_last).  Block = 16 row-lanes x 16 float4 columns
 // (64 channels); a wave reads 4 rows x 256 contiguous bytes.  Per-block partial moments are fp64; one wave per
 // channel merges them in fixed order (deterministic).  Bound: HBM bandwidth.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/obman_hip.h"
 
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
 Geo geo(long R, int C) {
   Geo g; g.R = R; g.C = C;
   const long col_blocks = C / CT;
-  long want = 2048 / col_blocks;  // ~2048 blocks in total (8 per CU); fewer partials for the finalize wave
+  static const long target = [] { const char* e = getenv("OBMAN_BN_BLOCKS"); return e ? atol(e) : 1024L; }();  // tuning knob
+  long want = target / col_blocks;  // ~1024 blocks in total (A/B on one box: 1024 >= 2048 >= 4096 within 1%)
   if (want < 1) want = 1;
   long rows = (R + want - 1) / want;
   rows = (rows + 15) / 16 * 16;

@@ -51,6 +51,11 @@ struct AGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k]),
   }
   __device__ KC kc(int k) const { const bool ok = k < K; const int c = ok ? k : 0; return KC{gamma[c], beta[c], ok}; }
   __device__ Raw raw(const Row& w, int k) const { const int c = k < K ? k : 0; return Raw{Gx[w.g + c], Fx[w.f + c]}; }
+  __device__ void raw4(const Row& w, int k, Raw* o) const {  // k % 4 == 0; columns >= K are masked by kc().ok
+    const int c = k <= ld - 4 ? k : ld - 4;
+    const float4 a = *reinterpret_cast<const float4*>(Gx + w.g + c), b = *reinterpret_cast<const float4*>(Fx + w.f + c);
+    o[0] = Raw{a.x, b.x}; o[1] = Raw{a.y, b.y}; o[2] = Raw{a.z, b.z}; o[3] = Raw{a.w, b.w};
+  }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
     const float v = fmaxf(__fmaf_rn(c.ga, x.a + x.b, c.be), 0.f);
     return (w.ok && c.ok) ? v : 0.f;
@@ -65,6 +70,10 @@ struct ABnRelu {  // a[r,k] = relu(s[k] * H[r,k] + t[k])
   __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
   __device__ KC kc(int k) const { const bool ok = k < K; const int c = ok ? k : 0; return KC{s[c], t[c], ok}; }
   __device__ Raw raw(const Row& w, int k) const { return Raw{H[w.o + (k < K ? k : 0)]}; }
+  __device__ void raw4(const Row& w, int k, Raw* o) const {
+    const float4 a = *reinterpret_cast<const float4*>(H + w.o + (k <= ld - 4 ? k : ld - 4));
+    o[0] = Raw{a.x}; o[1] = Raw{a.y}; o[2] = Raw{a.z}; o[3] = Raw{a.w};
+  }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
     const float v = fmaxf(__fmaf_rn(c.s, x.h, c.t), 0.f);
     return (w.ok && c.ok) ? v : 0.f;
@@ -79,6 +88,10 @@ struct APlain {  // a[r,k] = X[r,k]
   __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
   __device__ KC kc(int k) const { return KC{k < K}; }
   __device__ Raw raw(const Row& w, int k) const { return Raw{X[w.o + (k < K ? k : 0)]}; }
+  __device__ void raw4(const Row& w, int k, Raw* o) const {  // rows of X need not be 16-byte aligned: scalar loads
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = raw(w, k + j);
+  }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const { return (w.ok && c.ok) ? x.x : 0.f; }
 };
 // d(loss)/d(h) of a BatchNorm'd layer from the masked upstream gradient gy = d/d(y) * (y>0):
@@ -96,6 +109,11 @@ struct AGradH {  // gy materialised
     return KC{mean[c], rstd[c], k1[c], k2[c], k3[c], ok};
   }
   __device__ Raw raw(const Row& w, int k) const { const int c = k < K ? k : 0; return Raw{GY[w.o + c], H[w.o + c]}; }
+  __device__ void raw4(const Row& w, int k, Raw* o) const {
+    const int c = k <= ld - 4 ? k : ld - 4;
+    const float4 a = *reinterpret_cast<const float4*>(GY + w.o + c), b = *reinterpret_cast<const float4*>(H + w.o + c);
+    o[0] = Raw{a.x, b.x}; o[1] = Raw{a.y, b.y}; o[2] = Raw{a.z, b.z}; o[3] = Raw{a.w, b.w};
+  }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
     const float v = c.k1 * (x.gy - c.k2 - (x.h - c.m) * c.rs * c.k3);
     return (w.ok && c.ok) ? v : 0.f;
@@ -118,6 +136,10 @@ struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o
     return KC{s[c], t[c], mean[c], rstd[c], k1[c], k2[c], k3[c], W4[c], W4[K + c], W4[2 * K + c], ok};
   }
   __device__ Raw raw(const Row& w, int k) const { return Raw{H[w.o + (k < K ? k : 0)]}; }
+  __device__ void raw4(const Row& w, int k, Raw* o) const {
+    const float4 a = *reinterpret_cast<const float4*>(H + w.o + (k <= ld - 4 ? k : ld - 4));
+    o[0] = Raw{a.x}; o[1] = Raw{a.y}; o[2] = Raw{a.z}; o[3] = Raw{a.w};
+  }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
     const float gy = __fmaf_rn(c.s, x.h, c.t) > 0.f ? (w.g0 * c.w0 + w.g1 * c.w1 + w.g2 * c.w2) : 0.f;
     const float v = c.k1 * (gy - c.k2 - (x.h - c.m) * c.rs * c.k3);
@@ -161,21 +183,23 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
 
-  // A staging: element e = tid + 256 p, k = e % 32, m = e / 32  (16 rows per thread, fixed k per tile)
-  const int ak = tid & 31, am0 = tid >> 5;
-  typename AOp::Row rows[16];
+  // A staging: thread = 4 consecutive k (one 16-byte load per source array) x 4 rows (rm, rm+32, rm+64, rm+96)
+  const int kq = (tid & 7) * 4, rm = tid >> 3;
+  typename AOp::Row rows[4];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const int r = bm0 + am0 + 8 * p;
+  for (int p = 0; p < 4; ++p) {
+    const int r = bm0 + rm + 32 * p;
     rows[p] = aop.row(r, (r < aop.R ? r : aop.R - 1) / rows_N(aop));
   }
-  typename AOp::Raw ra[16];
-  typename AOp::KC kcur;
+  typename AOp::Raw ra[4][4];
+  typename AOp::KC kcur[4];
   float rb[8];
+  const int ak = tid & 31;  // B staging keeps the scalar mapping (weight rows are not 16-byte aligned)
   auto fetch = [&](int k0) {  // loads only: nothing here consumes a loaded value
-    kcur = aop.kc(k0 + ak);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) ra[p] = aop.raw(rows[p], k0 + ak);
+    for (int j = 0; j < 4; ++j) kcur[j] = aop.kc(k0 + kq + j);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) aop.raw4(rows[p], k0 + kq, ra[p]);
     if (B_NK) {  // W[n][k]: consecutive lanes along k
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
@@ -192,7 +216,9 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
   };
   auto stash = [&](int buf, int k0) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) T.As[buf][ak][am0 + 8 * p] = aop.fin(rows[p], kcur, ra[p]);
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T.As[buf][kq + j][rm + 32 * p] = aop.fin(rows[p], kcur[j], ra[p][j]);
     if (B_NK) {
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
@@ -325,34 +351,42 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
   const int mt = (M + BM - 1) / BM;
   const int bm0 = (blockIdx.x % mt) * BM, bn0 = (blockIdx.x / mt) * BN;
   const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
-  // staging: A tile [32 rows][128 m], B tile [32 rows][64 n]: consecutive lanes along m / n (contiguous in the source
-  // row).  The channel of a thread is fixed for the whole sweep: its constants are loaded once.
-  const typename AOp::KC kca = aop.kc(bm0 + (tid & 127));
-  const typename BOp::KC kcb = bop.kc(bn0 + (tid & 63));
-  typename AOp::Raw ra[16];
-  typename BOp::Raw rb[8];
-  typename AOp::Row rowa[16];
-  typename BOp::Row rowb[8];
+  // staging: A tile [32 rows][128 m]: thread = 4 consecutive channels (16-byte loads) x rows (tid>>5) + 8p, p < 4;
+  // B tile [32 rows][64 n]: 4 channels x rows (tid>>4) + 16p, p < 2.  A thread's channels are fixed for the whole
+  // sweep: their constants are loaded once.
+  const int ma = (tid & 31) * 4, ra0 = tid >> 5, nb = (tid & 15) * 4, rb0 = tid >> 4;
+  typename AOp::KC kca[4];
+  typename BOp::KC kcb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { kca[j] = aop.kc(bm0 + ma + j); kcb[j] = bop.kc(bn0 + nb + j); }
+  typename AOp::Raw ra[4][4];
+  typename BOp::Raw rb[2][4];
+  typename AOp::Row rowa[4];
+  typename BOp::Row rowb[2];
   auto fetch = [&](int r0) {
     const int bha = r0 / rows_N(aop), bhb = r0 / rows_N(bop);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int r = r0 + (tid >> 7) + 2 * p;
+    for (int p = 0; p < 4; ++p) {
+      const int r = r0 + ra0 + 8 * p;
       rowa[p] = aop.row(r < rend ? r : 0x7ffffff0, bha);
-      ra[p] = aop.raw(rowa[p], bm0 + (tid & 127));
+      aop.raw4(rowa[p], bm0 + ma, ra[p]);
     }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int r = r0 + (tid >> 6) + 4 * p;
+    for (int p = 0; p < 2; ++p) {
+      const int r = r0 + rb0 + 16 * p;
       rowb[p] = bop.row(r < rend ? r : 0x7ffffff0, bhb);
-      rb[p] = bop.raw(rowb[p], bn0 + (tid & 63));
+      bop.raw4(rowb[p], bn0 + nb, rb[p]);
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) T.As[buf][(tid >> 7) + 2 * p][tid & 127] = aop.fin(rowa[p], kca, ra[p]);
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) T.Bs[buf][(tid >> 6) + 4 * p][tid & 63] = bop.fin(rowb[p], kcb, rb[p]);
+      for (int j = 0; j < 4; ++j) T.As[buf][ra0 + 8 * p][ma + j] = aop.fin(rowa[p], kca[j], ra[p][j]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T.Bs[buf][rb0 + 16 * p][nb + j] = bop.fin(rowb[p], kcb[j], rb[p][j]);
   };
   f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
   const int nk = (rend - rbeg + BK - 1) / BK;
