@@ -243,8 +243,11 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
     const int cur = kt & 1;
     if (kt + 1 < nk) fetch((kt + 1) * BK);
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
+    // The next tile's operand transform + LDS writes go in the MIDDLE of the MFMA sweep: its loads were issued a
+    // half-sweep earlier (landed), and the VALU / LDS work hides under the matrix pipe instead of leaving it idle
+    // while every co-resident block sits in its write/barrier phase at the same time.
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = 0; kk < BK / 2; kk += 2) {
       const float b = T.Bs[cur][kk + kh][bcol];
       const float a0 = T.As[cur][kk + kh][arow];
       const float a1 = T.As[cur][kk + kh][arow + 32];
@@ -252,6 +255,14 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
     }
     if (kt + 1 < nk) stash(cur ^ 1, (kt + 1) * BK);
+#pragma unroll
+    for (int kk = BK / 2; kk < BK; kk += 2) {
+      const float b = T.Bs[cur][kk + kh][bcol];
+      const float a0 = T.As[cur][kk + kh][arow];
+      const float a1 = T.As[cur][kk + kh][arow + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
     __syncthreads();
   }
   epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, tid, smem);
@@ -400,14 +411,22 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     if (kt + 1 < nk) fetch(rbeg + (kt + 1) * BK);
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = 0; kk < BK / 2; kk += 2) {
       const float b = T.Bs[cur][kk + kh][bcol];
       const float a0 = T.As[cur][kk + kh][arow];
       const float a1 = T.As[cur][kk + kh][arow + 32];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
     }
-    if (kt + 1 < nk) stash(cur ^ 1);
+    if (kt + 1 < nk) stash(cur ^ 1);  // mid-sweep: hides under the matrix pipe (see gemm_rows_kernel)
+#pragma unroll
+    for (int kk = BK / 2; kk < BK; kk += 2) {
+      const float b = T.Bs[cur][kk + kh][bcol];
+      const float a0 = T.As[cur][kk + kh][arow];
+      const float a1 = T.As[cur][kk + kh][arow + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
     __syncthreads();
   }
   float* dst = part + (size_t)blockIdx.y * M * Nc;
