@@ -214,6 +214,18 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
       }
     }
   };
+  auto stash_part = [&](int buf, int k0, int q) {  // q = 0..7: two A elements + one B element
+    const int p = q >> 1, j0 = (q & 1) * 2;
+    T.As[buf][kq + j0][rm + 32 * p] = aop.fin(rows[p], kcur[j0], ra[p][j0]);
+    T.As[buf][kq + j0 + 1][rm + 32 * p] = aop.fin(rows[p], kcur[j0 + 1], ra[p][j0 + 1]);
+    if (B_NK) {
+      const int n = bn0 + (tid >> 5) + 8 * q, k = k0 + ak;
+      T.Bs[buf][ak][(tid >> 5) + 8 * q] = (n < Nc && k < K) ? rb[q] : 0.f;
+    } else {
+      const int n = bn0 + (tid & 63), k = k0 + (tid >> 6) + 4 * q;
+      T.Bs[buf][(tid >> 6) + 4 * q][tid & 63] = (n < Nc && k < K) ? rb[q] : 0.f;
+    }
+  };
   auto stash = [&](int buf, int k0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -243,25 +255,19 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
     const int cur = kt & 1;
     if (kt + 1 < nk) fetch((kt + 1) * BK);
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
-    // The next tile's operand transform + LDS writes go in the MIDDLE of the MFMA sweep: its loads were issued a
-    // half-sweep earlier (landed), and the VALU / LDS work hides under the matrix pipe instead of leaving it idle
-    // while every co-resident block sits in its write/barrier phase at the same time.
+    // The next tile's operand transform + LDS writes are spread over MFMA steps 4..11 (one eighth each): the loads were
+    // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
+    // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
+    const bool more = kt + 1 < nk;
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; kk += 2) {
+    for (int step = 0; step < BK / 2; ++step) {
+      const int kk = step * 2;
       const float b = T.Bs[cur][kk + kh][bcol];
       const float a0 = T.As[cur][kk + kh][arow];
       const float a1 = T.As[cur][kk + kh][arow + 32];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
-    }
-    if (kt + 1 < nk) stash(cur ^ 1, (kt + 1) * BK);
-#pragma unroll
-    for (int kk = BK / 2; kk < BK; kk += 2) {
-      const float b = T.Bs[cur][kk + kh][bcol];
-      const float a0 = T.As[cur][kk + kh][arow];
-      const float a1 = T.As[cur][kk + kh][arow + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+      if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
     }
     __syncthreads();
   }
@@ -389,6 +395,13 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
       bop.raw4(rowb[p], bn0 + nb, rb[p]);
     }
   };
+  auto stash_part = [&](int buf, int q) {  // q = 0..7: two A elements + one B element
+    const int p = q >> 1, j0 = (q & 1) * 2;
+    T.As[buf][ra0 + 8 * p][ma + j0] = aop.fin(rowa[p], kca[j0], ra[p][j0]);
+    T.As[buf][ra0 + 8 * p][ma + j0 + 1] = aop.fin(rowa[p], kca[j0 + 1], ra[p][j0 + 1]);
+    const int pb = q >> 2, jb = q & 3;
+    T.Bs[buf][rb0 + 16 * pb][nb + jb] = bop.fin(rowb[pb], kcb[jb], rb[pb][jb]);
+  };
   auto stash = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -410,22 +423,16 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     const int cur = kt & 1;
     if (kt + 1 < nk) fetch(rbeg + (kt + 1) * BK);
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
+    const bool more = kt + 1 < nk;
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; kk += 2) {
+    for (int step = 0; step < BK / 2; ++step) {  // next tile's transform + LDS writes spread over steps 4..11 (see gemm_rows_kernel)
+      const int kk = step * 2;
       const float b = T.Bs[cur][kk + kh][bcol];
       const float a0 = T.As[cur][kk + kh][arow];
       const float a1 = T.As[cur][kk + kh][arow + 32];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
-    }
-    if (kt + 1 < nk) stash(cur ^ 1);  // mid-sweep: hides under the matrix pipe (see gemm_rows_kernel)
-#pragma unroll
-    for (int kk = BK / 2; kk < BK; kk += 2) {
-      const float b = T.Bs[cur][kk + kh][bcol];
-      const float a0 = T.As[cur][kk + kh][arow];
-      const float a1 = T.As[cur][kk + kh][arow + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+      if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
     }
     __syncthreads();
   }
