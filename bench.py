@@ -147,6 +147,8 @@ def main():
     dt = time.perf_counter() - t0
     loss_val = float(total)
     pm_ms, pm_n = _lib.prof_summary(1)
+    dec_f_ms, dec_f_n = _lib.prof_summary(8)
+    dec_b_ms, dec_b_n = _lib.prof_summary(9)
     _lib.prof_enable(False)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -171,6 +173,17 @@ def main():
                      "note": "binding bound: intensity N*M/(2(N+M)) = %.0f flop/B >> 20 flop/B ridge"
                              % (n_pred * n_gt / (2.0 * (n_pred + n_gt)))},
         }
+        # decoder (K6): algorithmic flops of the three MFMA layers (861 720 flop/point incl. layer 1, which
+        # this implementation removes analytically; counted here: layers 2-4 only), backward = 2x forward
+        c1 = model.atlas_branch.decoder.bottleneck_size
+        dec_flop = 2.0 * args.batch * n_pred * (c1 * (c1 // 2) + (c1 // 2) * (c1 // 4) + (c1 // 4) * 3)
+        decoder = None
+        if dec_f_n and dec_b_n:
+            tf, tb = dec_f_ms / dec_f_n * 1e-3, dec_b_ms / dec_b_n * 1e-3
+            decoder = {"bound": "mfma", "dtype": "f32", "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_achieved": dec_flop / tf / 1e12,
+                       "bwd_achieved": 2 * dec_flop / tb / 1e12, "frac": 3 * dec_flop / (tf + tb) / 1e12 / VALU_PEAK_TFLOPS,
+                       "note": "whole obman_pointgen_fwd/bwd call (all its kernels), fp32-in MFMA peak = 157.3 TF"}
         traffic_file = os.path.join(REPO, "profiles", "chamfer_traffic.json")
         if os.path.exists(traffic_file):
             with open(traffic_file) as fh:
@@ -187,6 +200,7 @@ def main():
                        "name": args.config, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "parallelism": "dp%d" % world, "final_loss": loss_val},
             "roofline": roof,
+            "decoder_roofline": decoder,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size)

@@ -103,6 +103,9 @@ def bench_decoder():
         grid = torch.from_numpy(multi_patch(3, patches)[0].astype(np.float32)).cuda()
         feats = torch.randn(B, 512, device="cuda").requires_grad_()
         t_f = kernel_us(lambda: ops.pointgen_decode(dec, feats, grid), 8, iters=10, warmup=3)
+        if os.environ.get("OBMAN_GEMM_VARIANT"):
+            print(json.dumps(dict(kernel="decoder", variant=os.environ["OBMAN_GEMM_VARIANT"], fwd_us=round(t_f, 1))), flush=True)
+            continue
         out = ops.pointgen_decode(dec, feats, grid)
         loss = out.square().mean()
         params = [feats] + list(dec.parameters())
