@@ -25,6 +25,15 @@ constexpr int PM_REF_TILE = 2048;  // float4 -> 32 KiB LDS per block
 constexpr float PM_BIG = 1.0e18f;  // padding coordinate: d = 3e36 < FLT_MAX, never wins
 typedef unsigned long long u64;
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Two queries per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32.  Element-wise identical rounding to
+// obman_dist2 (sub, mul, fma, fma), so the scalar index-resolution pass reproduces these values bit for bit.
+__device__ __forceinline__ f2 pm_dist2_pk(f2 qx, f2 qy, f2 qz, float rx, float ry, float rz) {
+  const f2 dx = qx - rx, dy = qy - ry, dz = qz - rz;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
 struct PmDir {
   const float* q;  // queries  [B,nq,3]
   const float* r;  // references [B,nr,3]
@@ -56,15 +65,18 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
   float(*s_val)[64 * QPT] = reinterpret_cast<float(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4));
   int(*s_grp)[64 * QPT] = reinterpret_cast<int(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4) + 4 * 64 * QPT * sizeof(float));
 
-  float qx[QPT], qy[QPT], qz[QPT], best[QPT];
+  static_assert(QPT % 2 == 0, "queries are processed as packed pairs");
+  constexpr int QP = QPT / 2;
+  f2 qx[QP], qy[QP], qz[QP];
+  float best[QPT];
   int bestj[QPT];
 #pragma unroll
   for (int k = 0; k < QPT; ++k) {
     const int qi = qt * (64 * QPT) + k * 64 + lane;
     const int qc = qi < d.nq ? qi : d.nq - 1;  // clamp: idle lanes redo the last point, never stored
-    qx[k] = qb[(size_t)qc * 3 + 0];
-    qy[k] = qb[(size_t)qc * 3 + 1];
-    qz[k] = qb[(size_t)qc * 3 + 2];
+    qx[k >> 1][k & 1] = qb[(size_t)qc * 3 + 0];
+    qy[k >> 1][k & 1] = qb[(size_t)qc * 3 + 1];
+    qz[k >> 1][k & 1] = qb[(size_t)qc * 3 + 2];
     best[k] = __builtin_inff();
     bestj[k] = 0x7fffffff;
   }
@@ -91,15 +103,18 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
       const float4 r0 = sref[j], r1 = sref[j + 1], r2 = sref[j + 2], r3 = sref[j + 3];
       asm volatile("" ::"v"(r0.w), "v"(r1.w), "v"(r2.w), "v"(r3.w));  // keep the reads ds_read_b128 (b96 is 2x the LDS cycles)
 #pragma unroll
-      for (int k = 0; k < QPT; ++k) {
-        const float e0 = obman_dist2(qx[k], qy[k], qz[k], r0.x, r0.y, r0.z);
-        const float e1 = obman_dist2(qx[k], qy[k], qz[k], r1.x, r1.y, r1.z);
-        const float e2 = obman_dist2(qx[k], qy[k], qz[k], r2.x, r2.y, r2.z);
-        const float e3 = obman_dist2(qx[k], qy[k], qz[k], r3.x, r3.y, r3.z);
-        const float m = fminf(fminf(e0, e1), fminf(e2, e3));
-        const bool better = m < best[k];
-        best[k] = better ? m : best[k];
-        bestj[k] = better ? base + j : bestj[k];
+      for (int p = 0; p < QP; ++p) {
+        const f2 e0 = pm_dist2_pk(qx[p], qy[p], qz[p], r0.x, r0.y, r0.z);
+        const f2 e1 = pm_dist2_pk(qx[p], qy[p], qz[p], r1.x, r1.y, r1.z);
+        const f2 e2 = pm_dist2_pk(qx[p], qy[p], qz[p], r2.x, r2.y, r2.z);
+        const f2 e3 = pm_dist2_pk(qx[p], qy[p], qz[p], r3.x, r3.y, r3.z);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float m = fminf(fminf(e0[h], e1[h]), fminf(e2[h], e3[h]));
+          const bool better = m < best[2 * p + h];
+          best[2 * p + h] = better ? m : best[2 * p + h];
+          bestj[2 * p + h] = better ? base + j : bestj[2 * p + h];
+        }
       }
     }
     if (!single) __syncthreads();
@@ -250,14 +265,29 @@ __global__ __launch_bounds__(256) void pairmin_bwd_kernel(PmBwdSide s0, PmBwdSid
   g[2] = gz;
 }
 
-int choose_qpt(int B, int nq_max) {
-  // a block covers 64*QPT queries.  More queries per lane = fewer LDS reads per pair (VALU-bound from
-  // QPT 2 up); keep >= 2 blocks per CU in flight.  OBMAN_PM_QPT overrides (tuning only).
+// A block covers 64*QPT queries (QPT in {2,4,10}; packed pairs).  More queries per lane = fewer LDS reads per pair and,
+// for the short side of an asymmetric problem (600 GT points vs 16 050 vertices), QPT = 10 puts every query of a sample
+// into ONE block column so the long reference set is swept once instead of once per 64-query tile
+// (profiles/r01_chamfer_pmc.md: 10x re-read).  OBMAN_PM_QPT overrides (tuning only).
+int choose_qpt(int B, int nq, int nr) {
   static const int forced = [] { const char* e = getenv("OBMAN_PM_QPT"); return e ? atoi(e) : 0; }();
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
-  for (int qpt = 4; qpt > 1; qpt >>= 1)
-    if ((long)B * obman_cdiv(nq_max, 64 * qpt) >= 512) return qpt;
-  return 1;
+  if (forced == 2 || forced == 4 || forced == 10) return forced;
+  if (nq <= 640 && nr >= 4 * nq) return 10;
+  if ((long)B * obman_cdiv(nq, 256) >= 512) return 4;
+  return 2;
+}
+
+template <int QPT>
+void launch_fwd_t(dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b) {
+  pairmin_fwd_kernel<QPT><<<grid, PM_THREADS, smem, st>>>(a, b);
+}
+void launch_fwd(int qpt, dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b) {
+  ObmanProfScope prof(OBMAN_K_PAIRMIN_FWD, st);
+  switch (qpt) {
+    case 10: launch_fwd_t<10>(grid, smem, st, a, b); break;
+    case 4: launch_fwd_t<4>(grid, smem, st, a, b); break;
+    default: launch_fwd_t<2>(grid, smem, st, a, b); break;
+  }
 }
 
 void plan_dir(PmDir& d, int B, int qpt, bool have_ws) {
@@ -267,9 +297,9 @@ void plan_dir(PmDir& d, int B, int qpt, bool have_ws) {
   d.tile = PM_REF_TILE;
   if (have_ws && d.omin) {
     const long blocks = (long)B * d.qtiles;
-    if (blocks < 512 && d.nr >= 4 * PM_REF_TILE) {
+    if (blocks < 512 && d.nr >= 1024) {
       int want = (int)((1024 + blocks - 1) / blocks);
-      int maxsplit = obman_cdiv(d.nr, PM_REF_TILE);
+      int maxsplit = obman_cdiv(d.nr, 256);  // at least 64 references per wave
       d.rsplit = want < maxsplit ? want : maxsplit;
       d.rchunk = ((obman_cdiv(d.nr, d.rsplit) + 3) / 4) * 4;
       d.rsplit = obman_cdiv(d.nr, d.rchunk);
@@ -284,30 +314,32 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   if (Nx == 0 || Ny == 0) return -2;  // torch.min over an empty dim raises in the reference
   PmDir d0{x, y, min_x, idx_x, nullptr, Nx, Ny, 0, 1, Ny, PM_REF_TILE};
   PmDir d1{y, x, min_y, idx_y, nullptr, Ny, Nx, 0, 1, Nx, PM_REF_TILE};
-  const int nq_max = (min_x ? Nx : 0) > (min_y ? Ny : 0) ? Nx : Ny;
-  const int qpt = choose_qpt(B, nq_max);
+  const int q0 = choose_qpt(B, Nx, Ny), q1 = choose_qpt(B, Ny, Nx);
   const bool have_ws = ws && ws_bytes >= (long)sizeof(u64) * B * ((long)Nx + Ny);
-  plan_dir(d0, B, qpt, have_ws);
-  plan_dir(d1, B, qpt, have_ws);
+  plan_dir(d0, B, q0, have_ws);
+  plan_dir(d1, B, q1, have_ws);
   if (d0.rsplit > 1) d0.ws = (u64*)ws;
   if (d1.rsplit > 1) d1.ws = (u64*)ws + (size_t)B * Nx;
   if (d0.rsplit > 1) (void)hipMemsetAsync(d0.ws, 0xff, sizeof(u64) * (size_t)B * Nx, st);
   if (d1.rsplit > 1) (void)hipMemsetAsync(d1.ws, 0xff, sizeof(u64) * (size_t)B * Ny, st);
-  const int gx0 = min_x ? d0.qtiles * d0.rsplit : 0, gx1 = min_y ? d1.qtiles * d1.rsplit : 0;
-  dim3 grid(gx0 > gx1 ? gx0 : gx1, B, 2);
-  if (grid.x == 0) return 0;
-  // one LDS tile size for both directions: the longest per-block reference range, rounded to 16, capped
-  const int need0 = min_x ? d0.rchunk : 0, need1 = min_y ? d1.rchunk : 0;
-  int tile = ((((need0 > need1 ? need0 : need1) + 15) / 16) * 16);
-  if (tile > PM_REF_TILE) tile = PM_REF_TILE;
-  d0.tile = d1.tile = tile;
-  const size_t smem = (size_t)tile * sizeof(float4) + (size_t)8 * 64 * qpt * sizeof(float);
-  {
-    ObmanProfScope prof(OBMAN_K_PAIRMIN_FWD, st);
-    switch (qpt) {
-      case 4: pairmin_fwd_kernel<4><<<grid, PM_THREADS, smem, st>>>(d0, d1); break;
-      case 2: pairmin_fwd_kernel<2><<<grid, PM_THREADS, smem, st>>>(d0, d1); break;
-      default: pairmin_fwd_kernel<1><<<grid, PM_THREADS, smem, st>>>(d0, d1); break;
+  auto tile_of = [](const PmDir& d) {
+    int t = ((d.rchunk + 15) / 16) * 16;
+    return t > PM_REF_TILE ? PM_REF_TILE : t;
+  };
+  auto smem_of = [](int tile, int qpt) { return (size_t)tile * sizeof(float4) + (size_t)8 * 64 * qpt * sizeof(float); };
+  if (min_x && min_y && q0 == q1) {  // symmetric sizes: both directions in one launch
+    const int gx0 = d0.qtiles * d0.rsplit, gx1 = d1.qtiles * d1.rsplit;
+    const int tile = tile_of(d0) > tile_of(d1) ? tile_of(d0) : tile_of(d1);
+    d0.tile = d1.tile = tile;
+    launch_fwd(q0, dim3(gx0 > gx1 ? gx0 : gx1, B, 2), smem_of(tile, q0), st, d0, d1);
+  } else {  // one launch per direction, each with its own query tiling
+    if (min_x) {
+      d0.tile = tile_of(d0);
+      launch_fwd(q0, dim3(d0.qtiles * d0.rsplit, B, 1), smem_of(d0.tile, q0), st, d0, d0);
+    }
+    if (min_y) {
+      d1.tile = tile_of(d1);
+      launch_fwd(q1, dim3(d1.qtiles * d1.rsplit, B, 1), smem_of(d1.tile, q1), st, d1, d1);
     }
   }
   OBMAN_LAUNCH_CHECK();
