@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void pairmin_bwd_kernel(PmBwdSide s0, PmBwdSid
 int choose_qpt(int B, int nq, int nr) {
   static const int forced = [] { const char* e = getenv("OBMAN_PM_QPT"); return e ? atoi(e) : 0; }();
   if (forced == 2 || forced == 4 || forced == 10) return forced;
-  if (nq <= 640 && nr >= 4 * nq) return 10;
+  if (nq <= 640 && nr >= 8192) return 10;  // below that the extra memset + unpack launches of the split path cost more than the re-reads
   if ((long)B * obman_cdiv(nq, 256) >= 512) return 4;
   return 2;
 }
@@ -297,7 +297,7 @@ void plan_dir(PmDir& d, int B, int qpt, bool have_ws) {
   d.tile = PM_REF_TILE;
   if (have_ws && d.omin) {
     const long blocks = (long)B * d.qtiles;
-    if (blocks < 512 && d.nr >= 1024) {
+    if (blocks < 512 && d.nr >= 8192) {
       int want = (int)((1024 + blocks - 1) / blocks);
       int maxsplit = obman_cdiv(d.nr, 256);  // at least 64 references per wave
       d.rsplit = want < maxsplit ? want : maxsplit;

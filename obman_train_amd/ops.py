@@ -41,7 +41,7 @@ def _check_pair(x, y):
 def _workspace(B, nx, ny, device):
     nbytes = _lib.lib().obman_pairmin_ws_bytes(B, nx, ny)
     small, large = (nx, ny) if nx < ny else (ny, nx)
-    if large < 1024 or large < 4 * small or B * ((small + 639) // 640) >= 512:
+    if large < 8192 or B * ((small + 639) // 640) >= 512:
         return None, 0  # the launcher would not split the reference set: skip the allocation
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
