@@ -139,6 +139,14 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
 int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const float* ws, float* ws2,
                        const obman_pointgen_grads* g, obman_stream_t stream);
 
+/* ---- K8: edge-length regulariser -----------------------------------------------------------------
+ * Replaces edge_loss (atlasbranch.py:153-167).  verts [B,N,3], faces [F,3] int32 -> loss [1] =
+ * mean over samples and the 3F face edges of |squared edge length - per-sample mean|.  stats [3*B] fwd -> bwd.
+ * g_loss is a DEVICE scalar; grad [B,N,3] is overwritten (owner scan over the faces, deterministic). */
+int obman_edge_loss_fwd(const float* verts, const int* faces, int B, int N, int F, float* loss, float* stats, obman_stream_t stream);
+int obman_edge_loss_bwd(const float* verts, const int* faces, int B, int N, int F, const float* stats, const float* g_loss,
+                        float* grad, obman_stream_t stream);
+
 /* ---- fused BatchNorm2d (+ skip add) (+ ReLU), NHWC fp32 --------------------------------------------
  * Replaces bn -> relu and bn -> (+residual) -> relu of the ResNet blocks (bases/resnet.py:38-52,77-96) - separate
  * memory-bound passes in eager PyTorch.  x, skip, y, dy, dx, dskip are [R, C] row-major (R = B*H*W of a

@@ -25,6 +25,8 @@ _SIGNATURES = {
     "obman_pointgen_ws_floats": (_c_long, "pi"),
     "obman_pointgen_fwd": (_c_int, "pppp"),
     "obman_pointgen_bwd": (_c_int, "pppppp"),
+    "obman_edge_loss_fwd": (_c_int, "pp" "iii" "pp" "p"),
+    "obman_edge_loss_bwd": (_c_int, "pp" "iii" "ppp" "p"),
     "obman_bnact_ws_floats": (_c_long, "li"),
     "obman_bnact_fwd": (_c_int, "pppppp" "li" "iffi" "ppp" "p"),
     "obman_bnact_bwd": (_c_int, "ppppp" "li" "iii" "ppppp" "p"),

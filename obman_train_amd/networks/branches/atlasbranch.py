@@ -12,6 +12,7 @@ import torch
 from torch import nn
 import torch.nn.functional as torch_f
 
+from obman_train_amd import ops
 from obman_train_amd.icosphere import multi_patch
 from obman_train_amd.networks.branches import atlasutils
 from obman_train_amd.queries import TransQueries
@@ -87,11 +88,20 @@ class AtlasBranch(nn.Module):
         return self._assemble(verts, trans, scale, with_faces=True)
 
 
+_FACE_CACHE = {}
+
+
 def edge_loss(edges, faces):
-    f = torch.as_tensor(np.asarray(faces).astype(np.int64), device=edges.device) if not torch.is_tensor(faces) else faces.long()
-    a, b, c = edges[:, f[:, 0]], edges[:, f[:, 1]], edges[:, f[:, 2]]
-    lens = torch.cat([((a - c) ** 2).sum(2), ((c - b) ** 2).sum(2), ((b - a) ** 2).sum(2)], 1)
-    return (lens - lens.mean(1, keepdim=True)).abs().mean()
+    """Mean absolute deviation of the squared face-edge lengths from their per-sample mean (atlasbranch.py:153-167);
+    one fused HIP kernel per direction (``csrc/edge.hip``).  ``faces``: numpy [F,3] (reference) or int32 device tensor."""
+    if not torch.is_tensor(faces):
+        key = (faces.ctypes.data, faces.shape, str(edges.device))
+        if key not in _FACE_CACHE:
+            if len(_FACE_CACHE) > 16:
+                _FACE_CACHE.clear()
+            _FACE_CACHE[key] = torch.as_tensor(np.ascontiguousarray(faces, dtype=np.int32), device=edges.device)
+        faces = _FACE_CACHE[key]
+    return ops.edge_loss(edges, faces.to(dtype=torch.int32))
 
 
 class AtlasLoss:

@@ -390,3 +390,32 @@ def bn_act(bn, x, skip=None, relu=True, count=True):
     else:
         momentum = bn.momentum
     return _BNAct.apply(x, skip, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum, relu)
+
+
+class _EdgeLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, faces):
+        verts = _dev(verts, "verts")
+        faces = _dev(faces, "faces", torch.int32)
+        B, N, F = verts.shape[0], verts.shape[1], faces.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=verts.device)
+        stats = torch.empty(3 * B, dtype=torch.float32, device=verts.device)
+        _lib.check(_lib.lib().obman_edge_loss_fwd(verts.data_ptr(), faces.data_ptr(), B, N, F, loss.data_ptr(), stats.data_ptr(),
+                                                  _stream()), "obman_edge_loss_fwd")
+        ctx.save_for_backward(verts, faces, stats)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        verts, faces, stats = ctx.saved_tensors
+        B, N, F = verts.shape[0], verts.shape[1], faces.shape[0]
+        grad = torch.empty_like(verts)
+        g = g.contiguous().view(1)
+        _lib.check(_lib.lib().obman_edge_loss_bwd(verts.data_ptr(), faces.data_ptr(), B, N, F, stats.data_ptr(), g.data_ptr(),
+                                                  grad.data_ptr(), _stream()), "obman_edge_loss_bwd")
+        return grad, None
+
+
+def edge_loss(verts, faces):
+    """edge_loss(edges, faces) of atlasbranch.py:153-167: verts [B,N,3], faces [F,3] int32 (device) -> scalar."""
+    return _EdgeLoss.apply(verts, faces)
