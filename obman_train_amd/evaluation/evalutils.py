@@ -1,0 +1,35 @@
+"""Running averages of the per-step losses.  Mirror of ``mano_train/evaluation/evalutils.py:1-28`` (same class and
+method names, ``average_meters[name].avg``), plus ``add_loss_dict`` which takes a whole device-side loss dict and reads
+it back with ONE device->host copy (the reference calls ``.item()`` once per key per step, ``epochpass3d.py:111-117``)."""
+from obman_train_amd.trainer import read_losses
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+class AverageMeters:
+    def __init__(self):
+        self.average_meters = {}
+
+    def add_loss_value(self, loss_name, loss_val, n=1):
+        self.average_meters.setdefault(loss_name, AverageMeter()).update(loss_val, n=n)
+
+    def add_loss_dict(self, losses, n=1):
+        values = read_losses(losses)
+        for name, val in losses.items():  # numpy / python scalars (the reference's contact_auc) pass through
+            if name not in values and val is not None and not hasattr(val, "is_cuda"):
+                values[name] = float(val)
+        for name, val in values.items():
+            self.add_loss_value(name, val, n=n)
+        return values

@@ -1,0 +1,70 @@
+"""CPU: the 'next' row of SURVEY §8f - epoch loop, meters and reference-compatible checkpoint I/O - driven through the
+test-only oracle backend (tests/fake_ops.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import fake_ops
+from tests.handnet_common import build_fixture_model, fixture_sample
+
+
+def test_epoch_pass_trains_and_averages(golden, monkeypatch):
+    fake_ops.install(monkeypatch)
+    from obman_train_amd.netscripts.epochpass3d import epoch_pass
+    from obman_train_amd.trainer import make_optimizer
+
+    g = golden("handnet_eval")
+    model, _ = build_fixture_model(g, monkeypatch, train_mode=True)
+    opt = make_optimizer(model, "adam", lr=1e-3)
+    loader = [fixture_sample(g) for _ in range(3)]
+    before = model.mano_branch.pose_reg.weight.detach().clone()
+    meters, pck = epoch_pass(loader, model, epoch=0, optimizer=opt, train=True, freeze_batchnorm=True)
+    assert pck == {}
+    assert not model.training  # freeze_batchnorm => eval-mode BN during training (epochpass3d.py:48-52)
+    assert not torch.equal(before, model.mano_branch.pose_reg.weight)
+    am = meters.average_meters
+    assert am["total_loss"].count == 3 and am["contact_auc"].count == 3
+    first = float(g["total"][0])
+    assert am["total_loss"].sum / 3 == pytest.approx(am["total_loss"].avg)
+    assert abs(am["mano_verts3d"].avg) > 0 and np.isfinite(am["total_loss"].avg)
+    # first step sees the fixture's weights: the running sum starts from the reference's loss value
+    meters2, _ = epoch_pass(loader[:1], build_fixture_model(g, monkeypatch, train_mode=False)[0], epoch=0, train=False)
+    assert meters2.average_meters["total_loss"].avg == pytest.approx(first, rel=1e-4)
+
+
+def test_checkpoint_roundtrip_and_reference_layout(golden, monkeypatch, tmp_path):
+    fake_ops.install(monkeypatch)
+    from obman_train_amd.modelutils import modelio
+    from obman_train_amd.trainer import make_optimizer
+
+    g = golden("handnet_eval")
+    model, _ = build_fixture_model(g, monkeypatch, train_mode=False)
+    opt = make_optimizer(model, "sgd", lr=0.1)
+    # a reference-style checkpoint: DataParallel prefix + manopth buffers the HIP implementation does not hold
+    sd = {"module." + k: v.clone() for k, v in model.state_dict().items()}
+    sd["module.mano_branch.mano_layer_right.th_betas"] = torch.zeros(1, 10)
+    state = {"epoch": 7, "network": "handnet", "state_dict": sd, "best_score": 0.25, "optimizer": opt.state_dict()}
+    modelio.save_checkpoint(state, is_best=True, checkpoint=str(tmp_path), snapshot=7)
+    for name in ("checkpoint.pth.tar", "checkpoint_7.pth.tar", "model_best.pth.tar"):
+        assert os.path.exists(os.path.join(str(tmp_path), name))
+    fresh, _ = build_fixture_model(g, monkeypatch, train_mode=False)
+    with torch.no_grad():
+        fresh.mano_branch.pose_reg.weight.zero_()
+    with pytest.warns(UserWarning):
+        epoch, best = modelio.load_checkpoint(fresh, os.path.join(str(tmp_path), "checkpoint.pth.tar"), optimizer=opt)
+    assert (epoch, best) == (7, 0.25)
+    assert torch.equal(fresh.mano_branch.pose_reg.weight, model.mano_branch.pose_reg.weight)
+    total_a, _, _ = model.forward(fixture_sample(g))
+    total_b, _, _ = fresh.forward(fixture_sample(g))
+    assert float(total_a) == float(total_b)
+    # averaging two checkpoints (modelio.load_checkpoints)
+    sd2 = {k: (v + 2.0 if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    torch.save(dict(state, state_dict=sd2, epoch=9), os.path.join(str(tmp_path), "b.pth.tar"))
+    with pytest.warns(UserWarning):
+        epoch, _ = modelio.load_checkpoints(fresh, [os.path.join(str(tmp_path), "checkpoint.pth.tar"), os.path.join(str(tmp_path), "b.pth.tar")])
+    assert epoch == 9
+    torch.testing.assert_close(fresh.mano_branch.pose_reg.bias, model.mano_branch.pose_reg.bias + 1.0)
+    with pytest.raises(ValueError):
+        modelio.load_checkpoint(fresh, os.path.join(str(tmp_path), "nope.pth.tar"))
