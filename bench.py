@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--config", default="c2", help="c2 (headline) | c3p1 | c3")
     ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = autocast the ResNet encoder (configs[2] flavour; NOT the headline fp32 config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -127,6 +129,8 @@ def main():
     torch.manual_seed(0)
     model = HandNet(**cfg).to(dev)
     model.train()
+    if args.encoder_dtype == "bf16":
+        model.base_net.autocast_dtype = torch.bfloat16
     broadcast_parameters(model)
     opt = make_optimizer(model, "adam", lr=1e-4)
     buckets = GradientBuckets(model.parameters()) if world > 1 else None
@@ -192,7 +196,8 @@ def main():
             "metric": "train images/sec (fwd+bwd+Adam, bs=%d/GPU)" % args.batch,
             "value": args.batch * world * args.steps / dt, "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder / f32 heads", "data": "synthetic",
             "config": {"workload": "configs[1]: ResNet18 + MANO(30 PCA comps) LBS + 1-sphere AtlasNet(642 verts) "
                                    "+ Chamfer vs 600 GT points%s, %dx%d RGB, fp32, Adam"
                                    % (" + contact/penetration (%d patches)" % cfg.get("atlas_patches", 1)

@@ -114,6 +114,13 @@ class ResNet(nn.Module):
                 self.to(memory_format=torch.channels_last)
                 self._nhwc_weights = True
             x = x.contiguous(memory_format=torch.channels_last)
+        dtype = getattr(self, "autocast_dtype", None)
+        if dtype is not None and x.is_cuda and not torch.is_autocast_enabled():
+            # opt-in reduced-precision encoder (BASELINE configs[2] "bf16"): convolutions on the bf16 MFMA path, features
+            # handed to the fp32 heads.  The fused fp32 BN kernels are bypassed (stock bf16 BatchNorm) in this mode.
+            with torch.autocast("cuda", dtype=dtype):
+                feats, extra = self.forward(x)
+            return feats.float(), extra
         batched = x.is_cuda and self.training
         if batched:  # one multi-tensor add instead of one tiny kernel per BatchNorm layer
             if not hasattr(self, "_nbt") or self._nbt[0] is not self.bn1.num_batches_tracked:  # rebuilt after .to()/.cuda()

@@ -21,8 +21,8 @@ def test_handnet_matches_reference_golden(golden, monkeypatch, tag):
     assert_matches_fixture(g, total, results, losses, model)
 
 
-@pytest.mark.parametrize("contact", [False, True])
-def test_handnet_resnet18_matches_cpu_oracle(contact):
+@pytest.mark.parametrize("contact,patches", [(False, 1), (True, 1), (True, 3)])
+def test_handnet_resnet18_matches_cpu_oracle(contact, patches):
     """Config 1/2 model (ResNet18 + MANO + 1-sphere AtlasNet + Chamfer [+ contact]) at bs 4, 64x64 images:
     GPU product vs oracle.handnet_forward on the same weights.  Tolerance 1e-3 on loss scalars (MIOpen vs
     oneDNN convolutions differ at 1e-5..1e-4 after 18 layers); vertices 1e-3 rel of the hand scale."""
@@ -41,6 +41,8 @@ def test_handnet_resnet18_matches_cpu_oracle(contact):
                atlas_lambda=0.167, atlas_final_lambda=0.167, atlas_predict_trans=True, atlas_predict_scale=True,
                atlas_trans_weight=0.167, atlas_scale_weight=0.167, mano_lambda_verts=0.167, mano_lambda_joints3d=0.167,
                mano_use_shape=True, mano_lambda_shape=0.167, mano_lambda_pose_reg=0.167, mano_center_idx=0)
+    if patches > 1:  # configs[2]/[4] extension: P sphere patches (union of closed spheres), smaller spheres to keep the oracle fast
+        cfg.update(atlas_patches=patches, atlas_ico_divisions=2)
     if contact:
         cfg.update(contact_lambda=1.0, collision_lambda=1.0, contact_zones="zones", contact_mode="dist_tanh",
                    collision_mode="dist_tanh", contact_thresh=10, collision_thresh=20)
@@ -61,8 +63,9 @@ def test_handnet_resnet18_matches_cpu_oracle(contact):
     sample = {TransQueries.images: images, TransQueries.verts3d: gtv, TransQueries.joints3d: gtj,
               TransQueries.objpoints3d: gto, BaseQueries.sides: ["left"] * B, "root": "wrist"}
     packs = {s: omano.pack_to_torch(synthetic_mano(s)) for s in ("right", "left")}
+    ocfg = {k: v for k, v in cfg.items() if k not in ("atlas_patches", "atlas_ico_divisions")}
     o_total, o_res, o_losses = ohandnet.handnet_forward(
-        named, cfg, dict(sample), keys, packs, model.atlas_branch.test_verts.clone(), model.atlas_branch.test_faces,
+        named, ocfg, dict(sample), keys, packs, model.atlas_branch.test_verts.clone(), model.atlas_branch.test_faces,
         zones=load_contacts()[1], resnet_shell=resnet.resnet18(), training=True)
     o_total.backward()
     model.cuda()
