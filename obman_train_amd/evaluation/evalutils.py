@@ -4,18 +4,25 @@ it back with ONE device->host copy (the reference calls ``.item()`` once per key
 from obman_train_amd.trainer import read_losses
 
 
-class AverageMeter(object):
+class AverageMeter:
+    """Latest value, weighted running sum and count; ``avg`` is derived."""
+
+    __slots__ = ("val", "sum", "count")
+
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
+        self.val, self.sum, self.count = 0, 0, 0
+
+    @property
+    def avg(self):
+        return self.sum / self.count if self.count else 0
 
     def update(self, val, n=1):
         self.val = val
         self.sum += val * n
         self.count += n
-        self.avg = self.sum / self.count
 
 
 class AverageMeters:
