@@ -6,9 +6,9 @@ replicas behave: every rank runs the whole path on its own shard of the batch (B
 the batch-global masked means stay rank-local) and only gradients are exchanged: mean over ranks.
 
 MI355X specifics: xGMI is point-to-point, so a ring all-reduce is bound by one ~77 GB/s link direction;
-the 51.7 MB of fp32 gradients are packed into a few flat buckets (default 25 MB: large enough to run at
-link rate, small enough that the first bucket - the last layers' gradients, ready first - is on the
-wire while ResNet's backward is still running).  Buckets are filled in reverse parameter order by
+the 51.7 MB of fp32 gradients are packed into flat 8 MB buckets: large enough to run near
+link rate, small enough that only the LAST bucket (conv1/layer1, ready at the very end of backward, < 8 MB
+~ 0.2 ms on the ring) is exposed; the others are on the wire while ResNet's backward is still running.  Buckets are filled in reverse parameter order by
 post-accumulate-grad hooks, reduced asynchronously on RCCL's own stream, and copied back before the
 optimizer step (``finish()``).  With ``world_size == 1`` everything is a no-op.
 """
@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 
 class GradientBuckets:
-    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, group=None):
+    def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
