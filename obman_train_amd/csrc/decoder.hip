@@ -261,15 +261,18 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
     // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
     // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
     const bool more = kt + 1 < nk && !(variant & 1);
+    // fragments are double-buffered in registers: step i+1's LDS reads are issued before step i's MFMAs
+    float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
     for (int step = 0; step < BK / 2; ++step) {
-      const int kk = step * 2;
-      const float b = T.Bs[cur][kk + kh][bcol];
-      const float a0 = T.As[cur][kk + kh][arow];
-      const float a1 = T.As[cur][kk + kh][arow + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+      const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+      const float nb = T.Bs[cur][kn + kh][bcol];
+      const float na0 = T.As[cur][kn + kh][arow];
+      const float na1 = T.As[cur][kn + kh][arow + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
       if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
+      fb = nb; fa0 = na0; fa1 = na1;
     }
     if (!(variant & 2)) __syncthreads();
   }
@@ -427,15 +430,17 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     if (kt + 1 < nk) fetch(rbeg + (kt + 1) * BK);
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
     const bool more = kt + 1 < nk;
+    float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
-    for (int step = 0; step < BK / 2; ++step) {  // next tile's transform + LDS writes spread over steps 4..11 (see gemm_rows_kernel)
-      const int kk = step * 2;
-      const float b = T.Bs[cur][kk + kh][bcol];
-      const float a0 = T.As[cur][kk + kh][arow];
-      const float a1 = T.As[cur][kk + kh][arow + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    for (int step = 0; step < BK / 2; ++step) {  // register double-buffered fragments; next tile's transform spread over steps 4..11
+      const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+      const float nb = T.Bs[cur][kn + kh][bcol];
+      const float na0 = T.As[cur][kn + kh][arow];
+      const float na1 = T.As[cur][kn + kh][arow + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
       if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
+      fb = nb; fa0 = na0; fa1 = na1;
     }
     __syncthreads();
   }

@@ -36,7 +36,7 @@ def kernel_us(fn, kid, iters=30, warmup=5):
     torch.cuda.synchronize()
     ms, n = _lib.prof_summary(kid)
     _lib.prof_enable(False)
-    return ms * 1e3 / max(n, 1)
+    return ms * 1e3 / iters  # per CALL (an op may launch the kernel more than once, e.g. one launch per direction)
 
 
 def bench_chamfer():
