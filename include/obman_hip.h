@@ -147,6 +147,15 @@ int obman_edge_loss_fwd(const float* verts, const int* faces, int B, int N, int 
 int obman_edge_loss_bwd(const float* verts, const int* faces, int B, int N, int F, const float* stats, const float* g_loss,
                         float* grad, obman_stream_t stream);
 
+/* ---- K9: template-Laplacian regulariser -----------------------------------------------------------
+ * Replaces LaplacianLoss / Laplacian (laplacianloss.py:24-150; CPU SciPy round trip every step in the reference).
+ * CSR (row_ptr [N+1], col, val) of the fixed symmetric N x N cotangent Laplacian of the template sphere, shared by all
+ * samples; verts [B,N,3] -> loss [1] = mean_{b,i} ||(L x_b)_i||_2.  Lx [B,N,3] fwd -> bwd; partial: B*ceil(N/256). */
+int obman_laplacian_fwd(const int* row_ptr, const int* col, const float* val, const float* verts, int B, int N, float* Lx,
+                        float* partial, float* loss, obman_stream_t stream);
+int obman_laplacian_bwd(const int* row_ptr, const int* col, const float* val, const float* Lx, const float* g_loss, int B, int N,
+                        float* scratch, float* grad, obman_stream_t stream);
+
 /* ---- fused BatchNorm2d (+ skip add) (+ ReLU), NHWC fp32 --------------------------------------------
  * Replaces bn -> relu and bn -> (+residual) -> relu of the ResNet blocks (bases/resnet.py:38-52,77-96) - separate
  * memory-bound passes in eager PyTorch.  x, skip, y, dy, dx, dskip are [R, C] row-major (R = B*H*W of a

@@ -27,6 +27,8 @@ _SIGNATURES = {
     "obman_pointgen_bwd": (_c_int, "pppppp"),
     "obman_edge_loss_fwd": (_c_int, "pp" "iii" "pp" "p"),
     "obman_edge_loss_bwd": (_c_int, "pp" "iii" "ppp" "p"),
+    "obman_laplacian_fwd": (_c_int, "pppp" "ii" "ppp" "p"),
+    "obman_laplacian_bwd": (_c_int, "ppppp" "ii" "pp" "p"),
     "obman_bnact_ws_floats": (_c_long, "li"),
     "obman_bnact_fwd": (_c_int, "pppppp" "li" "iffi" "ppp" "p"),
     "obman_bnact_bwd": (_c_int, "ppppp" "li" "iii" "ppppp" "p"),

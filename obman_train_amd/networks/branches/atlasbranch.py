@@ -15,6 +15,7 @@ import torch.nn.functional as torch_f
 from obman_train_amd import ops
 from obman_train_amd.icosphere import multi_patch
 from obman_train_amd.networks.branches import atlasutils
+from obman_train_amd.networks.branches.laplacianloss import LaplacianLoss
 from obman_train_amd.queries import TransQueries
 
 
@@ -110,8 +111,7 @@ class AtlasLoss:
         if atlas_loss != "chamfer":
             raise ValueError("Removed support for earth mover distance !")
         if lambda_laplacian:
-            raise NotImplementedError("Laplacian regulariser is a 'next' row (SURVEY §8f #2); the reference's "
-                                      "legacy autograd.Function raises on torch >= 1.5 anyway")
+            self.laplacian_loss = LaplacianLoss(laplacian_faces, laplacian_verts)
         self.lambda_atlas, self.final_lambda_atlas = lambda_atlas, final_lambda_atlas
         self.trans_weight, self.scale_weight = trans_weight, scale_weight
         self.edge_regul_lambda, self.lambda_laplacian = edge_regul_lambda, lambda_laplacian
@@ -158,6 +158,10 @@ class AtlasLoss:
                 l_edge = edge_loss(mesh, preds["objfaces"])
                 out["atlas_edge_regul"] = l_edge
                 final = final + self.edge_regul_lambda * l_edge
+            if self.lambda_laplacian:
+                l_lap = self.laplacian_loss(mesh)
+                out["atlas_laplac"] = l_lap
+                final = final + self.lambda_laplacian * l_lap
         else:
             sym = None
             final = torch.zeros(1, device=preds["objpoints3d"].device)

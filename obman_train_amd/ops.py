@@ -419,3 +419,35 @@ class _EdgeLoss(torch.autograd.Function):
 def edge_loss(verts, faces):
     """edge_loss(edges, faces) of atlasbranch.py:153-167: verts [B,N,3], faces [F,3] int32 (device) -> scalar."""
     return _EdgeLoss.apply(verts, faces)
+
+
+class _LaplacianLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, row_ptr, col, val):
+        verts = _dev(verts, "verts")
+        B, N = verts.shape[0], verts.shape[1]
+        if row_ptr.numel() != N + 1:
+            raise ValueError("Laplacian built for %d vertices, got %d" % (row_ptr.numel() - 1, N))
+        dev = verts.device
+        Lx = torch.empty_like(verts)
+        partial = torch.empty(B * ((N + 255) // 256), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().obman_laplacian_fwd(row_ptr.data_ptr(), col.data_ptr(), val.data_ptr(), verts.data_ptr(), B, N,
+                                                  Lx.data_ptr(), partial.data_ptr(), loss.data_ptr(), _stream()), "obman_laplacian_fwd")
+        ctx.save_for_backward(Lx, row_ptr, col, val)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        Lx, row_ptr, col, val = ctx.saved_tensors
+        B, N = Lx.shape[0], Lx.shape[1]
+        scratch, grad = torch.empty_like(Lx), torch.empty_like(Lx)
+        g = g.contiguous().view(1)
+        _lib.check(_lib.lib().obman_laplacian_bwd(row_ptr.data_ptr(), col.data_ptr(), val.data_ptr(), Lx.data_ptr(), g.data_ptr(), B, N,
+                                                  scratch.data_ptr(), grad.data_ptr(), _stream()), "obman_laplacian_bwd")
+        return grad, None, None, None
+
+
+def laplacian_loss(verts, row_ptr, col, val):
+    """mean row norm of (L . verts) for the fixed template Laplacian given as CSR device tensors (int32, int32, float32)."""
+    return _LaplacianLoss.apply(verts, row_ptr, col, val)

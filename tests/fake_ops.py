@@ -111,9 +111,18 @@ def edge_loss(verts, faces):
     return oatlas.edge_loss(verts, faces.long())
 
 
+def laplacian_loss(verts, row_ptr, col, val):
+    n = row_ptr.numel() - 1
+    rows = torch.repeat_interleave(torch.arange(n), (row_ptr[1:] - row_ptr[:-1]).long())
+    L = torch.zeros(n, n, dtype=verts.dtype)
+    L[rows, col.long()] = val.to(verts.dtype)
+    Lx = torch.einsum('ij,bjc->bic', L, verts)
+    return torch.norm(Lx.reshape(-1, 3), p=2, dim=1).mean()
+
+
 def install(monkeypatch):
     from obman_train_amd import ops
 
-    for name in ("pairmin", "chamfer", "mano_lbs", "mesh_contains_hits", "contact_tail", "pointgen_decode", "edge_loss"):
+    for name in ("pairmin", "chamfer", "mano_lbs", "mesh_contains_hits", "contact_tail", "pointgen_decode", "edge_loss", "laplacian_loss"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_rocm", lambda device: None)

@@ -314,6 +314,21 @@ def gen_handnet():
         os.chdir(cwd)
 
 
+def gen_laplacian():
+    from mano_train.networks.branches.laplacianloss import Laplacian
+
+    v, f = icosphere(2)
+    tmpl = torch.from_numpy(v.astype(np.float32))
+    rng = np.random.RandomState(61)
+    V = torch.from_numpy((v[None] * rng.uniform(20, 60, size=(2, 1, 3)) + rng.normal(0, 3.0, size=(2,) + v.shape)).astype(np.float32))
+    lap = Laplacian(f, tmpl)          # legacy autograd.Function: call its methods directly
+    Lx = lap.forward(V)
+    loss = torch.norm(Lx.view(-1, 3), p=2, dim=1).mean()
+    g_Lx = Lx / torch.norm(Lx, p=2, dim=2, keepdim=True) / (Lx.shape[0] * Lx.shape[1])
+    grad = lap.backward(g_Lx)
+    save("laplacian", template=tmpl, faces=f.astype(np.int32), V=V, Lx=Lx, loss=loss.reshape(1), grad=grad)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     install_shims()
@@ -324,3 +339,4 @@ if __name__ == "__main__":
     gen_atlas()
     gen_manobranch()
     gen_handnet()
+    gen_laplacian()
