@@ -322,9 +322,17 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   if (d1.rsplit > 1) d1.ws = (u64*)ws + (size_t)B * Nx;
   if (d0.rsplit > 1) (void)hipMemsetAsync(d0.ws, 0xff, sizeof(u64) * (size_t)B * Nx, st);
   if (d1.rsplit > 1) (void)hipMemsetAsync(d1.ws, 0xff, sizeof(u64) * (size_t)B * Ny, st);
+  // LDS reference tile (points per staging pass); OBMAN_PM_TILE overrides the 2048-point cap for the tile sweep of
+  // BASELINE.json configs[4] (multiples of 16, <= 3072 so that tile + merge buffers stay under 64 KiB)
+  static const int tile_cap = [] {
+    const char* e = getenv("OBMAN_PM_TILE");
+    int t = e ? atoi(e) : PM_REF_TILE;
+    t = (t / 16) * 16;
+    return t < 64 ? 64 : (t > 3072 ? 3072 : t);
+  }();
   auto tile_of = [](const PmDir& d) {
     int t = ((d.rchunk + 15) / 16) * 16;
-    return t > PM_REF_TILE ? PM_REF_TILE : t;
+    return t > tile_cap ? tile_cap : t;
   };
   auto smem_of = [](int tile, int qpt) { return (size_t)tile * sizeof(float4) + (size_t)8 * 64 * qpt * sizeof(float); };
   if (min_x && min_y && q0 == q1) {  // symmetric sizes: both directions in one launch

@@ -33,14 +33,16 @@ def _oracle(dec, feats, grid, training):
     return out, f, params
 
 
-@pytest.mark.parametrize("c1,B,subdiv,training", [(35, 3, 1, True), (35, 2, 1, False), (515, 4, 3, True), (515, 2, 2, False),
-                                                  (131, 5, 2, True)])
-def test_decoder_forward_backward_matches_oracle(c1, B, subdiv, training):
+@pytest.mark.parametrize("c1,B,subdiv,training,patches", [(35, 3, 1, True, 1), (35, 2, 1, False, 1), (515, 4, 3, True, 1),
+                                                          (515, 2, 2, False, 1), (131, 5, 2, True, 1), (515, 2, 1, True, 25)])
+def test_decoder_forward_backward_matches_oracle(c1, B, subdiv, training, patches):
     from obman_train_amd import ops
 
     dec = _decoder(c1, 7)
     dec.train(training)
-    grid = torch.from_numpy(icosphere(subdiv)[0].astype(np.float32))
+    from obman_train_amd.icosphere import multi_patch
+
+    grid = torch.from_numpy(multi_patch(subdiv, patches)[0].astype(np.float32))  # patches=25: the configs[2] template layout
     rng = np.random.RandomState(8)
     feats = torch.from_numpy(rng.normal(0, 1, size=(B, c1 - 3)).astype(np.float32))
     cot = torch.from_numpy(rng.normal(0, 1, size=(B, grid.shape[0], 3)).astype(np.float32))

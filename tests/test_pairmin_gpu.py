@@ -118,7 +118,7 @@ def test_chamfer_full_size_properties():
     translation invariance of the direct form, zero self-distance."""
     from obman_train_amd import ops
 
-    for B, n_p, n_g in ((64, 642, 600), (8, 16050, 600)):
+    for B, n_p, n_g in ((64, 642, 600), (8, 16050, 600), (2, 64050, 600)):  # configs 1/2, 2 (25 x 642), 4 (25 x 2562)
         p, g = _rand(B, n_p, 11, offset=30.0).cuda(), _rand(B, n_g, 12, offset=25.0).cuda()
         l1, l2 = ops.chamfer(p, g)
         s2, s1 = ops.chamfer(g, p)  # swapped roles

@@ -42,7 +42,10 @@ def kernel_us(fn, kid, iters=30, warmup=5):
 def bench_chamfer():
     from obman_train_amd import ops
 
-    for B, n_p, n_g in ((64, 642, 600), (64, 2562, 600), (64, 16050, 600), (64, 64050, 600)):
+    sizes = ((64, 642, 600), (64, 2562, 600), (64, 16050, 600), (64, 64050, 600))
+    if os.environ.get("OBMAN_KBENCH_ONE"):
+        sizes = ((64, 64050, 600),)
+    for B, n_p, n_g in sizes:
         p = (torch.randn(B, n_p, 3, device="cuda") * 40).requires_grad_()
         g = torch.randn(B, n_g, 3, device="cuda") * 40
         t_f = kernel_us(lambda: ops.chamfer(p, g), 1) * 1e-6
@@ -55,6 +58,20 @@ def bench_chamfer():
             fwd_us=round(t_f * 1e6, 2), bwd_us=round(t_b * 1e6, 2),
             fwd_alg_GBps=round(20.0 * (n_p + n_g) * B / t_f / 1e9, 1), fwd_Tpairs_per_s=round(pairs / t_f / 1e12, 3),
             fwd_valu_TFLOPs=round(pairs * 5 / t_f / 1e12, 1))), flush=True)
+
+
+def bench_tile_sweep():
+    """BASELINE.json configs[4]: LDS reference-tile sweep of the pair-min kernel at 25 x 2562 predicted vertices.
+    The tile cap is read once per process (OBMAN_PM_TILE), so this re-executes itself per value."""
+    import subprocess
+
+    for tile in (256, 512, 1024, 2048, 3072):
+        env = dict(os.environ, OBMAN_PM_TILE=str(tile), OBMAN_KBENCH_ONE="1")
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "chamfer"], env=env, capture_output=True, text=True).stdout
+        for line in out.splitlines():
+            if line.startswith("{"):
+                d = json.loads(line)
+                print(json.dumps(dict(kernel="chamfer_tile_sweep", tile_points=tile, lds_bytes=tile * 16, **{k: d[k] for k in ("n_pred", "fwd_us", "fwd_Tpairs_per_s")})), flush=True)
 
 
 def bench_mano():
@@ -121,6 +138,8 @@ if __name__ == "__main__":
     torch.zeros(1, device="cuda")
     if which in ("chamfer", "all"):
         bench_chamfer()
+    if which == "tiles":
+        bench_tile_sweep()
     if which in ("mano", "all"):
         bench_mano()
     if which in ("contains", "all"):
