@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 // ================================================================================================ small kernels
 namespace dec {
 
-constexpr int PREP_COLS = 8;
+constexpr int PREP_COLS = 4;  // 129 blocks at C1 = 515
 
 // Layer 1 in factored form + closed-form BN-1 statistics.  One block = PREP_COLS output channels.
 //   G[n,c] = W1[c,0:3].grid[n],  F[b,c] = b1[c] + W1[c,3:].feat[b]
@@ -499,10 +499,18 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1,
     float acc[PREP_COLS];
 #pragma unroll
     for (int j = 0; j < PREP_COLS; ++j) acc[j] = 0.f;
-    for (int k = lane; k < Cf; k += 64) {
-      const float f = feat[(size_t)b * Cf + k];
+    for (int k0 = 0; k0 < Cf; k0 += 512) {  // 8 independent loads in flight per lane
+      float f[8];
 #pragma unroll
-      for (int j = 0; j < PREP_COLS; ++j) acc[j] = __fmaf_rn(f, sW[j * C1 + 3 + k], acc[j]);
+      for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; f[u] = k < Cf ? feat[(size_t)b * Cf + k] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + lane + 64 * u;
+        if (k < Cf) {
+#pragma unroll
+          for (int j = 0; j < PREP_COLS; ++j) acc[j] = __fmaf_rn(f[u], sW[j * C1 + 3 + k], acc[j]);
+        }
+      }
     }
 #pragma unroll
     for (int j = 0; j < PREP_COLS; ++j) {
@@ -775,6 +783,26 @@ __global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restri
   }
 }
 
+// g_feat[b,k] = sum_c dF[b,c] * W1[c, 3+k]: 64 samples x 512 features, contraction 515 - far too skinny for the tiled
+// MFMA kernel (one row block, 17 serial k-tiles); thread = (b, k), dF broadcast within the wave, W1 coalesced over k.
+__global__ __launch_bounds__(256) void gfeat_kernel(const float* __restrict__ dF, int ld1, const float* __restrict__ W1, int C1, int B,
+                                                    float* __restrict__ g_feat) {
+  const int Cf = C1 - 3, k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (k >= Cf) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float* d = dF + (size_t)b * ld1;
+  const float* w = W1 + 3 + k;
+  int c = 0;
+  for (; c + 3 < C1; c += 4) {
+    a0 = __fmaf_rn(d[c], w[(size_t)c * C1], a0);
+    a1 = __fmaf_rn(d[c + 1], w[(size_t)(c + 1) * C1], a1);
+    a2 = __fmaf_rn(d[c + 2], w[(size_t)(c + 2) * C1], a2);
+    a3 = __fmaf_rn(d[c + 3], w[(size_t)(c + 3) * C1], a3);
+  }
+  for (; c < C1; ++c) a0 = __fmaf_rn(d[c], w[(size_t)c * C1], a0);
+  g_feat[(size_t)b * Cf + k] = (a0 + a1) + (a2 + a3);
+}
+
 // out[m*ldo + off + n] = sum_c part[c][m][n]   (fixed chunk order)
 __global__ __launch_bounds__(256) void reduce_tn_kernel(const float* __restrict__ part, int chunks, int M, int Nc, int ldo, int off,
                                                         float* __restrict__ out) {
@@ -803,7 +831,7 @@ Dims dims_of(const obman_pointgen_params* p) {
   d.rb = (int)((d.R + BM - 1) / BM);
   return d;
 }
-constexpr int L4_ROWS = 128;
+constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 blocks at 64 x 642 points)
 constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gradient GEMMs
 
 // forward workspace (kept for the backward), float offsets
@@ -997,11 +1025,8 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     if (rc) return rc;
   }
   if (g->feat) {  // g_feat[b,k] = sum_c dF[b,c] W1[c,3+k]
-    APlain adf{ws2 + v.dF, d.ld1, d.B, d.C1};
-    EpiStoreImpl e;
-    e.C = g->feat; e.bias = nullptr; e.moments = nullptr; e.ldc = Cf; e.R = d.B; e.Nc = Cf;
-    rc = launch_rows<APlain, false, EpiStoreImpl>(adf, p->w1 + 3, d.C1, d.C1, Cf, d.B, e, st);
-    if (rc) return rc;
+    gfeat_kernel<<<dim3(obman_cdiv(Cf, 256), d.B), 256, 0, st>>>(ws2 + v.dF, d.ld1, p->w1, d.C1, d.B, g->feat);
+    OBMAN_LAUNCH_CHECK();
   }
   return 0;
 }
