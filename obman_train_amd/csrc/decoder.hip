@@ -789,17 +789,20 @@ __global__ __launch_bounds__(256) void gfeat_kernel(const float* __restrict__ dF
                                                     float* __restrict__ g_feat) {
   const int Cf = C1 - 3, k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (k >= Cf) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   const float* d = dF + (size_t)b * ld1;
   const float* w = W1 + 3 + k;
+  float acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
   int c = 0;
-  for (; c + 3 < C1; c += 4) {
-    a0 = __fmaf_rn(d[c], w[(size_t)c * C1], a0);
-    a1 = __fmaf_rn(d[c + 1], w[(size_t)(c + 1) * C1], a1);
-    a2 = __fmaf_rn(d[c + 2], w[(size_t)(c + 2) * C1], a2);
-    a3 = __fmaf_rn(d[c + 3], w[(size_t)(c + 3) * C1], a3);
+  for (; c + 15 < C1; c += 16) {  // 16 independent strided loads in flight per lane
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = __fmaf_rn(d[c + u], w[(size_t)(c + u) * C1], acc[u]);
   }
-  for (; c < C1; ++c) a0 = __fmaf_rn(d[c], w[(size_t)c * C1], a0);
+  for (; c < C1; ++c) acc[0] = __fmaf_rn(d[c], w[(size_t)c * C1], acc[0]);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; u += 4) { a0 += acc[u]; a1 += acc[u + 1]; a2 += acc[u + 2]; a3 += acc[u + 3]; }
   g_feat[(size_t)b * Cf + k] = (a0 + a1) + (a2 + a3);
 }
 
