@@ -68,16 +68,14 @@ class ManoBranch(nn.Module):
         verts, joints = ops.mano_lbs(
             pose, shape, self._models["right"].on(dev), self._models["left"].on(dev) if side is not None else None,
             side, ncomps=self.ncomps, use_pca=self.use_pca, center_idx=self.center_idx, root_palm=root_palm)
-        if self.adapt_skeleton:
-            lefts = torch.ones(B, 1, 1, device=dev) if side is None else None
+        if self.adapt_skeleton:  # per-side 21x21 joint re-mixing (manobranch.py:183-192)
+            jt = joints.permute(0, 2, 1)
+            right = self.right_skeleton_reg(jt).permute(0, 2, 1)
             if side is None:  # every hand is a right hand
-                joints = self.right_skeleton_reg(joints.permute(0, 2, 1)).permute(0, 2, 1)
+                joints = right
             else:
-                is_left = side.bool().view(B, 1, 1)
-                jl = self.left_skeleton_reg(joints.permute(0, 2, 1)).permute(0, 2, 1)
-                jr = self.right_skeleton_reg(joints.permute(0, 2, 1)).permute(0, 2, 1)
-                joints = torch.where(is_left, jl, jr)
-            del lefts
+                left = self.left_skeleton_reg(jt).permute(0, 2, 1)
+                joints = torch.where(side.bool().view(B, 1, 1), left, right)
         return {"verts": verts, "joints": joints, "shape": shape, "pose": pose}
 
 

@@ -3,6 +3,8 @@
 PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic of these ops runs
 in ``csrc/*.hip``.  Every op requires fp32 ROCm tensors and raises otherwise - no CPU path.
 """
+import ctypes as _ct
+
 import torch
 
 from . import _lib
@@ -240,9 +242,6 @@ def contact_tail(hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zo
     """-> (missed_loss, penetr_loss, out[8], attraction_mask u8, repulsion_mask u8, contact_points)."""
     return _ContactTail.apply(hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zone_mode, contact_mode,
                               contact_thresh, collision_mode, collision_thresh, target)
-
-
-import ctypes as _ct
 
 
 class _PointGen(torch.autograd.Function):
