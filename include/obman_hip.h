@@ -167,6 +167,14 @@ int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const
 int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats, long R, int C, int training,
                     int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream);
 
+/* Stem variant: y_pool = MaxPool2d(3, stride 2, pad 1)(relu(bn(x))) (bases/resnet.py:156-163) without materialising the
+ * full-resolution activation.  x [B,H,W,C] NHWC, y_pool / d_pool [B,(H-1)/2+1,(W-1)/2+1,C]; stats as above;
+ * ws: obman_bnact_ws_floats(B*H*W, C). */
+int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
+                     int training, float eps, float momentum, float* y_pool, float* stats, float* ws, obman_stream_t stream);
+int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, const float* gamma, const float* stats, int B, int H, int W,
+                     int C, int training, float* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream);
+
 /* ---- measurement utility (not on the product path) ----------------------------------------------
  * obman_prof_enable(1) makes the launchers bracket their main kernel with HIP events on the launch
  * stream (pool of 8192 records, reset by every enable call); obman_prof_summary synchronises and

@@ -32,6 +32,8 @@ _SIGNATURES = {
     "obman_bnact_ws_floats": (_c_long, "li"),
     "obman_bnact_fwd": (_c_int, "pppppp" "li" "iffi" "ppp" "p"),
     "obman_bnact_bwd": (_c_int, "ppppp" "li" "iii" "ppppp" "p"),
+    "obman_bnpool_fwd": (_c_int, "ppppp" "iiii" "iff" "ppp" "p"),
+    "obman_bnpool_bwd": (_c_int, "ppppp" "iiii" "i" "pppp" "p"),
     "obman_prof_enable": (_c_int, "i"),
     "obman_prof_summary": (_c_int, "ipp"),
     "obman_mano_model_floats": (_c_int, ""),

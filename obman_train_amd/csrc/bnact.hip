@@ -176,6 +176,108 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- stem: + MaxPool(3,2,1)
+// y_pool[b,ho,wo,c] = max over the 3x3 / stride-2 / pad-1 window of relu(s*x + t).  The full-resolution activation is
+// never written (268 MB at bs 64): forward reads x once and writes the pooled map; backward recomputes y from x and
+// routes d(pool) to every pixel with y == y_pool of a covering window and y > 0 (identical to torch's arg-max routing
+// except on exact ties of positive values; ties at 0 carry no gradient through the ReLU either way).
+struct PoolGeo { int H, W, Ho, Wo; };
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ X, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                       Geo g, PoolGeo pg, float* __restrict__ Yp) {
+  const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+  const int c = blockIdx.y * CT + cl * 4;
+  const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);  // rows = pooled pixels
+  const float4 vs = *reinterpret_cast<const float4*>(sc + c), vt = *reinterpret_cast<const float4*>(sh + c);
+  for (long r = r0 + rl; r < r1; r += 16) {
+    const int wo = (int)(r % pg.Wo), ho = (int)((r / pg.Wo) % pg.Ho);
+    const long b = r / ((long)pg.Wo * pg.Ho);
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // relu >= 0 and the window centre is always in bounds
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int h = 2 * ho + dy;
+      if (h < 0 || h >= pg.H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int w = 2 * wo + dx;
+        if (w < 0 || w >= pg.W) continue;
+        const float4 x = *reinterpret_cast<const float4*>(X + ((size_t)(b * pg.H + h) * pg.W + w) * g.C + c);
+        m.x = fmaxf(m.x, __fmaf_rn(vs.x, x.x, vt.x)); m.y = fmaxf(m.y, __fmaf_rn(vs.y, x.y, vt.y));
+        m.z = fmaxf(m.z, __fmaf_rn(vs.z, x.z, vt.z)); m.w = fmaxf(m.w, __fmaf_rn(vs.w, x.w, vt.w));
+      }
+    }
+    *reinterpret_cast<float4*>(Yp + (size_t)r * g.C + c) = m;
+  }
+}
+
+// d(loss)/d(relu output) of pixel (b,h,w): sum of the pooled gradients of the covering windows whose max this pixel is
+__device__ __forceinline__ float4 pool_dz(const float4 y, long b, int h, int w, const PoolGeo& pg, int C, int c,
+                                          const float* __restrict__ Yp, const float* __restrict__ Dp) {
+  float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ho0 = h >> 1, nho = (h & 1) ? 2 : 1, wo0 = w >> 1, nwo = (w & 1) ? 2 : 1;
+  for (int i = 0; i < nho; ++i) {
+    const int ho = ho0 + i;
+    if (ho >= pg.Ho) continue;
+    for (int j = 0; j < nwo; ++j) {
+      const int wo = wo0 + j;
+      if (wo >= pg.Wo) continue;
+      const size_t o = ((size_t)(b * pg.Ho + ho) * pg.Wo + wo) * C + c;
+      const float4 yp = *reinterpret_cast<const float4*>(Yp + o), dp = *reinterpret_cast<const float4*>(Dp + o);
+      dz.x += (y.x > 0.f && y.x == yp.x) ? dp.x : 0.f; dz.y += (y.y > 0.f && y.y == yp.y) ? dp.y : 0.f;
+      dz.z += (y.z > 0.f && y.z == yp.z) ? dp.z : 0.f; dz.w += (y.w > 0.f && y.w == yp.w) ? dp.w : 0.f;
+    }
+  }
+  return dz;
+}
+
+template <bool APPLY>  // false: per-block sums (dz, dz*xhat); true: dx = k1*(dz - k2 - xhat*k3)
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yp, const float* __restrict__ Dp,
+                                                       const float* __restrict__ sc, const float* __restrict__ sh,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ k, Geo g, PoolGeo pg, double* __restrict__ partial,
+                                                       float* __restrict__ DX) {
+  const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+  const int c = blockIdx.y * CT + cl * 4;
+  const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);  // rows = input pixels
+  const float4 vs = *reinterpret_cast<const float4*>(sc + c), vt = *reinterpret_cast<const float4*>(sh + c);
+  const float4 vm = *reinterpret_cast<const float4*>(mean + c), vr = *reinterpret_cast<const float4*>(rstd + c);
+  float4 k1 = make_float4(0, 0, 0, 0), k2 = k1, k3 = k1;
+  if (APPLY) {
+    k1 = *reinterpret_cast<const float4*>(k + c); k2 = *reinterpret_cast<const float4*>(k + g.C + c);
+    k3 = *reinterpret_cast<const float4*>(k + 2 * g.C + c);
+  }
+  float4 a = make_float4(0, 0, 0, 0), bb = a;
+  for (long r = r0 + rl; r < r1; r += 16) {
+    const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
+    const long b = r / ((long)pg.W * pg.H);
+    const size_t o = (size_t)r * g.C + c;
+    const float4 x = *reinterpret_cast<const float4*>(X + o);
+    const float4 y = make_float4(fmaxf(__fmaf_rn(vs.x, x.x, vt.x), 0.f), fmaxf(__fmaf_rn(vs.y, x.y, vt.y), 0.f),
+                                 fmaxf(__fmaf_rn(vs.z, x.z, vt.z), 0.f), fmaxf(__fmaf_rn(vs.w, x.w, vt.w), 0.f));
+    const float4 d = pool_dz(y, b, h, w, pg, g.C, c, Yp, Dp);
+    const float4 xh = make_float4((x.x - vm.x) * vr.x, (x.y - vm.y) * vr.y, (x.z - vm.z) * vr.z, (x.w - vm.w) * vr.w);
+    if (APPLY) {
+      *reinterpret_cast<float4*>(DX + o) = make_float4(k1.x * (d.x - k2.x - xh.x * k3.x), k1.y * (d.y - k2.y - xh.y * k3.y),
+                                                       k1.z * (d.z - k2.z - xh.z * k3.z), k1.w * (d.w - k2.w - xh.w * k3.w));
+    } else {
+      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+      bb.x = __fmaf_rn(d.x, xh.x, bb.x); bb.y = __fmaf_rn(d.y, xh.y, bb.y); bb.z = __fmaf_rn(d.z, xh.z, bb.z); bb.w = __fmaf_rn(d.w, xh.w, bb.w);
+    }
+  }
+  if (APPLY) return;
+  __shared__ float red[16][CT][2];
+  red[rl][cl * 4 + 0][0] = a.x; red[rl][cl * 4 + 1][0] = a.y; red[rl][cl * 4 + 2][0] = a.z; red[rl][cl * 4 + 3][0] = a.w;
+  red[rl][cl * 4 + 0][1] = bb.x; red[rl][cl * 4 + 1][1] = bb.y; red[rl][cl * 4 + 2][1] = bb.z; red[rl][cl * 4 + 3][1] = bb.w;
+  __syncthreads();
+  if (tid < CT * 2) {
+    const int ch = tid >> 1, q = tid & 1;
+    double s = 0;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) s += (double)red[kk][ch][q];
+    partial[((size_t)(blockIdx.y * CT + ch) * g.nblk + blockIdx.x) * 2 + q] = s;
+  }
+}
+
 Geo geo(long R, int C) {
   Geo g; g.R = R; g.C = C;
   const long col_blocks = C / CT;
@@ -245,6 +347,51 @@ int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float
   if (mode == 1) bnact::bwd_apply_kernel<1><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
   else if (mode == 2) bnact::bwd_apply_kernel<2><<<grid, 256, 0, st>>>(x, dskip, sc, sh, mean, rstd, k, g, dx);
   else bnact::bwd_apply_kernel<3><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
+/* Stem: y_pool = maxpool3x3/s2/p1(relu(bn(x))).  x [B,H,W,C] NHWC, y_pool [B,Ho,Wo,C], Ho = (H-1)/2+1.
+ * ws: obman_bnact_ws_floats(B*H*W, C) floats. */
+int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
+                     int training, float eps, float momentum, float* y_pool, float* stats, float* ws, obman_stream_t stream) {
+  if (!x || !y_pool || !stats || !ws || !gamma || !beta || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % bnact::CT) return -1;
+  if (!training && (!rmean || !rvar)) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long R = (long)B * H * W;
+  const bnact::Geo g = bnact::geo(R, C);
+  double* partial = reinterpret_cast<double*>(ws);
+  float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
+  if (training) {
+    bnact::sums_kernel<0><<<dim3(g.nblk, C / bnact::CT), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
+    OBMAN_LAUNCH_CHECK();
+  }
+  bnact::fwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, eps, momentum, gamma, beta, rmean, rvar, mean,
+                                                                rstd, sc, sh);
+  OBMAN_LAUNCH_CHECK();
+  const bnact::PoolGeo pg{H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+  const bnact::Geo gp = bnact::geo((long)B * pg.Ho * pg.Wo, C);
+  bnact::pool_fwd_kernel<<<dim3(gp.nblk, C / bnact::CT), 256, 0, st>>>(x, sc, sh, gp, pg, y_pool);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
+int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, const float* gamma, const float* stats, int B, int H, int W,
+                     int C, int training, float* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream) {
+  if (!x || !y_pool || !d_pool || !stats || !ws || !dx || !dgamma || !dbeta || B <= 0 || C % bnact::CT) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const long R = (long)B * H * W;
+  const bnact::Geo g = bnact::geo(R, C);
+  const bnact::PoolGeo pg{H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+  double* partial = reinterpret_cast<double*>(ws);
+  float* k = ws + (size_t)g.nblk * C * 2 * 2;
+  const float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
+  dim3 grid(g.nblk, C / bnact::CT);
+  bnact::pool_bwd_kernel<false><<<grid, 256, 0, st>>>(x, y_pool, d_pool, sc, sh, mean, rstd, nullptr, g, pg, partial, nullptr);
+  OBMAN_LAUNCH_CHECK();
+  bnact::bwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, gamma, rstd, dgamma, dbeta, k);
+  OBMAN_LAUNCH_CHECK();
+  bnact::pool_bwd_kernel<true><<<grid, 256, 0, st>>>(x, y_pool, d_pool, sc, sh, mean, rstd, k, g, pg, nullptr, dx);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }

@@ -132,7 +132,7 @@ class ResNet(nn.Module):
             for blk in self._blocks:
                 blk._count = False
         try:
-            x = self.maxpool(ops.bn_act(self.bn1, self.conv1(x), count=not batched))
+            x = ops.bn_relu_maxpool(self.bn1, self.conv1(x), self.maxpool, count=not batched)
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         finally:
             if batched:

@@ -450,3 +450,58 @@ class _LaplacianLoss(torch.autograd.Function):
 def laplacian_loss(verts, row_ptr, col, val):
     """mean row norm of (L . verts) for the fixed template Laplacian given as CSR device tensors (int32, int32, float32)."""
     return _LaplacianLoss.apply(verts, row_ptr, col, val)
+
+
+class _BNReLUPool(torch.autograd.Function):
+    """maxpool3x3/s2/p1(relu(bn(x))) for the ResNet stem without the full-resolution activation (csrc/bnact.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rmean, rvar, training, eps, momentum):
+        B, C, H, W = x.shape
+        lib = _lib.lib()
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.obman_bnact_ws_floats(B * H * W, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.obman_bnpool_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(rmean), _ptr(rvar), B, H, W, C,
+                                        int(training), float(eps), float(momentum), y.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                        _stream()), "obman_bnpool_fwd")
+        ctx.save_for_backward(x, y, weight, stats)
+        ctx.cfg = (B, H, W, C, int(training))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, stats = ctx.saved_tensors
+        B, H, W, C, training = ctx.cfg
+        lib = _lib.lib()
+        if not _is_nhwc(dy):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(weight), torch.empty_like(weight)
+        ws = torch.empty(lib.obman_bnact_ws_floats(B * H * W, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.obman_bnpool_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), weight.data_ptr(), stats.data_ptr(), B, H, W, C,
+                                        training, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream()),
+                   "obman_bnpool_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_maxpool(bn, x, pool, count=True):
+    """``pool(relu(bn(x)))`` for ``nn.MaxPool2d(3, stride=2, padding=1)``; fused for channels_last fp32 ROCm tensors with
+    C % 64 == 0, stock ops otherwise."""
+    def _t(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+    fused = (x.is_cuda and x.dtype == torch.float32 and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
+             and _t(pool.kernel_size) == (3, 3) and _t(pool.stride) == (2, 2) and _t(pool.padding) == (1, 1)
+             and _t(pool.dilation) == (1, 1) and not pool.ceil_mode and not pool.return_indices)
+    if not fused:
+        return pool(bn_act(bn, x, relu=True, count=count))
+    training = bn.training or bn.running_mean is None
+    if count and bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    if bn.momentum is None:
+        momentum = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
+    else:
+        momentum = bn.momentum
+    return _BNReLUPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum)

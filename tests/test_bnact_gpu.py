@@ -61,6 +61,35 @@ def test_bn_act_matches_torch(shape, relu, has_skip, training):
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("shape,training", [((2, 64, 16, 16), True), ((3, 64, 13, 9), True), ((2, 128, 8, 8), False), ((8, 64, 64, 64), True)])
+def test_bn_relu_maxpool_matches_torch(shape, training):
+    from obman_train_amd import ops
+
+    torch.manual_seed(1)
+    B, C, H, W = shape
+    bn = nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(-1.0, 1.5)  # negative scales too: the max is over relu(s*x+t), not over x
+        bn.bias.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+    bn.train(training)
+    bn_ref = copy.deepcopy(bn)
+    pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    x = (torch.randn(shape, device="cuda") * 2 + 0.3).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = ops.bn_relu_maxpool(bn, xa, pool)
+    yb = pool(torch.relu(bn_ref(xb)))
+    assert ya.shape == yb.shape and ya.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=2e-5)
+    w = torch.randn_like(yb)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    for a, b, name in ((xa.grad, xb.grad, "dx"), (bn.weight.grad, bn_ref.weight.grad, "dgamma"), (bn.bias.grad, bn_ref.bias.grad, "dbeta")):
+        err = (a - b).abs().max().item()
+        assert err <= 2e-4 * b.abs().max().item() + 1e-6, (name, err, b.abs().max().item())
+    torch.testing.assert_close(bn.running_var, bn_ref.running_var, rtol=1e-5, atol=1e-6)
+
+
 def test_resnet18_with_fused_bn_matches_stock_blocks():
     """Whole encoder: fused path (channels_last on the GPU) vs the same module evaluated with stock ops on the CPU."""
     from obman_train_amd.networks.bases.resnet import resnet18
