@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16 = autocast the ResNet encoder (configs[2] flavour; NOT the headline fp32 config)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="self-test: run the RCCL process group + gradient buckets even with a single rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -111,9 +113,12 @@ def main():
 
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     import warnings
     warnings.simplefilter("ignore")
     torch.backends.cudnn.benchmark = True
@@ -133,19 +138,19 @@ def main():
         model.base_net.autocast_dtype = torch.bfloat16
     broadcast_parameters(model)
     opt = make_optimizer(model, "adam", lr=1e-4)
-    buckets = GradientBuckets(model.parameters()) if world > 1 else None
+    buckets = GradientBuckets(model.parameters(), force=args.force_dist) if use_dist else None
     sample = make_batch(args.batch, dev, seed=rank, image_size=args.image_size)
 
     for _ in range(args.warmup):
         train_step(model, opt, sample, buckets)
     _lib.prof_enable(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         total, _, _ = train_step(model, opt, sample, buckets)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -154,7 +159,7 @@ def main():
     dec_f_ms, dec_f_n = _lib.prof_summary(8)
     dec_b_ms, dec_b_n = _lib.prof_summary(9)
     _lib.prof_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -211,7 +216,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

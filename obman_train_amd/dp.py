@@ -17,11 +17,11 @@ import torch.distributed as dist
 
 
 class GradientBuckets:
-    def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None):
+    def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 or (force and dist.is_available() and dist.is_initialized())  # force: 1-rank self-test
         self.buckets = []      # (flat buffer, [(param, offset, numel)])
         self._where = {}
         self._pending = []
