@@ -6,28 +6,38 @@ replicas behave: every rank runs the whole path on its own shard of the batch (B
 the batch-global masked means stay rank-local) and only gradients are exchanged: mean over ranks.
 
 MI355X specifics: xGMI is point-to-point, so a ring all-reduce is bound by one ~77 GB/s link direction;
-the 51.7 MB of fp32 gradients are packed into flat 8 MB buckets: large enough to run near
-link rate, small enough that only the LAST bucket (conv1/layer1, ready at the very end of backward, < 8 MB
-~ 0.2 ms on the ring) is exposed; the others are on the wire while ResNet's backward is still running.  Buckets are filled in reverse parameter order by
-post-accumulate-grad hooks, reduced asynchronously on RCCL's own stream, and copied back before the
-optimizer step (``finish()``).  With ``world_size == 1`` everything is a no-op.
+the 51.7 MB of fp32 gradients live in flat 8 MB buckets (the parameters' ``.grad`` are views into them): large
+enough to run near link rate, small enough that only the LAST bucket (conv1/layer1, ready at the very end of backward,
+< 8 MB ~ 0.2 ms on the ring) is exposed; the others are on the wire while ResNet's backward is still running.  Buckets
+are laid out in reverse parameter order, all-reduced (AVG) asynchronously on RCCL's own stream as soon as their last
+gradient has been accumulated, and waited for before the optimizer step (``finish()``).  With ``world_size == 1`` everything is a no-op.
 """
 import torch
 import torch.distributed as dist
 
 
 class GradientBuckets:
+    """Flat gradient buckets whose slices ARE the parameters' ``.grad`` tensors (no copy in, no copy out).
+
+    ``zero_grad()`` (instead of ``optimizer.zero_grad(set_to_none=True)``) keeps the views alive; autograd accumulates
+    straight into the bucket; the post-accumulate hook of the last parameter of a bucket launches its asynchronous
+    all-reduce (``AVG`` on RCCL, so no scaling pass); ``finish()`` waits before the optimizer step.  Parameters that get
+    no gradient in a step (``base_net.fc``) contribute zeros."""
+
     def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None, force=False):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
         self.params = [p for p in params if p.requires_grad]
-        self.enabled = self.world > 1 or (force and dist.is_available() and dist.is_initialized())  # force: 1-rank self-test
+        self.enabled = self.world > 1 or (force and live)  # force: single-rank self-test of the whole mechanism
         self.buckets = []      # (flat buffer, [(param, offset, numel)])
         self._where = {}
         self._pending = []
         self._works = []
+        self._seen = set()
         if not self.enabled:
             return
+        self._avg = dist.get_backend(group) == "nccl"  # RCCL averages in the collective; gloo has no AVG
         cur, cur_bytes = [], 0
         for p in reversed(self.params):  # backward produces the last layers' gradients first
             cur.append(p)
@@ -46,39 +56,51 @@ class GradientBuckets:
         slots, off = [], 0
         for p in plist:
             slots.append((p, off, p.numel()))
-            self._where[p] = (len(self.buckets), off)
+            self._where[p] = len(self.buckets)
+            p.grad = flat[off:off + p.numel()].view(p.shape)  # the gradient lives inside the bucket
             off += p.numel()
         self.buckets.append((flat, slots))
         self._pending.append(len(slots))
 
+    def zero_grad(self):
+        """Replacement for ``optimizer.zero_grad``: one memset per bucket, gradient views stay attached."""
+        if not self.enabled:
+            for p in self.params:
+                p.grad = None
+            return
+        for flat, slots in self.buckets:
+            flat.zero_()
+            for p, off, n in slots:
+                if p.grad is None or p.grad.data_ptr() != flat.data_ptr() + off * flat.element_size():
+                    p.grad = flat[off:off + n].view(p.shape)  # someone detached it (set_to_none): re-attach
+
+    def _launch(self, b):
+        flat = self.buckets[b][0]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works.append((b, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
+
     def _on_grad(self, p):
-        b, off = self._where[p]
-        flat, slots = self.buckets[b]
-        flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if p in self._seen:  # a second accumulation into the same parameter in one step (not on this path)
+            return
+        self._seen.add(p)
+        b = self._where[p]
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            self._works.append((b, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            self._launch(b)
 
     def finish(self):
-        """Wait for the reductions, write mean gradients back into ``param.grad``.  Call before ``optimizer.step()``."""
+        """Wait for every bucket (launching the ones left open by gradient-less parameters).  Call before ``optimizer.step()``."""
         if not self.enabled:
             return
-        # parameters that received no gradient this step (e.g. base_net.fc) leave their bucket open: flush
         for b, left in enumerate(self._pending):
             if left > 0:
-                flat, slots = self.buckets[b]
-                for p, off, n in slots:
-                    if p.grad is None:
-                        flat[off:off + n].zero_()
-                self._works.append((b, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
-        inv = 1.0 / self.world
+                self._launch(b)
         for b, work in self._works:
             work.wait()
-            flat, slots = self.buckets[b]
-            for p, off, n in slots:
-                if p.grad is not None:
-                    p.grad.copy_(flat[off:off + n].view_as(p.grad) * inv)
+            if not self._avg:
+                self.buckets[b][0].mul_(1.0 / self.world)
         self._works = []
+        self._seen = set()
         self._pending = [len(slots) for _, slots in self.buckets]
 
 

@@ -27,7 +27,10 @@ def epoch_pass(loader, model, epoch, optimizer=None, debug=True, freeze_batchnor
         with torch.set_grad_enabled(train):
             model_loss, results, model_losses = net.forward(sample, return_features=inspect_weights)
         if train:
-            optimizer.zero_grad(set_to_none=True)
+            if buckets is not None and buckets.enabled:
+                buckets.zero_grad()
+            else:
+                optimizer.zero_grad(set_to_none=True)
             model_loss.backward()
             if buckets is not None:
                 buckets.finish()

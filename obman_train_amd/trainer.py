@@ -7,7 +7,10 @@ import torch
 
 def train_step(model, optimizer, sample, buckets=None):
     total, results, losses = model.forward(sample)
-    optimizer.zero_grad(set_to_none=True)
+    if buckets is not None and buckets.enabled:
+        buckets.zero_grad()  # gradients are views into the all-reduce buckets: zero them in place
+    else:
+        optimizer.zero_grad(set_to_none=True)
     total.backward()
     if buckets is not None:
         buckets.finish()
