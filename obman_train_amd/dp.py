@@ -50,6 +50,15 @@ class GradientBuckets:
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
+    @staticmethod
+    def _view(flat, off, p):
+        """Slice of the bucket shaped AND strided like the parameter (fused optimizers require grad.layout == param.layout;
+        conv filters are channels_last)."""
+        dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+        if dense:
+            return torch.as_strided(flat, p.shape, p.stride(), off)
+        return flat[off:off + p.numel()].view(p.shape)
+
     def _close(self, plist):
         total = sum(p.numel() for p in plist)
         flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
@@ -57,7 +66,7 @@ class GradientBuckets:
         for p in plist:
             slots.append((p, off, p.numel()))
             self._where[p] = len(self.buckets)
-            p.grad = flat[off:off + p.numel()].view(p.shape)  # the gradient lives inside the bucket
+            p.grad = self._view(flat, off, p)  # the gradient lives inside the bucket
             off += p.numel()
         self.buckets.append((flat, slots))
         self._pending.append(len(slots))
@@ -71,8 +80,9 @@ class GradientBuckets:
         for flat, slots in self.buckets:
             flat.zero_()
             for p, off, n in slots:
-                if p.grad is None or p.grad.data_ptr() != flat.data_ptr() + off * flat.element_size():
-                    p.grad = flat[off:off + n].view(p.shape)  # someone detached it (set_to_none): re-attach
+                if (p.grad is None or p.grad.data_ptr() != flat.data_ptr() + off * flat.element_size()
+                        or p.grad.stride() != p.stride()):
+                    p.grad = self._view(flat, off, p)  # detached (set_to_none) or the parameter was re-laid-out: re-attach
 
     def _launch(self, b):
         flat = self.buckets[b][0]
