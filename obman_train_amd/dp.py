@@ -6,7 +6,7 @@ replicas behave: every rank runs the whole path on its own shard of the batch (B
 the batch-global masked means stay rank-local) and only gradients are exchanged: mean over ranks.
 
 MI355X specifics: xGMI is point-to-point, so a ring all-reduce is bound by one ~77 GB/s link direction;
-the 51.7 MB of fp32 gradients live in flat 8 MB buckets (the parameters' ``.grad`` are views into them): large
+the 51.7 MB of fp32 gradients are packed into flat 8 MB buckets (one multi-tensor copy per bucket): large
 enough to run near link rate, small enough that only the LAST bucket (conv1/layer1, ready at the very end of backward,
 < 8 MB ~ 0.2 ms on the ring) is exposed; the others are on the wire while ResNet's backward is still running.  Buckets
 are laid out in reverse parameter order, all-reduced (AVG) asynchronously on RCCL's own stream as soon as their last
@@ -17,12 +17,14 @@ import torch.distributed as dist
 
 
 class GradientBuckets:
-    """Flat gradient buckets whose slices ARE the parameters' ``.grad`` tensors (no copy in, no copy out).
+    """Flat gradient buckets, one multi-tensor copy per bucket, no copy back.
 
-    ``zero_grad()`` (instead of ``optimizer.zero_grad(set_to_none=True)``) keeps the views alive; autograd accumulates
-    straight into the bucket; the post-accumulate hook of the last parameter of a bucket launches its asynchronous
-    all-reduce (``AVG`` on RCCL, so no scaling pass); ``finish()`` waits before the optimizer step.  Parameters that get
-    no gradient in a step (``base_net.fc``) contribute zeros."""
+    Autograd assigns fresh gradient tensors (``zero_grad`` = set to None, so no accumulate-add kernels); when the last
+    gradient of a bucket has arrived its post-accumulate hook packs the whole bucket with ONE ``torch._foreach_copy_``
+    launch, re-points every ``.grad`` at its slice of the flat buffer (strided like the parameter: fused optimizers need
+    grad.layout == param.layout, conv filters are channels_last) and starts the asynchronous all-reduce (``AVG`` on RCCL,
+    so no scaling pass).  ``finish()`` waits before the optimizer step.  Parameters without a gradient in a step
+    (``base_net.fc``) contribute zeros and keep ``grad = None``."""
 
     def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None, force=False):
         self.group = group
@@ -52,8 +54,6 @@ class GradientBuckets:
 
     @staticmethod
     def _view(flat, off, p):
-        """Slice of the bucket shaped AND strided like the parameter (fused optimizers require grad.layout == param.layout;
-        conv filters are channels_last)."""
         dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
         if dense:
             return torch.as_strided(flat, p.shape, p.stride(), off)
@@ -66,26 +66,28 @@ class GradientBuckets:
         for p in plist:
             slots.append((p, off, p.numel()))
             self._where[p] = len(self.buckets)
-            p.grad = self._view(flat, off, p)  # the gradient lives inside the bucket
             off += p.numel()
         self.buckets.append((flat, slots))
         self._pending.append(len(slots))
 
     def zero_grad(self):
-        """Replacement for ``optimizer.zero_grad``: one memset per bucket, gradient views stay attached."""
-        if not self.enabled:
-            for p in self.params:
-                p.grad = None
-            return
-        for flat, slots in self.buckets:
-            flat.zero_()
-            for p, off, n in slots:
-                if (p.grad is None or p.grad.data_ptr() != flat.data_ptr() + off * flat.element_size()
-                        or p.grad.stride() != p.stride()):
-                    p.grad = self._view(flat, off, p)  # detached (set_to_none) or the parameter was re-laid-out: re-attach
+        for p in self.params:
+            p.grad = None
 
     def _launch(self, b):
-        flat = self.buckets[b][0]
+        flat, slots = self.buckets[b]
+        views, grads = [], []
+        for p, off, n in slots:
+            v = self._view(flat, off, p)
+            if p.grad is None:
+                v.zero_()
+            else:
+                views.append(v)
+                grads.append(p.grad)
+        if views:
+            torch._foreach_copy_(views, grads)
+            for (p, off, n), v in zip([s for s in slots if s[0].grad is not None], views):
+                p.grad = v
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._works.append((b, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
 

@@ -61,7 +61,8 @@ def _worker(rank, world, port, out_dir):
         loss = ((net(x[shard]) - y[shard]) ** 2).mean()
         loss.backward()
         buckets.finish()
-    assert net.body[0].weight.grad.data_ptr() >= buckets.buckets[-1][0].data_ptr()  # gradients live inside the buckets
+    flat = buckets.buckets[buckets._where[net.body[0].weight]][0]
+    assert flat.data_ptr() <= net.body[0].weight.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4  # grad now lives in its bucket
     grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}
     torch.save(grads, os.path.join(out_dir, "grads_%d.pt" % rank))
     dist.destroy_process_group()
@@ -78,7 +79,7 @@ def test_bucketed_allreduce_matches_full_batch(tmp_path):
         got = torch.load(os.path.join(str(tmp_path), "grads_%d.pt" % rank))
         for k, g in want.items():
             if g is None:
-                assert got[k] is None or float(got[k].abs().max()) == 0.0  # gradient-less parameters hold zeros
+                assert got[k] is None
             else:
                 torch.testing.assert_close(got[k], g, rtol=1e-5, atol=1e-6)
 
