@@ -329,6 +329,22 @@ def gen_laplacian():
     save("laplacian", template=tmpl, faces=f.astype(np.int32), V=V, Lx=Lx, loss=loss.reshape(1), grad=grad)
 
 
+def gen_zimeval():
+    from mano_train.evaluation.zimeval import EvalUtil
+
+    rng = np.random.RandomState(71)
+    gt = rng.normal(0, 40, size=(12, 21, 3)).astype(np.float32)
+    pred = (gt + rng.normal(0, 12, size=gt.shape)).astype(np.float32)
+    vis = rng.uniform(size=(12, 21)) > 0.2
+    vis[:, 5] = False  # a keypoint that is never visible
+    ev = EvalUtil()
+    for g, p, v in zip(gt, pred, vis):
+        ev.feed(torch.from_numpy(g), torch.from_numpy(p), keypoint_vis=v)
+    epe_mean, epe_joint, epe_median, auc, curve, thr = ev.get_measures(0, 50, 20)
+    save("zimeval", gt=gt, pred=pred, vis=vis, epe_mean=epe_mean, epe_joint=np.array(epe_joint), epe_median=epe_median, auc=auc,
+         curve=curve, thresholds=thr)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     install_shims()
@@ -340,3 +356,4 @@ if __name__ == "__main__":
     gen_manobranch()
     gen_handnet()
     gen_laplacian()
+    gen_zimeval()

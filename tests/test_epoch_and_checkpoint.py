@@ -21,7 +21,8 @@ def test_epoch_pass_trains_and_averages(golden, monkeypatch):
     loader = [fixture_sample(g) for _ in range(3)]
     before = model.mano_branch.pose_reg.weight.detach().clone()
     meters, pck = epoch_pass(loader, model, epoch=0, optimizer=opt, train=True, freeze_batchnorm=True)
-    assert pck == {}
+    assert set(pck) == {"auc", "thres", "pck_curve", "epe_mean", "epe_median", "evaluator"}
+    assert pck["pck_curve"].shape == (20,) and 0.0 <= pck["auc"] <= 1.0 and pck["epe_mean"] > 0
     assert not model.training  # freeze_batchnorm => eval-mode BN during training (epochpass3d.py:48-52)
     assert not torch.equal(before, model.mano_branch.pose_reg.weight)
     am = meters.average_meters
@@ -68,3 +69,40 @@ def test_checkpoint_roundtrip_and_reference_layout(golden, monkeypatch, tmp_path
     torch.testing.assert_close(fresh.mano_branch.pose_reg.bias, model.mano_branch.pose_reg.bias + 1.0)
     with pytest.raises(ValueError):
         modelio.load_checkpoint(fresh, os.path.join(str(tmp_path), "nope.pth.tar"))
+
+
+def test_evalutil_matches_reference_golden(golden):
+    from obman_train_amd.evaluation.zimeval import EvalUtil
+
+    g = golden("zimeval")
+    a, b = EvalUtil(), EvalUtil()
+    for gt, pred, vis in zip(g["gt"], g["pred"], g["vis"]):
+        a.feed(torch.from_numpy(gt), torch.from_numpy(pred), keypoint_vis=vis)            # the reference's per-sample API
+    b.feed_batch(np.sqrt(((g["gt"] - g["pred"]) ** 2).sum(2)), g["vis"])                   # batched distances
+    for ev in (a, b):
+        epe_mean, epe_joint, epe_median, auc, curve, thr = ev.get_measures(0, 50, 20)
+        np.testing.assert_allclose(epe_mean, g["epe_mean"], rtol=1e-6)
+        np.testing.assert_allclose(np.array(epe_joint), g["epe_joint"], rtol=1e-6)
+        np.testing.assert_allclose(epe_median, g["epe_median"], rtol=1e-6)
+        np.testing.assert_allclose(auc, g["auc"], rtol=1e-9)
+        np.testing.assert_allclose(curve, g["curve"], rtol=1e-9)
+        np.testing.assert_allclose(thr, g["thresholds"])
+    assert len(a.data[5]) == 0 and len(a.data[0]) == int(g["vis"][:, 0].sum())
+
+
+def test_save_results_writes_reference_layout(golden, monkeypatch, tmp_path):
+    fake_ops.install(monkeypatch)
+    from obman_train_amd.netscripts import savemano
+    from obman_train_amd.netscripts.epochpass3d import epoch_pass
+
+    g = golden("handnet_eval")
+    model, _ = build_fixture_model(g, monkeypatch, train_mode=False)
+    epoch_pass([fixture_sample(g)], model, epoch=3, train=False, save_results=True, save_path=str(tmp_path))
+    path = os.path.join(str(tmp_path), "save_results", "val", "epoch_3", "batch_000000.pkl")
+    data = savemano.load_batch(path)
+    assert set(data) == {"sample", "results"}
+    # what the reference's load_batch_info reads (savemano.py:13-17)
+    assert data["results"]["verts"].shape == (3, 778, 3) and isinstance(data["results"]["verts"], np.ndarray)
+    assert data["results"]["objfaces"].shape == (320, 3)
+    assert data["results"]["contact_info"]["repulsion_masks"].shape == (3, 778)
+    assert data["sample"]["sides"] == ["left", "left", "right"] and "images" in data["sample"]
