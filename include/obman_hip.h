@@ -75,10 +75,12 @@ int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const 
                        float* verts, float* joints, float* state, obman_stream_t stream);
 
 /* Backward: g_verts [B,778,3] / g_joints [B,21,3] (either NULL = zeros) -> g_pose [B,npose],
- * g_betas [B,10] (NULL = not wanted).  Deterministic (fixed reduction trees, no atomics). */
+ * g_betas [B,10] (NULL = not wanted).  scratch: obman_mano_bwd_scratch_floats(B) floats (per-tile partial sums).
+ * Deterministic (fixed reduction trees, no atomics). */
+int obman_mano_bwd_scratch_floats(int B);
 int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const int* side, const float* state,
                        const float* g_verts, const float* g_joints, int B, int ncomps, int use_pca, int center_idx,
-                       int root_palm, float* g_pose, float* g_betas, obman_stream_t stream);
+                       int root_palm, float* g_pose, float* g_betas, float* scratch, obman_stream_t stream);
 
 /* ---- K4: ray-parity inside test -----------------------------------------------------------------
  * Replaces batch_mesh_contains_points (contactutils.py:62-159) + the obj_verts[:, faces] gather

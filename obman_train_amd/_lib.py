@@ -39,7 +39,8 @@ _SIGNATURES = {
     "obman_mano_model_floats": (_c_int, ""),
     "obman_mano_state_floats": (_c_int, ""),
     "obman_mano_lbs_fwd": (_c_int, "ppppp" "iiiii" "ppp" "p"),
-    "obman_mano_lbs_bwd": (_c_int, "pppppp" "iiiii" "pp" "p"),
+    "obman_mano_bwd_scratch_floats": (_c_int, "i"),
+    "obman_mano_lbs_bwd": (_c_int, "pppppp" "iiiii" "ppp" "p"),
 }
 _KIND = {"p": _c_void_p, "i": _c_int, "l": _c_long, "f": _c_float}
 _lib = None

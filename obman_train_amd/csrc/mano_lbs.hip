@@ -1,4 +1,4 @@
-// K7 - MANO linear-blend skinning, forward + hand-written backward, one workgroup per sample (gfx950).
+// K7 - MANO linear-blend skinning, forward + hand-written backward, four vertex-tile workgroups per sample (gfx950).
 //
 // Replaces the external manopth.ManoLayer the reference calls at manobranch.py:92-105,170-182
 // (a chain of ~60 small torch ops: launch-latency bound on a GPU) with ONE fused kernel per
@@ -16,8 +16,6 @@
 namespace {
 
 constexpr int NV = 778, NE = 2334, NJ = 16, NPM = 135;
-constexpr int MT = 1024;            // threads per block (16 waves): one sample per block, 4x the loads in flight of a 256-thread block
-constexpr int MW = MT / 64;
 // model blob layout (float offsets) - mirrored by obman_train_amd/mano_model.py
 constexpr int OFF_COMPS = 0;                  // [45][45] PCA basis rows
 constexpr int OFF_MEAN = OFF_COMPS + 2025;    // [45]
@@ -85,19 +83,22 @@ __device__ __forceinline__ void rodrigues_bwd(const float* a, const float* G, fl
   ga[2] = gnz * inv + gtheta * sz * inv;
 }
 
-__global__ __launch_bounds__(MT) void mano_fwd_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
-                                                       const int* __restrict__ side, const float* __restrict__ pose,
-                                                       const float* __restrict__ betas, int npose, int ncomps, int use_pca,
-                                                       int center_idx, int root_palm, float* __restrict__ verts,
-                                                       float* __restrict__ joints, float* __restrict__ state) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* __restrict__ M = (side && side[b]) ? m_left : m_right;
-  __shared__ float s_aa[48], s_beta[10], s_R[144], s_pm[NPM + 1], s_J[48], s_GR[144], s_Gt[48], s_trel[48];
-  __shared__ float s_vp[NE];   // posed rest shape, overwritten in place by the skinned vertices
-  __shared__ float s_jc[63];   // 16 chain joints + 5 tips (un-reordered), then centre
-  const float* p = pose + (size_t)b * npose;
+constexpr int NTILE = 4, TILE_V = 195, FT = 256;   // 4 vertex tiles x 195 vertices (last one 193), 256 threads per block
+constexpr int LIST_V = TILE_V + 7;                   // tile + 5 fingertips + 2 palm vertices
+constexpr int PART = 400;                            // per (sample, tile) backward partials: 192 joint sums | 145 rows | 48 joint grads
 
-  if (tid < 10) s_beta[tid] = betas ? betas[(size_t)b * 10 + tid] : 0.f;
+__device__ __forceinline__ bool center_needs_verts(int center_idx, int root_palm) {
+  if (center_idx < 0) return false;
+  const int src = c_reorder[center_idx];
+  return src >= 16 || (root_palm && src == 0);
+}
+
+// Pose phase shared by every block of a sample: PCA -> axis-angle -> rotations, joints, kinematic chain, rest-pose removal.
+// (A few hundred flops; recomputed per vertex tile instead of a second launch.)  Ends with a barrier.
+__device__ __forceinline__ void mano_pose_phase(const float* __restrict__ M, const float* __restrict__ p, const float* __restrict__ betas_b,
+                                                int ncomps, int use_pca, int tid, float* s_aa, float* s_beta, float* s_R, float* s_pm,
+                                                float* s_J, float* s_GR, float* s_Gt, float* s_trel) {
+  if (tid < 10) s_beta[tid] = betas_b ? betas_b[tid] : 0.f;
   if (tid >= 64 && tid < 67) s_aa[tid - 64] = p[tid - 64];
   if (tid >= 128 && tid < 173) {
     const int m = tid - 128;
@@ -127,8 +128,7 @@ __global__ __launch_bounds__(MT) void mano_fwd_kernel(const float* __restrict__ 
     s_J[e] = j;
   }
   __syncthreads();
-  // kinematic chain: lanes 0..4 walk one finger each (3 joints), lane 5 writes the root
-  if (tid < 5) {
+  if (tid < 5) {  // one finger per lane, 3 joints each
     float Rp[9], tp[3], Jp[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rp[k] = s_R[k];
@@ -153,21 +153,6 @@ __global__ __launch_bounds__(MT) void mano_fwd_kernel(const float* __restrict__ 
     for (int k = 0; k < 9; ++k) s_GR[k] = s_R[k];
     for (int k = 0; k < 3; ++k) s_Gt[k] = s_J[k];
   }
-  // blend shapes: v_posed[e] = T[e] + sum_k S[k][e] beta[k] + sum_k P[k][e] pose_map[k]
-  for (int e = tid; e < NE; e += MT) {
-    float acc = M[OFF_VT + e];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) acc = __fmaf_rn(M[OFF_SD + k * NE + e], s_beta[k], acc);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    const float* pd = M + OFF_PD + e;
-#pragma unroll 9
-    for (int k = 0; k < NPM; k += 3) {
-      a0 = __fmaf_rn(pd[(size_t)k * NE], s_pm[k], a0);
-      a1 = __fmaf_rn(pd[(size_t)(k + 1) * NE], s_pm[k + 1], a1);
-      a2 = __fmaf_rn(pd[(size_t)(k + 2) * NE], s_pm[k + 2], a2);
-    }
-    s_vp[e] = acc + (a0 + a1 + a2);
-  }
   __syncthreads();
   if (tid < NJ) {
 #pragma unroll
@@ -175,15 +160,57 @@ __global__ __launch_bounds__(MT) void mano_fwd_kernel(const float* __restrict__ 
       s_trel[tid * 3 + r] = s_Gt[tid * 3 + r] - (s_GR[tid * 9 + r * 3] * s_J[tid * 3] + s_GR[tid * 9 + r * 3 + 1] * s_J[tid * 3 + 1] +
                                                  s_GR[tid * 9 + r * 3 + 2] * s_J[tid * 3 + 2]);
   }
-  if (state) {
-    float* st = state + (size_t)b * OBMAN_MANO_STATE_FLOATS;
-    for (int k = tid; k < 144; k += MT) { st[S_R + k] = s_R[k]; st[S_GR + k] = s_GR[k]; }
-    if (tid < 48) { st[S_J + tid] = s_J[tid]; st[S_GT + tid] = s_Gt[tid]; st[S_AA + tid] = s_aa[tid]; }
-    for (int e = tid; e < NE; e += MT) st[S_VP + e] = s_vp[e];
+  __syncthreads();
+}
+
+// Forward: grid (NTILE, B).  Each block blends + skins its 195 vertices (the 1.26 MB pose basis of a sample is read by 4 CUs
+// instead of one); block 0 of a sample additionally evaluates the 7 special vertices and writes the joints.
+__global__ __launch_bounds__(FT) void mano_fwd_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
+                                                       const int* __restrict__ side, const float* __restrict__ pose,
+                                                       const float* __restrict__ betas, int npose, int ncomps, int use_pca,
+                                                       int center_idx, int root_palm, float* __restrict__ verts,
+                                                       float* __restrict__ joints, float* __restrict__ state) {
+  const int vt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* __restrict__ M = (side && side[b]) ? m_left : m_right;
+  __shared__ float s_aa[48], s_beta[10], s_R[144], s_pm[NPM + 1], s_J[48], s_GR[144], s_Gt[48], s_trel[48];
+  __shared__ float s_vp[LIST_V * 3];  // posed rest shape of the block's vertex list, overwritten by the skinned vertices
+  __shared__ int s_vl[LIST_V];
+  __shared__ float s_jc[63];
+  const int v0 = vt * TILE_V, nv = min(NV, v0 + TILE_V) - v0;
+  const bool spec = vt == 0 || center_needs_verts(center_idx, root_palm);
+  const int nl = nv + (spec ? 7 : 0);
+  if (tid < nv) s_vl[tid] = v0 + tid;
+  if (spec && tid < 7) s_vl[nv + tid] = tid < 5 ? (int)M[OFF_TIPS + tid] : (int)M[OFF_PALM + tid - 5];
+  mano_pose_phase(M, pose + (size_t)b * npose, betas ? betas + (size_t)b * 10 : nullptr, ncomps, use_pca, tid, s_aa, s_beta, s_R, s_pm,
+                  s_J, s_GR, s_Gt, s_trel);
+  // blend shapes: v_posed[e] = T[e] + sum_k S[k][e] beta[k] + sum_k P[k][e] pose_map[k]
+  for (int i = tid; i < nl * 3; i += FT) {
+    const int e = s_vl[i / 3] * 3 + i % 3;
+    float acc = M[OFF_VT + e];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc = __fmaf_rn(M[OFF_SD + k * NE + e], s_beta[k], acc);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float* pd = M + OFF_PD + e;
+#pragma unroll 15
+    for (int k = 0; k < NPM; k += 3) {
+      a0 = __fmaf_rn(pd[(size_t)k * NE], s_pm[k], a0);
+      a1 = __fmaf_rn(pd[(size_t)(k + 1) * NE], s_pm[k + 1], a1);
+      a2 = __fmaf_rn(pd[(size_t)(k + 2) * NE], s_pm[k + 2], a2);
+    }
+    s_vp[i] = acc + (a0 + a1 + a2);
   }
   __syncthreads();
-  // skinning: one vertex per lane
-  for (int v = tid; v < NV; v += MT) {
+  if (state) {
+    float* st = state + (size_t)b * OBMAN_MANO_STATE_FLOATS;
+    if (vt == 0) {
+      for (int k = tid; k < 144; k += FT) { st[S_R + k] = s_R[k]; st[S_GR + k] = s_GR[k]; }
+      if (tid < 48) { st[S_J + tid] = s_J[tid]; st[S_GT + tid] = s_Gt[tid]; st[S_AA + tid] = s_aa[tid]; }
+    }
+    for (int i = tid; i < nv * 3; i += FT) st[S_VP + v0 * 3 + i] = s_vp[i];
+  }
+  __syncthreads();
+  if (tid < nl) {  // skinning: one vertex per lane
+    const int v = s_vl[tid];
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = 0.f;
@@ -195,24 +222,20 @@ __global__ __launch_bounds__(MT) void mano_fwd_kernel(const float* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 3; ++k) T[9 + k] = __fmaf_rn(w, s_trel[i * 3 + k], T[9 + k]);
     }
-    const float x = s_vp[v * 3], y = s_vp[v * 3 + 1], z = s_vp[v * 3 + 2];
-    const float ox = T[0] * x + T[1] * y + T[2] * z + T[9];
-    const float oy = T[3] * x + T[4] * y + T[5] * z + T[10];
-    const float oz = T[6] * x + T[7] * y + T[8] * z + T[11];
-    s_vp[v * 3] = ox; s_vp[v * 3 + 1] = oy; s_vp[v * 3 + 2] = oz;
+    const float x = s_vp[tid * 3], y = s_vp[tid * 3 + 1], z = s_vp[tid * 3 + 2];
+    s_vp[tid * 3] = T[0] * x + T[1] * y + T[2] * z + T[9];
+    s_vp[tid * 3 + 1] = T[3] * x + T[4] * y + T[5] * z + T[10];
+    s_vp[tid * 3 + 2] = T[6] * x + T[7] * y + T[8] * z + T[11];
   }
   __syncthreads();
-  if (tid < 63) {
+  if (tid < 63) {  // un-reordered joints: 16 chain joints (or the palm point) + 5 fingertip vertices
     const int j = tid / 3, c = tid % 3;
-    float val;
+    float val = 0.f;
     if (j < 16) {
       val = s_Gt[j * 3 + c];
-      if (j == 0 && root_palm) {
-        const int p0 = (int)M[OFF_PALM], p1 = (int)M[OFF_PALM + 1];
-        val = (s_vp[p0 * 3 + c] + s_vp[p1 * 3 + c]) * 0.5f;
-      }
-    } else {
-      val = s_vp[(int)M[OFF_TIPS + j - 16] * 3 + c];
+      if (j == 0 && root_palm && spec) val = (s_vp[(nv + 5) * 3 + c] + s_vp[(nv + 6) * 3 + c]) * 0.5f;
+    } else if (spec) {
+      val = s_vp[(nv + j - 16) * 3 + c];
     }
     s_jc[tid] = val;
   }
@@ -222,57 +245,53 @@ __global__ __launch_bounds__(MT) void mano_fwd_kernel(const float* __restrict__ 
     const int src = c_reorder[center_idx];
     cx = s_jc[src * 3]; cy = s_jc[src * 3 + 1]; cz = s_jc[src * 3 + 2];
   }
-  float* vo = verts + (size_t)b * NE;
-  for (int e = tid; e < NE; e += MT) {
-    const int c = e % 3;
-    vo[e] = (s_vp[e] - (c == 0 ? cx : (c == 1 ? cy : cz))) * 1000.f;
+  float* vo = verts + (size_t)b * NE + v0 * 3;
+  for (int i = tid; i < nv * 3; i += FT) {
+    const int c = i % 3;
+    vo[i] = (s_vp[i] - (c == 0 ? cx : (c == 1 ? cy : cz))) * 1000.f;
   }
-  if (tid < 63) {
+  if (vt == 0 && tid < 63) {
     const int j = tid / 3, c = tid % 3;
     joints[(size_t)b * 63 + tid] = (s_jc[c_reorder[j] * 3 + c] - (c == 0 ? cx : (c == 1 ? cy : cz))) * 1000.f;
   }
 }
 
-__global__ __launch_bounds__(MT) void mano_bwd_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
-                                                       const int* __restrict__ side, const float* __restrict__ state,
-                                                       const float* __restrict__ g_verts, const float* __restrict__ g_joints,
-                                                       int npose, int ncomps, int use_pca, int center_idx, int root_palm,
-                                                       float* __restrict__ g_pose, float* __restrict__ g_betas) {
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Backward, part 1: grid (NTILE, B).  Per vertex tile: skinning backward (gradient of the posed rest shape + partial sums of the
+// 16 joint-transform gradients) and the tile's share of d/d(pose_map), d/d(beta).  Partials -> part[b][tile][PART].
+__global__ __launch_bounds__(FT) void mano_bwd_tile_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
+                                                           const int* __restrict__ side, const float* __restrict__ state,
+                                                           const float* __restrict__ g_verts, const float* __restrict__ g_joints,
+                                                           int center_idx, int root_palm, float* __restrict__ part) {
+  const int vt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ M = (side && side[b]) ? m_left : m_right;
   const float* __restrict__ st = state + (size_t)b * OBMAN_MANO_STATE_FLOATS;
-  __shared__ float s_R[144], s_J[48], s_GR[144], s_Gt[48], s_aa[48];
-  __shared__ float s_vp[NE], s_gv[NE];          // posed rest shape; grads of skinned verts, later of v_posed
-  __shared__ float s_gj[63], s_cat[63];         // joint grads (21-order) and un-reordered
-  __shared__ float s_red[MW][4];                 // centre reduction
-  __shared__ float s_part[MW][NJ][12];           // per-wave partial joint-transform grads
-  __shared__ float s_gGR[144], s_gGt[48], s_gtrel[48], s_gJ[48], s_gR[144];
-  __shared__ float s_root[5][16];               // per-finger contributions to the root (9 + 3 + 3)
-  __shared__ float s_gpm[NPM + 10], s_gaa[48];
-
-  for (int k = tid; k < 144; k += MT) { s_R[k] = st[S_R + k]; s_GR[k] = st[S_GR + k]; }
-  if (tid < 48) { s_J[tid] = st[S_J + tid]; s_Gt[tid] = st[S_GT + tid]; s_aa[tid] = st[S_AA + tid]; }
-  for (int e = tid; e < NE; e += MT) s_vp[e] = st[S_VP + e];
-  // phase 0: scale, centre
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int v = tid; v < NV; v += MT) {
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    if (g_verts) {
-      const float* g = g_verts + (size_t)b * NE + v * 3;
-      gx = g[0] * 1000.f; gy = g[1] * 1000.f; gz = g[2] * 1000.f;
-    }
-    s_gv[v * 3] = gx; s_gv[v * 3 + 1] = gy; s_gv[v * 3 + 2] = gz;
-    sx += gx; sy += gy; sz += gz;
+  float* __restrict__ out = part + ((size_t)b * NTILE + vt) * PART;
+  __shared__ float s_GR[144];
+  __shared__ float s_vp[TILE_V * 3], s_gv[TILE_V * 3];
+  __shared__ float s_gj[63], s_cat[63], s_red[4][4];
+  __shared__ float s_part[4][NJ][12];
+  const int v0 = vt * TILE_V, nv = min(NV, v0 + TILE_V) - v0;
+  for (int k = tid; k < 144; k += FT) s_GR[k] = st[S_GR + k];
+  for (int i = tid; i < nv * 3; i += FT) {
+    s_vp[i] = st[S_VP + v0 * 3 + i];
+    s_gv[i] = g_verts ? g_verts[(size_t)b * NE + v0 * 3 + i] * 1000.f : 0.f;
   }
-  sx = obman_wave_sum(sx); sy = obman_wave_sum(sy); sz = obman_wave_sum(sz);
+  // the centring term needs the gradient sum over ALL vertices of the sample (every tile recomputes it: 9 loads / lane)
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (g_verts) {
+    for (int v = tid; v < NV; v += FT) {
+      const float* g = g_verts + (size_t)b * NE + v * 3;
+      sx += g[0]; sy += g[1]; sz += g[2];
+    }
+  }
+  sx = obman_wave_sum(sx) * 1000.f; sy = obman_wave_sum(sy) * 1000.f; sz = obman_wave_sum(sz) * 1000.f;
   if (lane == 0) { s_red[wave][0] = sx; s_red[wave][1] = sy; s_red[wave][2] = sz; }
   if (tid < 63) s_gj[tid] = g_joints ? g_joints[(size_t)b * 63 + tid] * 1000.f : 0.f;
   __syncthreads();
   if (tid == 0) {
     if (center_idx >= 0) {
       for (int c = 0; c < 3; ++c) {
-        float tot = 0.f;
-        for (int w = 0; w < MW; ++w) tot += s_red[w][c];
+        float tot = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
         for (int j = 0; j < 21; ++j) tot += s_gj[j * 3 + c];
         s_gj[center_idx * 3 + c] -= tot;
       }
@@ -280,52 +299,88 @@ __global__ __launch_bounds__(MT) void mano_bwd_kernel(const float* __restrict__ 
     for (int j = 0; j < 21; ++j)
       for (int c = 0; c < 3; ++c) s_cat[c_reorder[j] * 3 + c] = s_gj[j * 3 + c];
     if (root_palm) {
-      const int p0 = (int)M[OFF_PALM], p1 = (int)M[OFF_PALM + 1];
-      for (int c = 0; c < 3; ++c) {
-        const float g = 0.5f * s_cat[c];
-        s_gv[p0 * 3 + c] += g;
-        s_gv[p1 * 3 + c] += g;
-        s_cat[c] = 0.f;
+      for (int q = 0; q < 2; ++q) {
+        const int v = (int)M[OFF_PALM + q] - v0;
+        if (v >= 0 && v < nv)
+          for (int c = 0; c < 3; ++c) s_gv[v * 3 + c] += 0.5f * s_cat[c];
       }
+      for (int c = 0; c < 3; ++c) s_cat[c] = 0.f;
     }
     for (int t = 0; t < 5; ++t) {
-      const int v = (int)M[OFF_TIPS + t];
-      for (int c = 0; c < 3; ++c) s_gv[v * 3 + c] += s_cat[(16 + t) * 3 + c];
+      const int v = (int)M[OFF_TIPS + t] - v0;
+      if (v >= 0 && v < nv)
+        for (int c = 0; c < 3; ++c) s_gv[v * 3 + c] += s_cat[(16 + t) * 3 + c];
     }
-    for (int k = 0; k < 48; ++k) s_gGt[k] = s_cat[k];
   }
   __syncthreads();
-  // phase 2: skinning backward.  verts[v] = sum_i w_vi (GR_i vp_v + trel_i)
-  static_assert(MT >= NV, "one vertex per lane");
-  const bool vok = tid < NV;
+  if (vt == 0 && tid < 48) out[337 + tid] = s_cat[tid];  // d/d(chain joint translations), consumed by the chain kernel
+  // skinning backward.  verts[v] = sum_i w_vi (GR_i vp_v + trel_i)
+  const bool vok = tid < nv;
   const float gvx = vok ? s_gv[tid * 3] : 0.f, gvy = vok ? s_gv[tid * 3 + 1] : 0.f, gvz = vok ? s_gv[tid * 3 + 2] : 0.f;
   const float px = vok ? s_vp[tid * 3] : 0.f, py = vok ? s_vp[tid * 3 + 1] : 0.f, pz = vok ? s_vp[tid * 3 + 2] : 0.f;
-  __syncthreads();  // every lane has its s_gv in registers: s_gv can now receive d(loss)/d(v_posed)
+  __syncthreads();  // every lane holds its s_gv in registers: s_gv now receives d(loss)/d(v_posed)
   float gpx = 0.f, gpy = 0.f, gpz = 0.f;
 #pragma unroll 4
   for (int i = 0; i < NJ; ++i) {
     const float* G = &s_GR[i * 9];
-    const float wji = vok ? M[OFF_W + i * NV + tid] : 0.f;
+    const float wji = vok ? M[OFF_W + i * NV + v0 + tid] : 0.f;
     const float wx = wji * gvx, wy = wji * gvy, wz = wji * gvz;
     float acc[12] = {wx * px, wx * py, wx * pz, wy * px, wy * py, wy * pz, wz * px, wz * py, wz * pz, wx, wy, wz};
-    gpx += G[0] * wx + G[3] * wy + G[6] * wz;  // d/d(v_posed) = sum_i w GR_i^T gv
+    gpx += G[0] * wx + G[3] * wy + G[6] * wz;
     gpy += G[1] * wx + G[4] * wy + G[7] * wz;
     gpz += G[2] * wx + G[5] * wy + G[8] * wz;
-    if (wave < (NV + 63) / 64) {  // waves beyond the last vertex contribute zeros
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        const float r = obman_wave_sum(acc[k]);
-        if (lane == 0) s_part[wave][i][k] = r;
-      }
+    for (int k = 0; k < 12; ++k) {
+      const float r = obman_wave_sum(acc[k]);
+      if (lane == 0) s_part[wave][i][k] = r;
     }
   }
   if (vok) { s_gv[tid * 3] = gpx; s_gv[tid * 3 + 1] = gpy; s_gv[tid * 3 + 2] = gpz; }
   __syncthreads();
   if (tid < NJ * 12) {
     const int i = tid / 12, k = tid % 12;
-    float r = 0.f;
-    for (int w = 0; w < (NV + 63) / 64; ++w) r += s_part[w][i][k];
-    if (k < 9) s_gGR[i * 9 + k] = r; else s_gtrel[i * 3 + k - 9] = r;
+    out[tid] = (s_part[0][i][k] + s_part[1][i][k]) + (s_part[2][i][k] + s_part[3][i][k]);
+  }
+  // the tile's share of <P[k], g_vp> (k < 135) and <S[k], g_vp> (10 shape rows): one row per wave pass, lanes over the tile
+  const int ne = nv * 3;
+  for (int row = wave; row < NPM + 10; row += 4) {
+    const float* basis = (row < NPM ? M + OFF_PD + (size_t)row * NE : M + OFF_SD + (size_t)(row - NPM) * NE) + v0 * 3;
+    float a0 = 0.f, a1 = 0.f;
+    int e = lane;
+    for (; e + 64 < ne; e += 128) {
+      a0 = __fmaf_rn(basis[e], s_gv[e], a0);
+      a1 = __fmaf_rn(basis[e + 64], s_gv[e + 64], a1);
+    }
+    if (e < ne) a0 = __fmaf_rn(basis[e], s_gv[e], a0);
+    const float r = obman_wave_sum(a0 + a1);
+    if (lane == 0) out[192 + row] = r;
+  }
+}
+
+// Backward, part 2: grid (B), 64 threads.  Sums the tile partials, then the serial part: rest-pose removal, kinematic chain,
+// Rodrigues and PCA backward.
+__global__ __launch_bounds__(64) void mano_bwd_chain_kernel(const float* __restrict__ m_right, const float* __restrict__ m_left,
+                                                            const int* __restrict__ side, const float* __restrict__ state,
+                                                            const float* __restrict__ part, int npose, int ncomps, int use_pca,
+                                                            float* __restrict__ g_pose, float* __restrict__ g_betas) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* __restrict__ M = (side && side[b]) ? m_left : m_right;
+  const float* __restrict__ st = state + (size_t)b * OBMAN_MANO_STATE_FLOATS;
+  const float* __restrict__ pb = part + (size_t)b * NTILE * PART;
+  __shared__ float s_R[144], s_J[48], s_GR[144], s_aa[48];
+  __shared__ float s_gGR[144], s_gGt[48], s_gtrel[48], s_gJ[48], s_gR[144];
+  __shared__ float s_root[5][16];
+  __shared__ float s_gpm[NPM + 10], s_gaa[48];
+  for (int k = tid; k < 144; k += 64) { s_R[k] = st[S_R + k]; s_GR[k] = st[S_GR + k]; }
+  if (tid < 48) { s_J[tid] = st[S_J + tid]; s_aa[tid] = st[S_AA + tid]; s_gGt[tid] = pb[337 + tid]; }
+  for (int k = tid; k < 192 + NPM + 10; k += 64) {
+    const float r = (pb[k] + pb[PART + k]) + (pb[2 * PART + k] + pb[3 * PART + k]);
+    if (k < 192) {
+      const int i = k / 12, q = k % 12;
+      if (q < 9) s_gGR[i * 9 + q] = r; else s_gtrel[i * 3 + q - 9] = r;
+    } else {
+      s_gpm[k - 192] = r;
+    }
   }
   __syncthreads();
   // phase 4: trel_i = Gt_i - GR_i J_i
@@ -400,19 +455,6 @@ __global__ __launch_bounds__(MT) void mano_bwd_kernel(const float* __restrict__ 
   }
   __syncthreads();
   if (tid < 3) s_gJ[tid] += s_gGt[tid];
-  // phase 6: d/d(pose_map[k]) = <P[k], g_vp>, d/d(beta[k]) = <S[k], g_vp> (+ joint path): one row per wave pass
-  for (int row = wave; row < NPM + 10; row += MW) {
-    const float* basis = row < NPM ? M + OFF_PD + (size_t)row * NE : M + OFF_SD + (size_t)(row - NPM) * NE;
-    float a0 = 0.f, a1 = 0.f;
-    int e = lane;
-    for (; e + 64 < NE; e += 128) {
-      a0 = __fmaf_rn(basis[e], s_gv[e], a0);
-      a1 = __fmaf_rn(basis[e + 64], s_gv[e + 64], a1);
-    }
-    if (e < NE) a0 = __fmaf_rn(basis[e], s_gv[e], a0);
-    const float r = obman_wave_sum(a0 + a1);
-    if (lane == 0) s_gpm[row] = r;
-  }
   __syncthreads();
   if (g_betas && tid < 10) {
     float g = s_gpm[NPM + tid];
@@ -420,8 +462,8 @@ __global__ __launch_bounds__(MT) void mano_bwd_kernel(const float* __restrict__ 
     g_betas[(size_t)b * 10 + tid] = g;
   }
   // phase 7: Rodrigues backward
-  if (tid >= 64 && tid < 64 + NJ) {
-    const int i = tid - 64;
+  if (tid >= 32 && tid < 32 + NJ) {
+    const int i = tid - 32;
     float G[9], ga[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) G[k] = s_gR[i * 9 + k] + (i > 0 ? s_gpm[(i - 1) * 9 + k] : 0.f);
@@ -432,14 +474,13 @@ __global__ __launch_bounds__(MT) void mano_bwd_kernel(const float* __restrict__ 
   float* gp = g_pose + (size_t)b * npose;
   if (tid < 3) gp[tid] = s_gaa[tid];
   if (use_pca) {
-    if (tid >= 64 && tid < 64 + ncomps) {
-      const int k = tid - 64;
+    for (int k = tid; k < ncomps; k += 64) {
       float g = 0.f;
       for (int m = 0; m < 45; ++m) g = __fmaf_rn(M[OFF_COMPS + k * 45 + m], s_gaa[3 + m], g);
       gp[3 + k] = g;
     }
-  } else if (tid >= 64 && tid < 64 + 45) {
-    gp[3 + tid - 64] = s_gaa[3 + tid - 64];
+  } else if (tid < 45) {
+    gp[3 + tid] = s_gaa[3 + tid];
   }
 }
 
@@ -460,7 +501,7 @@ int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const 
   if (B == 0) return 0;
   const int npose = 3 + (use_pca ? ncomps : 45);
   ObmanProfScope prof(OBMAN_K_MANO_FWD, (hipStream_t)stream);
-  mano_fwd_kernel<<<B, MT, 0, (hipStream_t)stream>>>(model_right, model_left, side, pose, betas, npose, ncomps, use_pca,
+  mano_fwd_kernel<<<dim3(NTILE, B), FT, 0, (hipStream_t)stream>>>(model_right, model_left, side, pose, betas, npose, ncomps, use_pca,
                                                        center_idx, root_palm, verts, joints, state);
   OBMAN_LAUNCH_CHECK();
   return 0;
@@ -468,17 +509,22 @@ int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const 
 
 int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const int* side, const float* state,
                        const float* g_verts, const float* g_joints, int B, int ncomps, int use_pca, int center_idx,
-                       int root_palm, float* g_pose, float* g_betas, obman_stream_t stream) {
-  if (B < 0 || !model_right || !state || !g_pose) return -1;
+                       int root_palm, float* g_pose, float* g_betas, float* scratch, obman_stream_t stream) {
+  if (B < 0 || !model_right || !state || !g_pose || !scratch) return -1;
   if (use_pca ? (ncomps < 0 || ncomps > 45) : 0) return -2;
   if (side && !model_left) return -4;
   if (B == 0) return 0;
   const int npose = 3 + (use_pca ? ncomps : 45);
-  ObmanProfScope prof(OBMAN_K_MANO_BWD, (hipStream_t)stream);
-  mano_bwd_kernel<<<B, MT, 0, (hipStream_t)stream>>>(model_right, model_left, side, state, g_verts, g_joints, npose, ncomps,
-                                                       use_pca, center_idx, root_palm, g_pose, g_betas);
+  hipStream_t st = (hipStream_t)stream;
+  ObmanProfScope prof(OBMAN_K_MANO_BWD, st);
+  mano_bwd_tile_kernel<<<dim3(NTILE, B), FT, 0, st>>>(model_right, model_left, side, state, g_verts, g_joints, center_idx, root_palm,
+                                                       scratch);
+  OBMAN_LAUNCH_CHECK();
+  mano_bwd_chain_kernel<<<B, 64, 0, st>>>(model_right, model_left, side, state, scratch, npose, ncomps, use_pca, g_pose, g_betas);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
+
+int obman_mano_bwd_scratch_floats(int B) { return B * NTILE * PART; }
 
 }  // extern "C"

@@ -168,9 +168,11 @@ class _ManoLBS(torch.autograd.Function):
         o = dict(device=state.device, dtype=torch.float32)
         g_pose = torch.empty((B, npose), **o)
         g_betas = torch.empty((B, 10), **o) if (has_betas and ctx.needs_input_grad[1]) else None
+        scratch = torch.empty(_lib.lib().obman_mano_bwd_scratch_floats(B), **o)
         _lib.check(_lib.lib().obman_mano_lbs_bwd(
             blob_right.data_ptr(), _ptr(blob_left), _ptr(side), state.data_ptr(), _ptr(g_verts), _ptr(g_joints), B,
-            ncomps, use_pca, cidx, root_palm, g_pose.data_ptr(), _ptr(g_betas), _stream()), "obman_mano_lbs_bwd")
+            ncomps, use_pca, cidx, root_palm, g_pose.data_ptr(), _ptr(g_betas), scratch.data_ptr(), _stream()),
+            "obman_mano_lbs_bwd")
         return g_pose, g_betas, None, None, None, None, None, None, None
 
 
