@@ -96,17 +96,32 @@ __device__ __forceinline__ bool center_needs_verts(int center_idx, int root_palm
 // Pose phase shared by every block of a sample: PCA -> axis-angle -> rotations, joints, kinematic chain, rest-pose removal.
 // (A few hundred flops; recomputed per vertex tile instead of a second launch.)  Ends with a barrier.
 __device__ __forceinline__ void mano_pose_phase(const float* __restrict__ M, const float* __restrict__ p, const float* __restrict__ betas_b,
-                                                int ncomps, int use_pca, int tid, float* s_aa, float* s_beta, float* s_R, float* s_pm,
-                                                float* s_J, float* s_GR, float* s_Gt, float* s_trel) {
+                                                int ncomps, int use_pca, int tid, int nthreads, float* s_aa, float* s_beta, float* s_R,
+                                                float* s_pm, float* s_J, float* s_GR, float* s_Gt, float* s_trel, float* s_tab) {
+  // Small model tables go through LDS first (one coalesced pass): a serial loop of dependent L2 loads (30 PCA steps) costs
+  // ~0.7 us per step otherwise.  s_tab: [ncomps*45 PCA rows | 48 pose coefficients]
+  const int npose = 3 + (use_pca ? ncomps : 45);
+  if (use_pca)
+    for (int i = tid; i < ncomps * 45; i += nthreads) s_tab[i] = M[OFF_COMPS + i];
+  for (int i = tid; i < npose; i += nthreads) s_tab[45 * 45 + i] = p[i];
   if (tid < 10) s_beta[tid] = betas_b ? betas_b[tid] : 0.f;
-  if (tid >= 64 && tid < 67) s_aa[tid - 64] = p[tid - 64];
-  if (tid >= 128 && tid < 173) {
-    const int m = tid - 128;
+  __syncthreads();
+  const float* sp = s_tab + 45 * 45;
+  if (tid < 3) s_aa[tid] = sp[tid];
+  if (tid >= 64 && tid < 109) {
+    const int m = tid - 64;
     float h = M[OFF_MEAN + m];
     if (use_pca) {
-      for (int k = 0; k < ncomps; ++k) h = __fmaf_rn(p[3 + k], M[OFF_COMPS + k * 45 + m], h);
+      float h1 = 0.f;
+      int k = 0;
+      for (; k + 1 < ncomps; k += 2) {
+        h = __fmaf_rn(sp[3 + k], s_tab[k * 45 + m], h);
+        h1 = __fmaf_rn(sp[4 + k], s_tab[(k + 1) * 45 + m], h1);
+      }
+      if (k < ncomps) h = __fmaf_rn(sp[3 + k], s_tab[k * 45 + m], h);
+      h += h1;
     } else {
-      h += p[3 + m];
+      h += sp[3 + m];
     }
     s_aa[3 + m] = h;
   }
@@ -122,9 +137,12 @@ __device__ __forceinline__ void mano_pose_phase(const float* __restrict__ M, con
   }
   if (tid >= 64 && tid < 112) {
     const int e = tid - 64;
+    float js[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) js[k] = M[OFF_JS + k * 48 + e];  // 10 independent loads
     float j = M[OFF_JT + e];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) j = __fmaf_rn(M[OFF_JS + k * 48 + e], s_beta[k], j);
+    for (int k = 0; k < 10; ++k) j = __fmaf_rn(js[k], s_beta[k], j);
     s_J[e] = j;
   }
   __syncthreads();
@@ -176,13 +194,14 @@ __global__ __launch_bounds__(FT) void mano_fwd_kernel(const float* __restrict__ 
   __shared__ float s_vp[LIST_V * 3];  // posed rest shape of the block's vertex list, overwritten by the skinned vertices
   __shared__ int s_vl[LIST_V];
   __shared__ float s_jc[63];
+  __shared__ float s_tab[45 * 45 + 48];
   const int v0 = vt * TILE_V, nv = min(NV, v0 + TILE_V) - v0;
   const bool spec = vt == 0 || center_needs_verts(center_idx, root_palm);
   const int nl = nv + (spec ? 7 : 0);
   if (tid < nv) s_vl[tid] = v0 + tid;
   if (spec && tid < 7) s_vl[nv + tid] = tid < 5 ? (int)M[OFF_TIPS + tid] : (int)M[OFF_PALM + tid - 5];
-  mano_pose_phase(M, pose + (size_t)b * npose, betas ? betas + (size_t)b * 10 : nullptr, ncomps, use_pca, tid, s_aa, s_beta, s_R, s_pm,
-                  s_J, s_GR, s_Gt, s_trel);
+  mano_pose_phase(M, pose + (size_t)b * npose, betas ? betas + (size_t)b * 10 : nullptr, ncomps, use_pca, tid, FT, s_aa, s_beta, s_R,
+                  s_pm, s_J, s_GR, s_Gt, s_trel, s_tab);
   // blend shapes: v_posed[e] = T[e] + sum_k S[k][e] beta[k] + sum_k P[k][e] pose_map[k]
   for (int i = tid; i < nl * 3; i += FT) {
     const int e = s_vl[i / 3] * 3 + i % 3;
@@ -371,6 +390,11 @@ __global__ __launch_bounds__(64) void mano_bwd_chain_kernel(const float* __restr
   __shared__ float s_gGR[144], s_gGt[48], s_gtrel[48], s_gJ[48], s_gR[144];
   __shared__ float s_root[5][16];
   __shared__ float s_gpm[NPM + 10], s_gaa[48];
+  __shared__ float s_comps[45 * 45], s_js[480];  // small model tables: staged once, coalesced (serial L2 loads are ~0.7 us each)
+  if (use_pca)
+    for (int i = tid; i < ncomps * 45; i += 64) s_comps[i] = M[OFF_COMPS + i];
+  if (g_betas)
+    for (int i = tid; i < 480; i += 64) s_js[i] = M[OFF_JS + i];
   for (int k = tid; k < 144; k += 64) { s_R[k] = st[S_R + k]; s_GR[k] = st[S_GR + k]; }
   if (tid < 48) { s_J[tid] = st[S_J + tid]; s_aa[tid] = st[S_AA + tid]; s_gGt[tid] = pb[337 + tid]; }
   for (int k = tid; k < 192 + NPM + 10; k += 64) {
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(64) void mano_bwd_chain_kernel(const float* __restr
   __syncthreads();
   if (g_betas && tid < 10) {
     float g = s_gpm[NPM + tid];
-    for (int e = 0; e < 48; ++e) g = __fmaf_rn(M[OFF_JS + tid * 48 + e], s_gJ[e], g);
+    for (int e = 0; e < 48; ++e) g = __fmaf_rn(s_js[tid * 48 + e], s_gJ[e], g);
     g_betas[(size_t)b * 10 + tid] = g;
   }
   // phase 7: Rodrigues backward
@@ -476,7 +500,7 @@ __global__ __launch_bounds__(64) void mano_bwd_chain_kernel(const float* __restr
   if (use_pca) {
     for (int k = tid; k < ncomps; k += 64) {
       float g = 0.f;
-      for (int m = 0; m < 45; ++m) g = __fmaf_rn(M[OFF_COMPS + k * 45 + m], s_gaa[3 + m], g);
+      for (int m = 0; m < 45; ++m) g = __fmaf_rn(s_comps[k * 45 + m], s_gaa[3 + m], g);
       gp[3 + k] = g;
     }
   } else if (tid < 45) {
