@@ -362,17 +362,27 @@ __global__ __launch_bounds__(FT) void mano_bwd_tile_kernel(const float* __restri
   }
   // the tile's share of <P[k], g_vp> (k < 135) and <S[k], g_vp> (10 shape rows): one row per wave pass, lanes over the tile
   const int ne = nv * 3;
-  for (int row = wave; row < NPM + 10; row += 4) {
-    const float* basis = (row < NPM ? M + OFF_PD + (size_t)row * NE : M + OFF_SD + (size_t)(row - NPM) * NE) + v0 * 3;
-    float a0 = 0.f, a1 = 0.f;
-    int e = lane;
-    for (; e + 64 < ne; e += 128) {
-      a0 = __fmaf_rn(basis[e], s_gv[e], a0);
-      a1 = __fmaf_rn(basis[e + 64], s_gv[e + 64], a1);
+  constexpr int RG = 6;  // rows per pass: 6 x ~10 independent loads in flight per lane (one row at a time exposes a full L2
+                         // round trip per row: 36 rows x ~2 us)
+  for (int row0 = wave * RG; row0 < NPM + 10; row0 += 4 * RG) {
+    float acc[RG];
+    const float* basis[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      const int row = row0 + r < NPM + 10 ? row0 + r : NPM + 9;
+      basis[r] = (row < NPM ? M + OFF_PD + (size_t)row * NE : M + OFF_SD + (size_t)(row - NPM) * NE) + v0 * 3;
+      acc[r] = 0.f;
     }
-    if (e < ne) a0 = __fmaf_rn(basis[e], s_gv[e], a0);
-    const float r = obman_wave_sum(a0 + a1);
-    if (lane == 0) out[192 + row] = r;
+    for (int e = lane; e < ne; e += 64) {
+      const float g = s_gv[e];
+#pragma unroll
+      for (int r = 0; r < RG; ++r) acc[r] = __fmaf_rn(basis[r][e], g, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      const float v = obman_wave_sum(acc[r]);
+      if (lane == 0 && row0 + r < NPM + 10) out[192 + row0 + r] = v;
+    }
   }
 }
 
