@@ -373,10 +373,15 @@ __global__ __launch_bounds__(FT) void mano_bwd_tile_kernel(const float* __restri
       basis[r] = (row < NPM ? M + OFF_PD + (size_t)row * NE : M + OFF_SD + (size_t)(row - NPM) * NE) + v0 * 3;
       acc[r] = 0.f;
     }
-    for (int e = lane; e < ne; e += 64) {
-      const float g = s_gv[e];
+    constexpr int NIT = (TILE_V * 3 + 63) / 64;  // 10 lane-strided steps cover the tile; fully unrolled so that all
+#pragma unroll                                    // RG x NIT loads are issued before the first one is consumed
+    for (int it = 0; it < NIT; ++it) {
+      const int e = lane + 64 * it;
+      const bool ok = e < ne;
+      const int ec = ok ? e : 0;
+      const float g = ok ? s_gv[ec] : 0.f;
 #pragma unroll
-      for (int r = 0; r < RG; ++r) acc[r] = __fmaf_rn(basis[r][e], g, acc[r]);
+      for (int r = 0; r < RG; ++r) acc[r] = __fmaf_rn(basis[r][ec], g, acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
