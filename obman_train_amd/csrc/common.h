@@ -20,11 +20,26 @@ __device__ __forceinline__ float obman_dist2(float ax, float ay, float az, float
   return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
-// Wave-level sum over 64 lanes (all lanes get the result).
+// Lane exchange inside a 16-lane DPP row: the operand modifier of a VALU op (no LDS-crossbar round trip like ds_bpermute,
+// whose ~80-cycle dependent latency dominated kernels that end in many reductions).
+template <int CTRL>
+__device__ __forceinline__ float obman_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// Wave-level sum over 64 lanes (all lanes get the result).  Butterfly inside each 16-lane row with DPP
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row sums are read as scalars and added in a fixed
+// order: ((r0 + r1) + (r2 + r3)).  Deterministic; every lane sees the same bits.
 __device__ __forceinline__ float obman_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += obman_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += obman_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += obman_dpp<0x141>(v);  // row_half_mirror
+  v += obman_dpp<0x140>(v);  // row_mirror
+  const int vi = __builtin_bit_cast(int, v);  // readlane is an integer builtin: pass the bits, not the value
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float obman_wave_max(float v) {
 #pragma unroll

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(FT) void mano_bwd_tile_kernel(const float* __restri
   __shared__ float s_GR[144];
   __shared__ float s_vp[TILE_V * 3], s_gv[TILE_V * 3];
   __shared__ float s_gj[63], s_cat[63], s_red[4][4];
-  __shared__ float s_part[4][NJ][12];
+  __shared__ float s_w[TILE_V * NJ];   // skinning weights of the tile, vertex-major
+  __shared__ float s_mm[4][256];       // per-wave 16x16 MFMA results
   const int v0 = vt * TILE_V, nv = min(NV, v0 + TILE_V) - v0;
   for (int k = tid; k < 144; k += FT) s_GR[k] = st[S_GR + k];
   for (int i = tid; i < nv * 3; i += FT) {
@@ -334,32 +335,55 @@ __global__ __launch_bounds__(FT) void mano_bwd_tile_kernel(const float* __restri
   __syncthreads();
   if (vt == 0 && tid < 48) out[337 + tid] = s_cat[tid];  // d/d(chain joint translations), consumed by the chain kernel
   // skinning backward.  verts[v] = sum_i w_vi (GR_i vp_v + trel_i)
+  //   d/d(v_posed_v) = sum_i w_vi GR_i^T gv_v                                  (per lane, VALU)
+  //   d/d(GR_i | trel_i) = sum_v w_vi [gv_v (x) vp_v | gv_v]  = W^T X,  X[v] = (gv (x) vp, gv) in R^12
+  // The second line is a [16 x nv] x [nv x 12] product: done on the matrix core (v_mfma_f32_16x16x4_f32, exact fp32 fma
+  // chains) instead of 192 wave reductions of 6 dependent ds_bpermute steps each (51 of the kernel's 76 us before).
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const bool vok = tid < nv;
-  const float gvx = vok ? s_gv[tid * 3] : 0.f, gvy = vok ? s_gv[tid * 3 + 1] : 0.f, gvz = vok ? s_gv[tid * 3 + 2] : 0.f;
-  const float px = vok ? s_vp[tid * 3] : 0.f, py = vok ? s_vp[tid * 3 + 1] : 0.f, pz = vok ? s_vp[tid * 3 + 2] : 0.f;
-  __syncthreads();  // every lane holds its s_gv in registers: s_gv now receives d(loss)/d(v_posed)
-  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-#pragma unroll 4
-  for (int i = 0; i < NJ; ++i) {
-    const float* G = &s_GR[i * 9];
-    const float wji = vok ? M[OFF_W + i * NV + v0 + tid] : 0.f;
-    const float wx = wji * gvx, wy = wji * gvy, wz = wji * gvz;
-    float acc[12] = {wx * px, wx * py, wx * pz, wy * px, wy * py, wy * pz, wz * px, wz * py, wz * pz, wx, wy, wz};
-    gpx += G[0] * wx + G[3] * wy + G[6] * wz;
-    gpy += G[1] * wx + G[4] * wy + G[7] * wz;
-    gpz += G[2] * wx + G[5] * wy + G[8] * wz;
+  float wv[NJ];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const float r = obman_wave_sum(acc[k]);
-      if (lane == 0) s_part[wave][i][k] = r;
+  for (int i = 0; i < NJ; ++i) wv[i] = vok ? M[OFF_W + i * NV + v0 + tid] : 0.f;  // 16 independent coalesced loads
+  if (vok) {
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) s_w[tid * NJ + i] = wv[i];
+  }
+  __syncthreads();
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int j = lane & 15, g = lane >> 4;
+    for (int t = wave; t * 4 < nv; t += 4) {
+      const int v = 4 * t + g;
+      float a = 0.f, x = 0.f;
+      if (v < nv) {
+        a = s_w[v * NJ + j];                                   // A[i = lane&15][k = lane>>4] = w[v][i]
+        if (j < 9) x = s_gv[v * 3 + j / 3] * s_vp[v * 3 + j % 3];  // B[k][j] = X[v][j]
+        else if (j < 12) x = s_gv[v * 3 + j - 9];
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_mm[wave][(g * 4 + r) * 16 + j] = acc[r];  // D: row = 4*(lane>>4)+r (joint), col = lane&15
+  }
+  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+  if (vok) {
+    const float gvx = s_gv[tid * 3], gvy = s_gv[tid * 3 + 1], gvz = s_gv[tid * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const float* G = &s_GR[i * 9];
+      const float wx = wv[i] * gvx, wy = wv[i] * gvy, wz = wv[i] * gvz;
+      gpx += G[0] * wx + G[3] * wy + G[6] * wz;
+      gpy += G[1] * wx + G[4] * wy + G[7] * wz;
+      gpz += G[2] * wx + G[5] * wy + G[8] * wz;
     }
   }
+  __syncthreads();  // MFMA operands have been read: s_gv can now receive d(loss)/d(v_posed)
   if (vok) { s_gv[tid * 3] = gpx; s_gv[tid * 3 + 1] = gpy; s_gv[tid * 3 + 2] = gpz; }
-  __syncthreads();
   if (tid < NJ * 12) {
     const int i = tid / 12, k = tid % 12;
-    out[tid] = (s_part[0][i][k] + s_part[1][i][k]) + (s_part[2][i][k] + s_part[3][i][k]);
+    out[tid] = (s_mm[0][i * 16 + k] + s_mm[1][i * 16 + k]) + (s_mm[2][i * 16 + k] + s_mm[3][i * 16 + k]);
   }
+  __syncthreads();
   // the tile's share of <P[k], g_vp> (k < 135) and <S[k], g_vp> (10 shape rows): one row per wave pass, lanes over the tile
   const int ne = nv * 3;
   constexpr int RG = 6;  // rows per pass: 6 x ~10 independent loads in flight per lane (one row at a time exposes a full L2

@@ -43,7 +43,12 @@ def test_decoder_forward_backward_matches_oracle(c1, B, subdiv, training, patche
     from obman_train_amd.icosphere import multi_patch
 
     grid = torch.from_numpy(multi_patch(subdiv, patches)[0].astype(np.float32))  # patches=25: the configs[2] template layout
-    rng = np.random.RandomState(8)
+    # Seed note: a ReLU derivative is discontinuous at 0, so an input whose pre-activation lands within fp32 rounding of
+    # zero flips one mask element between ANY two fp32 evaluation orders and moves one channel's gradient by ~1/sqrt(rows)
+    # of its magnitude (seed 8 does this for the 25-patch case: fp64 and fp32 runs of the oracle itself disagree there).
+    # Seeds 100.. are free of such ties for every case below (tools/decoder_err.py prints the per-parameter errors against
+    # an fp64 run of the oracle: 1e-6 .. 1e-5), so the gradient tolerance is 2e-4 of each tensor's max.
+    rng = np.random.RandomState(100)
     feats = torch.from_numpy(rng.normal(0, 1, size=(B, c1 - 3)).astype(np.float32))
     cot = torch.from_numpy(rng.normal(0, 1, size=(B, grid.shape[0], 3)).astype(np.float32))
     want, f_o, params = _oracle(dec, feats, grid, training)
@@ -60,7 +65,7 @@ def test_decoder_forward_backward_matches_oracle(c1, B, subdiv, training, patche
     def check(name, g, w):
         err = (g.cpu() - w).abs().max().item()
         ref = w.abs().max().item()
-        assert err <= 2e-3 * ref + 1e-5, (name, err, ref)
+        assert err <= 2e-4 * ref + 1e-5, (name, err, ref)
 
     check("features", f_g.grad, f_o.grad)
     for name, prm in dec_g.named_parameters():
