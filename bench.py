@@ -100,6 +100,79 @@ def cpu_baseline(cfg, seconds, image_size):
     }
 
 
+def input_stream_probe(batch, image_size, src_hw=(270, 480)):
+    """K10 outside the timed region: one batch of FHB-sized frames (configs[4] "FHB input stream") through
+    HandDataset -> DeviceImageStage with the reference's default jitter; device time of obman_imgstream_fwd (HIP events on
+    the launch stream) and the host cost of drawing + staging one batch."""
+    import random
+
+    import numpy as np
+
+    from obman_train_amd import ops
+    from obman_train_amd.handobjectdatasets import HandDataset, SyntheticPoses
+    from obman_train_amd.queries import BaseQueries, TransQueries
+
+    np.random.seed(0)
+    random.seed(0)
+    ds = HandDataset(SyntheticPoses(n=batch, src_hw=src_hw), inp_res=image_size, sides="left",
+                     queries=[TransQueries.images, TransQueries.joints3d, TransQueries.verts3d, TransQueries.objpoints3d,
+                              BaseQueries.sides])
+    samples = [ds.get_sample(i) for i in range(batch)]  # warms imports and the synthetic frame pool
+    t0 = time.perf_counter()
+    samples = [ds.get_sample(i) for i in range(batch)]
+    t_draw = time.perf_counter() - t0
+    stage = ds.image_stage(channels_last=True)
+    plans = [s[TransQueries.images] for s in samples]
+    stage.pack(plans)
+    t0 = time.perf_counter()
+    host, words, max_blur, any_contrast = stage.pack(plans)
+    t_pack = time.perf_counter() - t0
+    src, par = host.cuda(), words.cuda()
+    run = lambda: ops.image_stream(src, par, max_blur, any_contrast, image_size, channels_last=True)  # noqa: E731
+    for _ in range(5):
+        run()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    st.record()
+    for _ in range(30):
+        run()
+    en.record()
+    torch.cuda.synchronize()
+    t = st.elapsed_time(en) * 1e-3 / 30
+    # algorithmic bytes per batch: source read by blur + (contrast reduction or warp gather) as RGB888/RGBX, the blurred
+    # RGBX copy written once, the fp32 crop written once
+    alg = batch * (src_hw[0] * src_hw[1] * (3 + 4 + 4) + image_size * image_size * 12)
+    pil = None
+    try:  # what handataset.py:373-405 executes per sample on a DataLoader worker, timed on one host core with the real Pillow
+        from PIL import Image, ImageEnhance, ImageFilter
+
+        n_ref = min(batch, 16)
+        t0 = time.perf_counter()
+        for p in plans[:n_ref]:
+            im = Image.fromarray(p.image, "RGB").filter(ImageFilter.GaussianBlur(0.25))
+            for op, f in p.ops:
+                if op == 1:
+                    im = ImageEnhance.Brightness(im).enhance(f)
+                elif op == 2:
+                    im = ImageEnhance.Color(im).enhance(f)
+                elif op == 4:
+                    im = ImageEnhance.Contrast(im).enhance(f)
+                else:
+                    h, s_, v = im.convert("HSV").split()
+                    im = Image.merge("HSV", (Image.fromarray((np.asarray(h).astype(np.int32) + int(f * 255)).astype(np.uint8), "L"), s_, v)).convert("RGB")
+            im = im.transform((image_size, image_size), Image.AFFINE, (1.0, 0.1, 3.0, -0.1, 1.0, 5.0))
+            _ = np.asarray(im).transpose(2, 0, 1).astype(np.float32) / np.float32(255) - np.float32(0.5)
+        pil = {"ms_per_image": (time.perf_counter() - t0) / n_ref * 1e3, "cores": 1, "images": n_ref,
+               "impl": "Pillow %s: GaussianBlur + the sample's colour ops + AFFINE crop + /255 (the reference's CPU pixel path)" % Image.__version__}
+    except ImportError:
+        pass
+    return {"cpu_pixel_path": pil,"kernel": "obman_imgstream_fwd (K10: blur + colour jitter + affine crop + normalise, bit-exact vs PIL path)",
+            "batch": batch, "src_hw": list(src_hw), "out": [3, image_size, image_size], "device_us": t * 1e6,
+            "images_per_s_device": batch / t, "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": alg / t / 1e9 / HBM_PEAK_GBPS, "host_draw_ms": t_draw * 1e3, "host_stage_ms": t_pack * 1e3,
+            "note": "outside the timed region; integer/fp64 ALU-bound (exact PIL uint8 semantics), not HBM-bound"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,6 +285,8 @@ def main():
             "roofline": roof,
             "decoder_roofline": decoder,
         }
+        if world == 1:
+            out["input_stream"] = input_stream_probe(args.batch, args.image_size)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -12,6 +12,8 @@
 #ifndef OBMAN_HIP_H
 #define OBMAN_HIP_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -176,6 +178,40 @@ int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, floa
                      int training, float eps, float momentum, float* y_pool, float* stats, float* ws, obman_stream_t stream);
 int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, const float* gamma, const float* stats, int B, int H, int W,
                      int C, int training, float* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream);
+
+/* ---- K10: GPU-side image input stream -----------------------------------------------------------
+ * Replaces the CPU pixel pipeline of HandDataset.get_sample (handobjectdatasets/handataset.py:373-405): per sample
+ * Gaussian blur (PIL ImageFilter.GaussianBlur = 3+3 extended-box passes) and colour jitter (imgtrans.py:31-53:
+ * torchvision adjust_brightness / saturation / hue / contrast on uint8, in the sample's shuffled order) of the source
+ * image, the affine crop handutils.transform_img (handutils.py:48-60: PIL AFFINE transform, NEAREST, 16.16 fixed
+ * point), to_tensor (/255), the optional black frame (handataset.py:390-397) and normalize (handataset.py:399-404).
+ * Byte/integer work: bit-identical to the CPU path.
+ * src [B, pitch_h, pitch_w, 3] uint8 RGB (PIL raw "RGB": the host stages a plain memcpy of the decoded image), each
+ * sample's image in the top-left src_h x src_w corner of its slot.  params: DEVICE array of B records, filled by the host from its RNG draws:
+ *   flip      read the source mirrored left-right (Image.FLIP_LEFT_RIGHT, handataset.py:134-135)
+ *   A[6]      xin = (A[2] + x*A[0] + y*A[1]) >> 16, yin = (A[5] + x*A[3] + y*A[4]) >> 16   (Geometry.c affine_fixed)
+ *   blur_r/ww/fw  integer radius (-1: no blur) and 8.24 weights of the extended box filter (BoxBlur.c)
+ *   op[k], factor[k], k < n_ops <= 4   1 brightness, 2 saturation, 3 hue (uses hue_shift, a uint8 increment of H),
+ *             4 contrast; factor = blend factor as C float
+ * max_blur_r = max over the batch of blur_r (-1 skips the blur kernel; > 8 is rejected), any_contrast = some sample has
+ * op 4 (runs the whole-image luma reduction).  mean3 / std3: HOST float[3] or NULL (0.5 / 1, the reference's default).
+ * black_pad: frame width in pixels (int(inp_res * 0.2) in the reference) or 0.  out [B,3,res,res] fp32, or
+ * [B,res,res,3] when channels_last.  ws: obman_imgstream_ws_bytes(B, pitch_h, pitch_w) bytes of scratch. */
+typedef struct obman_img_params {
+  int32_t src_h, src_w, flip;
+  int32_t A[6];
+  int32_t blur_r;
+  uint32_t blur_ww, blur_fw;
+  int32_t n_ops;
+  int32_t op[4];
+  float factor[4];
+  int32_t hue_shift;
+  int32_t reserved[2];
+} obman_img_params; /* 24 x 32-bit words */
+long obman_imgstream_ws_bytes(int B, int pitch_h, int pitch_w);
+int obman_imgstream_fwd(const uint8_t* src, int B, int pitch_h, int pitch_w, const obman_img_params* params, int max_blur_r,
+                        int any_contrast, int out_res, int channels_last, int black_pad, const float* mean3, const float* std3,
+                        void* ws, float* out, obman_stream_t stream);
 
 /* ---- measurement utility (not on the product path) ----------------------------------------------
  * obman_prof_enable(1) makes the launchers bracket their main kernel with HIP events on the launch

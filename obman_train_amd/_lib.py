@@ -34,6 +34,8 @@ _SIGNATURES = {
     "obman_bnact_bwd": (_c_int, "ppppp" "li" "iii" "ppppp" "p"),
     "obman_bnpool_fwd": (_c_int, "ppppp" "iiii" "iff" "ppp" "p"),
     "obman_bnpool_bwd": (_c_int, "ppppp" "iiii" "i" "pppp" "p"),
+    "obman_imgstream_ws_bytes": (_c_long, "iii"),
+    "obman_imgstream_fwd": (_c_int, "piiip" "ii" "iii" "pp" "pp" "p"),
     "obman_prof_enable": (_c_int, "i"),
     "obman_prof_summary": (_c_int, "ipp"),
     "obman_mano_model_floats": (_c_int, ""),
@@ -58,6 +60,16 @@ class PointGenParams(ctypes.Structure):  # obman_pointgen_params
 class PointGenGrads(ctypes.Structure):  # obman_pointgen_grads
     _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("w4", _fp), ("b4", _fp),
                 ("bn_w", _fp * 3), ("bn_b", _fp * 3), ("feat", _fp)]
+
+
+class ImgParams(ctypes.Structure):  # obman_img_params: 24 x 32-bit words per sample
+    _fields_ = [("src_h", ctypes.c_int32), ("src_w", ctypes.c_int32), ("flip", ctypes.c_int32), ("A", ctypes.c_int32 * 6),
+                ("blur_r", ctypes.c_int32), ("blur_ww", ctypes.c_uint32), ("blur_fw", ctypes.c_uint32),
+                ("n_ops", ctypes.c_int32), ("op", ctypes.c_int32 * 4), ("factor", _c_float * 4),
+                ("hue_shift", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+
+
+assert ctypes.sizeof(ImgParams) == 96
 
 
 class ObmanHipError(RuntimeError):

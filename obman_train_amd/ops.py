@@ -507,3 +507,33 @@ def bn_relu_maxpool(bn, x, pool, count=True):
     else:
         momentum = bn.momentum
     return _BNReLUPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum)
+
+
+def image_stream(src_rgb, params_words, max_blur_r, any_contrast, out_res, channels_last=False, black_pad=0,
+                 mean=(0.5, 0.5, 0.5), std=(1.0, 1.0, 1.0)):
+    """K10 (csrc/imgstream.hip): a batch of source images -> network inputs, the pixel pipeline of
+    HandDataset.get_sample (handataset.py:373-405) bit for bit.
+
+    src_rgb [B,Hp,Wp,3] uint8 device tensor (PIL raw "RGB", every image in the top-left corner of its slot),
+    params_words [B,24] int32 device tensor (one ``obman_img_params`` per sample, see include/obman_hip.h).
+    -> [B,3,out_res,out_res] fp32; with channels_last the same logical shape in torch.channels_last memory format."""
+    if not (isinstance(src_rgb, torch.Tensor) and src_rgb.is_cuda and src_rgb.dtype == torch.uint8 and src_rgb.dim() == 4
+            and src_rgb.shape[3] == 3):
+        raise _lib.ObmanHipError("src_rgb must be a [B,H,W,3] uint8 ROCm tensor (the HIP path has no CPU fallback)")
+    params_words = _dev(params_words, "params_words", torch.int32)
+    src_rgb = src_rgb.contiguous()
+    B, Hp, Wp = int(src_rgb.shape[0]), int(src_rgb.shape[1]), int(src_rgb.shape[2])
+    if tuple(params_words.shape) != (B, 24):
+        raise ValueError("params_words must be [B,24] int32, got %s" % (tuple(params_words.shape),))
+    lib = _lib.lib()
+    ws = torch.empty(lib.obman_imgstream_ws_bytes(B, Hp, Wp), dtype=torch.uint8, device=src_rgb.device)
+    if channels_last:
+        out = torch.empty((B, out_res, out_res, 3), dtype=torch.float32, device=src_rgb.device)
+    else:
+        out = torch.empty((B, 3, out_res, out_res), dtype=torch.float32, device=src_rgb.device)
+    mean3 = (_ct.c_float * 3)(*[float(m) for m in mean])
+    std3 = (_ct.c_float * 3)(*[float(s) for s in std])
+    _lib.check(lib.obman_imgstream_fwd(_ptr(src_rgb), B, Hp, Wp, _ptr(params_words), int(max_blur_r), int(bool(any_contrast)),
+                                       int(out_res), int(bool(channels_last)), int(black_pad), _ct.addressof(mean3),
+                                       _ct.addressof(std3), _ptr(ws), _ptr(out), _stream()), "obman_imgstream_fwd")
+    return out.permute(0, 3, 1, 2) if channels_last else out

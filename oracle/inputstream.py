@@ -2,7 +2,7 @@
 
 Restates, in plain numpy (no PIL, no torchvision), what ``HandDataset.get_sample``
 (``handobjectdatasets/handataset.py:103-411``) does to one sample: side flip, centre / scale / rotation
-jitter, the affine crop (``handutils.py:46-102``), Gaussian blur + colour jitter of the source image
+jitter, the affine crop (``handutils.py:48-101``), Gaussian blur + colour jitter of the source image
 (``handataset.py:373-383``, ``imgtrans.py:5-53``), nearest-neighbour warp, tensorisation and normalisation
 (``handataset.py:384-405``) and the matching 2-D / 3-D annotation transforms.
 
@@ -219,7 +219,7 @@ def get_color_params(brightness=0, contrast=0, saturation=0, hue=0, rng=_random)
 
 
 def color_jitter_plan(brightness=0, contrast=0, saturation=0, hue=0, rng=_random):
-    """``imgtrans.py:31-53``: the op list is built as [brightness, saturation, hue, contrast] and shuffled."""
+    """``imgtrans.py:30-53``: the op list is built as [brightness, saturation, hue, contrast] and shuffled."""
     b, c, s, h = get_color_params(brightness, contrast, saturation, hue, rng)
     ops = []
     if b is not None:
@@ -250,7 +250,7 @@ def to_tensor_normalize(rgb, mean=(0.5, 0.5, 0.5), std=(1, 1, 1), black_padding=
 
 # ------------------------------------------------------------------------------------------------- handutils.py
 def get_affine_trans_no_rot(center, scale, res):
-    """``handutils.py:80-88``."""
+    """``handutils.py:94-101``."""
     t = np.zeros((3, 3))
     t[0, 0] = float(res[1]) / scale
     t[1, 1] = float(res[0]) / scale
@@ -261,7 +261,7 @@ def get_affine_trans_no_rot(center, scale, res):
 
 
 def get_affine_transform(center, scale, res, rot=0):
-    """``handutils.py:46-77``: (crop o rotation about the origin) and the rotation-free crop about the centre rotated
+    """``handutils.py:63-91``: (crop o rotation about the origin) and the rotation-free crop about the centre rotated
     around the image middle, both as float32."""
     rot_mat = np.zeros((3, 3))
     sn, cs = np.sin(rot), np.cos(rot)
@@ -282,20 +282,20 @@ def get_affine_transform(center, scale, res, rot=0):
 
 
 def transform_coords(pts, affine_trans):
-    """``handutils.py:23-32``: homogeneous transform, truncated to int."""
+    """``handutils.py:36-45``: homogeneous transform, truncated to int."""
     hom = np.concatenate([pts, np.ones([np.array(pts).shape[0], 1])], 1)
     return affine_trans.dot(hom.transpose()).transpose()[:, :2].astype(int)
 
 
 def transform_img(rgb, affine_trans, res):
-    """``handutils.py:35-43`` + the crop of ``handataset.py:385-387`` (a no-op: the transform already has size res)."""
+    """``handutils.py:48-60`` + the crop of ``handataset.py:385-387`` (a no-op: the transform already has size res)."""
     trans = np.linalg.inv(affine_trans)
     coeffs = (trans[0, 0], trans[0, 1], trans[0, 2], trans[1, 0], trans[1, 1], trans[1, 2])
     return affine_nearest(rgb, coeffs, res[0], res[1])
 
 
 def points_from_mesh(faces, vertices, vertex_nb=600):
-    """``vertexsample.py:11-30``: area-weighted uniform surface samples (global ``np.random`` draws, same order)."""
+    """``vertexsample.py:11-29``: area-weighted uniform surface samples (global ``np.random`` draws, same order)."""
     v = vertices[faces]
     areas = 0.5 * np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1)
     proba = areas / areas.sum()
@@ -417,3 +417,43 @@ def get_sample(pose, idx, queries, *, inp_res=256, center_idx=9, point_nb=600, m
         img = transform_img(np.ascontiguousarray(img), affinetrans, [inp_res, inp_res])
         sample["images"] = to_tensor_normalize(img, black_padding=black_padding, inp_res=inp_res)
     return sample
+
+
+# ------------------------------------------------------------------------------- CPU model of the C-ABI entry point
+def imgstream_fwd(images, records, out_res, black_pad=0, mean=(0.5, 0.5, 0.5), std=(1, 1, 1)):
+    """What ``obman_imgstream_fwd`` (include/obman_hip.h, K10) must return for a batch: ``images`` uint8 [H,W,3] arrays,
+    ``records`` dicts with the fields of ``obman_img_params`` (flip, A[6], blur=(r, ww, fw), ops=[(op, factor)]).
+    Composition of the pinned primitives above in the reference's order: flip, blur, colour ops on the whole source
+    image, fixed-point nearest warp, tensorise, frame, normalise.  -> float32 [B,3,out_res,out_res]."""
+    out = []
+    for img, rec in zip(images, records):
+        img = np.ascontiguousarray(img[:, ::-1] if rec["flip"] else img)
+        r, ww, fw = rec["blur"]
+        if r >= 0:
+            for _ in range(3):
+                img = _box_pass_h(img, r, ww, fw)
+            img = img.transpose(1, 0, 2)
+            for _ in range(3):
+                img = _box_pass_h(img, r, ww, fw)
+            img = np.ascontiguousarray(img.transpose(1, 0, 2))
+        for op, f in rec["ops"]:
+            img = apply_color_op(img, op, f)
+        A = rec["A"]
+        H, W = img.shape[:2]
+        x = np.arange(out_res, dtype=np.int64)[None, :]
+        y = np.arange(out_res, dtype=np.int64)[:, None]
+        xin = (A[2] + x * A[0] + y * A[1]) >> 16
+        yin = (A[5] + x * A[3] + y * A[4]) >> 16
+        ok = (xin >= 0) & (xin < W) & (yin >= 0) & (yin < H)
+        crop = np.zeros((out_res, out_res, 3), np.uint8)
+        crop[ok] = img[yin[ok], xin[ok]]
+        t = (crop.transpose(2, 0, 1).astype(F32) / F32(255)).astype(F32)
+        if black_pad:
+            t[:, 0:black_pad, :] = 0
+            t[:, -black_pad:-1, :] = 0
+            t[:, :, 0:black_pad] = 0
+            t[:, :, -black_pad:-1] = 0
+        m = np.asarray(mean, F32)[:, None, None]
+        s = np.asarray(std, F32)[:, None, None]
+        out.append(((t - m).astype(F32) / s).astype(F32))
+    return np.stack(out)

@@ -1,6 +1,6 @@
 """Per-kernel micro-benchmark on the GPU box (HIP events on the launch stream).
 
-    python tools/kbench.py [chamfer|contains|mano|decoder|all]
+    python tools/kbench.py [chamfer|contains|mano|decoder|imgstream|all]
 Prints one JSON line per measurement: algorithmic bytes/flops / average time."""
 import json
 import os
@@ -108,6 +108,46 @@ def bench_contains():
                               Gpairs_per_s=round(pairs / t / 1e3, 1), valu_TFLOPs=round(pairs * 50 / t / 1e6, 1))), flush=True)
 
 
+def bench_imgstream():
+    """K10: one batch of 64 source images (FHB 480x270 and ObMan 256x256) -> 64 x 3 x 256 x 256 fp32, default jitter."""
+    import random
+    import time
+
+    import numpy as np
+
+    from obman_train_amd.handobjectdatasets import handutils, imgtrans
+    from obman_train_amd.handobjectdatasets.imagestage import DeviceImageStage, ImagePlan
+
+    for (H, W) in ((270, 480), (256, 256)):
+        rng = np.random.RandomState(0)
+        random.seed(0)
+        plans = []
+        for b in range(64):
+            img = rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+            aff, _ = handutils.get_affine_transform(np.array([W // 2 + rng.randint(-20, 20), H // 2 + rng.randint(-20, 20)]),
+                                                    rng.uniform(150, 260), [256, 256], rot=rng.uniform(-np.pi, np.pi))
+            plans.append(ImagePlan(img, b % 2, handutils.fixed_point_affine(aff, [256, 256]),
+                                   blur=imgtrans.box_blur_weights(random.random() * 0.5),
+                                   ops=imgtrans.color_jitter_plan(brightness=0.5, saturation=0.5, hue=0.15, contrast=0.5)))
+        for cl in (False, True):
+            stage = DeviceImageStage(inp_res=256, channels_last=cl)
+            host, words, max_blur, any_contrast = stage.pack(plans)
+            src, par = host.cuda(), words.cuda()
+            from obman_train_amd import ops
+
+            t = timeit(lambda: ops.image_stream(src, par, max_blur, any_contrast, 256, channels_last=cl), iters=50, warmup=5)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                stage.pack(plans)
+            t_pack = (time.perf_counter() - t0) / 5
+            # algorithmic bytes: source read (4 B/px, twice when blurred or contrast-reduced: blur pass + warp gather of the
+            # crop footprint is <= the image) + blurred copy write + fp32 output write
+            alg = 64 * (H * W * 4 * 3 + 256 * 256 * 12)
+            print(json.dumps(dict(kernel="imgstream", src_hw=[H, W], B=64, channels_last=cl, device_us=round(t * 1e6, 1),
+                                  alg_GBps=round(alg / t / 1e9, 1), images_per_s_device=round(64 / t),
+                                  host_pack_ms=round(t_pack * 1e3, 2))), flush=True)
+
+
 def bench_decoder():
     import numpy as np
 
@@ -144,5 +184,7 @@ if __name__ == "__main__":
         bench_mano()
     if which in ("contains", "all"):
         bench_contains()
+    if which in ("imgstream", "all"):
+        bench_imgstream()
     if which in ("decoder", "all"):
         bench_decoder()
