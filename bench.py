@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16 = autocast the ResNet encoder (configs[2] flavour; NOT the headline fp32 config)")
+    ap.add_argument("--decoder-dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = AtlasNet decoder GEMMs on the bf16 matrix pipe (configs[2] flavour; NOT the headline fp32 config)")
     ap.add_argument("--force-dist", action="store_true",
                     help="self-test: run the RCCL process group + gradient buckets even with a single rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,6 +211,7 @@ def main():
     model.train()
     if args.encoder_dtype == "bf16":
         model.base_net.autocast_dtype = torch.bfloat16
+    model.atlas_branch.decoder.mfma_dtype = args.decoder_dtype
     broadcast_parameters(model)
     opt = make_optimizer(model, "adam", lr=1e-4)
     buckets = GradientBuckets(model.parameters(), force=args.force_dist) if use_dist else None
@@ -262,10 +265,12 @@ def main():
         decoder = None
         if dec_f_n and dec_b_n:
             tf, tb = dec_f_ms / dec_f_n * 1e-3, dec_b_ms / dec_b_n * 1e-3
-            decoder = {"bound": "mfma", "dtype": "f32", "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            dpeak = VALU_PEAK_TFLOPS if args.decoder_dtype == "f32" else 2500.0
+            decoder = {"bound": "mfma", "dtype": args.decoder_dtype, "peak": dpeak, "unit": "TFLOP/s",
                        "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_achieved": dec_flop / tf / 1e12,
-                       "bwd_achieved": 2 * dec_flop / tb / 1e12, "frac": 3 * dec_flop / (tf + tb) / 1e12 / VALU_PEAK_TFLOPS,
-                       "note": "whole obman_pointgen_fwd/bwd call (all its kernels), fp32-in MFMA peak = 157.3 TF"}
+                       "bwd_achieved": 2 * dec_flop / tb / 1e12, "frac": 3 * dec_flop / (tf + tb) / 1e12 / dpeak,
+                       "note": "whole obman_pointgen_fwd/bwd call (all its kernels); peak = dense MFMA rate of the operand "
+                               "dtype (157.3 TF fp32-in, 2500 TF bf16)"}
         traffic_file = os.path.join(REPO, "profiles", "chamfer_traffic.json")
         if os.path.exists(traffic_file):
             with open(traffic_file) as fh:
@@ -275,7 +280,9 @@ def main():
             "value": args.batch * world * args.steps / dt, "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder / f32 heads", "data": "synthetic",
+            "dtype": "f32" if (args.encoder_dtype, args.decoder_dtype) == ("f32", "f32") else
+                     "%s encoder / %s decoder MFMA / f32 heads, losses, optimizer" % (args.encoder_dtype, args.decoder_dtype),
+            "data": "synthetic",
             "config": {"workload": "configs[1]: ResNet18 + MANO(30 PCA comps) LBS + 1-sphere AtlasNet(642 verts) "
                                    "+ Chamfer vs 600 GT points%s, %dx%d RGB, fp32, Adam"
                                    % (" + contact/penetration (%d patches)" % cfg.get("atlas_patches", 1)

@@ -113,7 +113,7 @@ int obman_contact_bwd(const float* hand, const float* obj, const int* idx21, con
                       int B, int V, int N, int contact_mode, float contact_thresh, int collision_mode,
                       float collision_thresh, int target, float* grad_hand, float* grad_obj, obman_stream_t stream);
 
-/* ---- K6: AtlasNet PointGenCon decoder (fp32 MFMA) ---------------------------------------------------
+/* ---- K6: AtlasNet PointGenCon decoder (fp32 MFMA; optional bf16 MFMA) ---------------------------------------------------
  * Replaces atlasbranch.py:117-132 (grid/feature repeat + concat) + PointGenCon.forward (atlasutils.py:65-75):
  * 4 pointwise convs C1 -> C1 -> C1/2 -> C1/4 -> 3 with BatchNorm1d + ReLU after the first three, x out_factor.
  * C1 = 3 + feature size (515).  grid [N,3] is the shared sphere template, feat [B,C1-3]; weights are the conv
@@ -123,6 +123,8 @@ int obman_contact_bwd(const float* hand, const float* obj, const int* idx21, con
 typedef struct {
   int B, N, C1, training;
   float eps, momentum, out_factor;
+  int mfma_bf16; /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32
+                    accumulation and fp32 BatchNorm statistics (BASELINE configs[2] flavour) */
   const float *grid, *feat;
   const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
   const float* bn_w[3];

@@ -51,7 +51,7 @@ _fp = ctypes.c_void_p
 
 class PointGenParams(ctypes.Structure):  # obman_pointgen_params
     _fields_ = [("B", _c_int), ("N", _c_int), ("C1", _c_int), ("training", _c_int),
-                ("eps", _c_float), ("momentum", _c_float), ("out_factor", _c_float),
+                ("eps", _c_float), ("momentum", _c_float), ("out_factor", _c_float), ("mfma_bf16", _c_int),
                 ("grid", _fp), ("feat", _fp),
                 ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("w4", _fp), ("b4", _fp),
                 ("bn_w", _fp * 3), ("bn_b", _fp * 3), ("bn_rm", _fp * 3), ("bn_rv", _fp * 3)]

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
 
 // ---- epilogue bodies (members defined here to keep the kernel readable)
 struct EpiStoreImpl : EpiStore {
-  __device__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
+  __device__ __forceinline__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
     const int col = c0 + (lane & 31);
     const float bv = (bias && col < Nc) ? bias[col] : 0.f;
     double s1 = 0.0, s2 = 0.0;
@@ -314,41 +314,90 @@ struct EpiStoreImpl : EpiStore {
       }
     }
   }
+  // bf16 kernel: one 32-row tile per wave, four M-waves per block (fixed-order sum over the waves)
+  __device__ __forceinline__ void finish32(const f32x16& a, int r0, int c0, int lane, int wm, int wn, char* smem) const {
+    const int col = c0 + (lane & 31);
+    const float bv = (bias && col < Nc) ? bias[col] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = r0 + acc_row(reg, lane);
+      const float v = a[reg] + bv;
+      if (r < R && col < Nc) {
+        C[(size_t)r * ldc + col] = v;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+      }
+    }
+    if (moments) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      double* red = reinterpret_cast<double*>(smem);
+      __syncthreads();
+      if (wm > 0 && lane < 32) { double* q = red + ((((wm - 1) * 2 + wn) * 32) + lane) * 2; q[0] = s1; q[1] = s2; }
+      __syncthreads();
+      if (wm == 0 && lane < 32 && col < Nc) {
+        double* dst = moments + ((size_t)blockIdx.x * Nc + col) * 2;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { const double* q = red + (((w * 2 + wn) * 32) + lane) * 2; s1 += q[0]; s2 += q[1]; }
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
 };
 
 struct EpiMaskStatsImpl : EpiMaskStats {
-  __device__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
-    const int col = c0 + (lane & 31);
-    const bool cok = col < Nc;
-    double s1 = 0.0, s2 = 0.0;
-    float c_s = 0.f, c_t = 0.f, c_m = 0.f, c_r = 0.f;
-    if (cok) {
-      if (mode == 0) { c_s = s[col]; c_t = t[col]; c_m = mean[col]; c_r = rstd[col]; }
-      else { c_s = gamma[col]; c_t = beta[col]; }
-    }
+  // One 32x32 accumulator tile: C = acc * (y > 0) and this lane's column partials S1 = sum C, S2 = sum C * xhat.
+  // The 16 rows a lane holds are r0 + (reg&3) + 8 (reg>>2) + 4 (lane>>5); their (sample, vertex) split advances
+  // incrementally from one division per tile.  Partials stay fp32 inside the lane (16 terms), fp64 across lanes/blocks.
+  struct Part { float s1, s2; };
+  struct Cst { float s, t, m, r; };
+  __device__ __forceinline__ Part tile(const f32x16& a, int r0, int col, bool cok, int lane, const Cst c) const {
+    float s1 = 0.f, s2 = 0.f;
+    const float c_s = c.s, c_t = c.t, c_m = c.m, c_r = c.r;
+    const int rb = r0 + 4 * (lane >> 5);
+    int b = 0, n = 0;
+    if (mode != 0) { b = rb / N; n = rb - b * N; }
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int r = r0 + tt * 32 + acc_row(reg, lane);
-        if (r < R && cok) {
-          float xh, y;
-          if (mode == 0) {
-            const float h = H[(size_t)r * ldc + col];
-            y = __fmaf_rn(c_s, h, c_t);
-            xh = (h - c_m) * c_r;
-          } else {
-            const int b = r / N, n = r - b * N;
-            xh = Gx[(size_t)n * ldc + col] + Fx[(size_t)b * ldc + col];
-            y = __fmaf_rn(c_s, xh, c_t);
-          }
-          const float v = y > 0.f ? (tt == 0 ? a0[reg] : a1[reg]) : 0.f;
-          C[(size_t)r * ldc + col] = v;
-          s1 += (double)v;
-          s2 += (double)v * (double)xh;
+    for (int reg = 0; reg < 16; ++reg) {
+      const int off = (reg & 3) + 8 * (reg >> 2);
+      const int r = rb + off;
+      int bb = b, nn = n + off;
+      if (mode != 0) while (nn >= N) { nn -= N; ++bb; }
+      if (r < R && cok) {
+        float xh, y;
+        if (mode == 0) {
+          const float h = H[(size_t)r * ldc + col];
+          y = __fmaf_rn(c_s, h, c_t);
+          xh = (h - c_m) * c_r;
+        } else {
+          xh = Gx[(size_t)nn * ldc + col] + Fx[(size_t)bb * ldc + col];
+          y = __fmaf_rn(c_s, xh, c_t);
         }
+        const float v = y > 0.f ? a[reg] : 0.f;
+        C[(size_t)r * ldc + col] = v;
+        s1 += v;
+        s2 = __fmaf_rn(v, xh, s2);
       }
     }
+    return Part{s1, s2};
+  }
+  __device__ __forceinline__ Cst consts(int col, bool cok) const {
+    Cst c{0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+      if (mode == 0) c = Cst{s[col], t[col], mean[col], rstd[col]};
+      else c = Cst{gamma[col], beta[col], 0.f, 0.f};
+    }
+    return c;
+  }
+  // fp32 kernel: wave tile = two stacked 32x32 tiles, two M-waves per block
+  __device__ __forceinline__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
+    const int col = c0 + (lane & 31);
+    const bool cok = col < Nc;
+    const Cst c = consts(col, cok);
+    const Part p0 = tile(a0, r0, col, cok, lane, c), p1 = tile(a1, r0 + 32, col, cok, lane, c);
+    double s1 = (double)p0.s1 + (double)p1.s1, s2 = (double)p0.s2 + (double)p1.s2;
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     double* red = reinterpret_cast<double*>(smem);
@@ -359,6 +408,26 @@ struct EpiMaskStatsImpl : EpiMaskStats {
       double* dst = sums + ((size_t)blockIdx.x * Nc + col) * 2;
       dst[0] = s1 + red[(wn * 32 + lane) * 2];
       dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
+    }
+  }
+  // bf16 kernel: wave tile = one 32-row tile, four M-waves per block (fixed-order sum over the waves)
+  __device__ __forceinline__ void finish32(const f32x16& a, int r0, int c0, int lane, int wm, int wn, char* smem) const {
+    const int col = c0 + (lane & 31);
+    const bool cok = col < Nc;
+    const Part p0 = tile(a, r0, col, cok, lane, consts(col, cok));
+    double s1 = (double)p0.s1, s2 = (double)p0.s2;
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    double* red = reinterpret_cast<double*>(smem);
+    __syncthreads();
+    if (wm > 0 && lane < 32) { double* q = red + ((((wm - 1) * 2 + wn) * 32) + lane) * 2; q[0] = s1; q[1] = s2; }
+    __syncthreads();
+    if (wm == 0 && lane < 32 && cok) {
+      double* dst = sums + ((size_t)blockIdx.x * Nc + col) * 2;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { const double* q = red + (((w * 2 + wn) * 32) + lane) * 2; s1 += q[0]; s2 += q[1]; }
+      dst[0] = s1;
+      dst[1] = s2;
     }
   }
 };
@@ -462,6 +531,210 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
   float s = 0.f;
   for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
   out[i] = scale * s;
+}
+
+
+// ================================================================================================ bf16 MFMA flavour
+// Same operand generators and epilogues, but the tiles live in LDS as bf16 and the contraction runs on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32-input rate, fp32 accumulate).  With the matrix pipe that cheap the cost moves to
+// operand generation, so a block covers 128 rows x (64*WN) output columns: the generated A tile is reused by every
+// column of the layer (N = 257 -> one 320-wide block instead of five 64-wide ones).  LDS tiles are [row][k] with k
+// contiguous and an 80-byte pitch: 16-byte aligned rows, and each 16-lane service group of a ds_read_b128 fragment read
+// ({0-3,12-15,20-27}, ...) lands on 16 disjoint 4-bank slots (20 r mod 64).  Weights are cast to bf16 [n][k] images once
+// per call (wcast_kernel), so B staging is a 16-byte copy.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned short bfraw;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers (HIP's uint4 class went to scratch)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int LP = 40;  // LDS row pitch in bf16 elements (32 k + 8 pad)
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
+  const f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// out[n][k] (pitch Kp, zero beyond K) = transposed ? W[k][n] : W[n][k]
+__global__ __launch_bounds__(256) void wcast_kernel(const float* __restrict__ W, int ld, int Nn, int K, int Kp, int transposed,
+                                                    bfraw* __restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= (long)Nn * Kp) return;
+  const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+  auto at = [&](int kk) { return kk < K ? (transposed ? W[(size_t)kk * ld + n] : W[(size_t)n * ld + kk]) : 0.f; };
+  *reinterpret_cast<unsigned*>(out + i) = pack_bf16(at(k), at(k + 1));
+}
+
+constexpr int NTB = 512;  // 8 waves: 4 along M x 2 along N, wave tile 32 x (32*WN) -> <= 256 registers, two waves per SIMD
+
+template <class AOp, class Epi, int WN>
+__global__ __launch_bounds__(NTB) void gemm_rows_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int K, int Nc, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BNW = 64 * WN;
+  constexpr int BCH = (256 * WN + NTB - 1) / NTB;  // 16-byte B chunks per thread
+  bfraw* As = reinterpret_cast<bfraw*>(smem);  // [2][BM][LP]
+  bfraw* Bs = As + 2 * BM * LP;                // [2][BNW][LP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BNW;
+  const int kq = (tid & 7) * 4, rm = tid >> 3;  // A staging: 4 consecutive k x rows rm, rm + 64
+  typename AOp::Row rows[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = bm0 + rm + 64 * p;
+    rows[p] = aop.row(r, (r < aop.R ? r : aop.R - 1) / rows_N(aop));
+  }
+  typename AOp::Raw ra[2][4];
+  typename AOp::KC kcur[4];
+  u32x4 rb[BCH];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kcur[j] = aop.kc(k0 + kq + j);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) aop.raw4(rows[p], k0 + kq, ra[p]);
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {  // B tile = BNW rows x 4 chunks of 8 k (16 bytes)
+      const int c = tid + NTB * j, n = bn0 + (c >> 2);
+      if (c < 256 * WN) rb[j] = *reinterpret_cast<const u32x4*>(Wb + (size_t)(n < Nc ? n : Nc - 1) * Kp + k0 + (c & 3) * 8);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      u32x2 w;
+      w.x = pack_bf16(aop.fin(rows[p], kcur[0], ra[p][0]), aop.fin(rows[p], kcur[1], ra[p][1]));
+      w.y = pack_bf16(aop.fin(rows[p], kcur[2], ra[p][2]), aop.fin(rows[p], kcur[3], ra[p][3]));
+      *reinterpret_cast<u32x2*>(As + ((size_t)buf * BM + rm + 64 * p) * LP + kq) = w;
+    }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      const int c = tid + NTB * j;
+      if (c < 256 * WN) *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + (c >> 2)) * LP + (c & 3) * 8) = rb[j];
+    }
+  };
+  f32x16 acc[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int nk = (K + BK - 1) / BK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int fk = (lane >> 5) * 8, fr = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) fetch((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((size_t)cur * BM + wm * 32 + fr) * LP + ks * 16 + fk);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((size_t)cur * BNW + wn * 32 * WN + j * 32 + fr) * LP + ks * 16 + fk);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) epi.finish32(acc[j], bm0 + wm * 32, bn0 + wn * 32 * WN + j * 32, lane, wm, wn, smem);
+}
+
+// Weight gradients on the bf16 pipe: C[M x Nc] = sum_r A[r,m] B[r,n].  The contraction index is the row, so a lane's
+// fragment is 8 consecutive ROWS of one channel: each thread generates a column strip (A: one channel x 8 rows, B: WN
+// channels x 4 rows; loads stay coalesced along the channel), packs row pairs and writes 16- / 8-byte pieces of the
+// [channel][row] tile.  Row descriptors are wave-uniform (scalar registers).
+template <class AOp, class BOp, int WN>
+__global__ __launch_bounds__(NTB) void gemm_tn_bf16_kernel(AOp aop, BOp bop, int M, int Nc, int R, int rows_per_chunk, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BNW = 64 * WN;
+  bfraw* As = reinterpret_cast<bfraw*>(smem);  // [2][BM][LP]   (m, r)
+  bfraw* Bs = As + 2 * BM * LP;                // [2][BNW][LP]  (n, r)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int mt = (M + BM - 1) / BM;
+  const int bm0 = (blockIdx.x % mt) * BM, bn0 = (blockIdx.x / mt) * BNW;
+  const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
+  const int qa = __builtin_amdgcn_readfirstlane(tid >> 7);  // A: rows qa*8 .. +7 of the 32-row k-tile
+  const int gb = __builtin_amdgcn_readfirstlane(tid >> 6);  // B: rows gb*4 .. +3
+  const int ma = tid & 127, nbl = tid & 63;
+  const typename AOp::KC kca = aop.kc(bm0 + ma);
+  typename BOp::KC kcb[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) kcb[j] = bop.kc(bn0 + nbl + 64 * j);
+  typename AOp::Row rowa[8];
+  typename AOp::Raw ra[8];
+  typename BOp::Row rowb[4];
+  typename BOp::Raw rb[WN][4];
+  auto fetch = [&](int r0) {
+    const int bha = r0 / rows_N(aop), bhb = r0 / rows_N(bop);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + qa * 8 + i;
+      rowa[i] = aop.row(r < rend ? r : 0x7ffffff0, bha);
+      ra[i] = aop.raw(rowa[i], bm0 + ma);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + gb * 4 + i;
+      rowb[i] = bop.row(r < rend ? r : 0x7ffffff0, bhb);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) rb[j][i] = bop.raw(rowb[i], bn0 + nbl + 64 * j);
+    }
+  };
+  auto stash = [&](int buf) {
+    u32x4 w;
+    w.x = pack_bf16(aop.fin(rowa[0], kca, ra[0]), aop.fin(rowa[1], kca, ra[1]));
+    w.y = pack_bf16(aop.fin(rowa[2], kca, ra[2]), aop.fin(rowa[3], kca, ra[3]));
+    w.z = pack_bf16(aop.fin(rowa[4], kca, ra[4]), aop.fin(rowa[5], kca, ra[5]));
+    w.w = pack_bf16(aop.fin(rowa[6], kca, ra[6]), aop.fin(rowa[7], kca, ra[7]));
+    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + ma) * LP + qa * 8) = w;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      u32x2 v;
+      v.x = pack_bf16(bop.fin(rowb[0], kcb[j], rb[j][0]), bop.fin(rowb[1], kcb[j], rb[j][1]));
+      v.y = pack_bf16(bop.fin(rowb[2], kcb[j], rb[j][2]), bop.fin(rowb[3], kcb[j], rb[j][3]));
+      *reinterpret_cast<u32x2*>(Bs + ((size_t)buf * BNW + nbl + 64 * j) * LP + gb * 4) = v;
+    }
+  };
+  f32x16 acc[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int nk = (rend - rbeg + BK - 1) / BK;
+  if (nk > 0) {
+    fetch(rbeg);
+    stash(0);
+  }
+  __syncthreads();
+  const int fk = (lane >> 5) * 8, fr = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) fetch(rbeg + (kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((size_t)cur * BM + wm * 32 + fr) * LP + ks * 16 + fk);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((size_t)cur * BNW + wn * 32 * WN + j * 32 + fr) * LP + ks * 16 + fk);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+  }
+  float* dst = part + (size_t)blockIdx.y * M * Nc;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = bn0 + wn * 32 * WN + j * 32 + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = bm0 + wm * 32 + acc_row(reg, lane);
+      if (m < M && col < Nc) dst[(size_t)m * Nc + col] = acc[j][reg];
+    }
+  }
 }
 
 }  // namespace dec
@@ -694,33 +967,57 @@ __global__ __launch_bounds__(256) void l4_bwd_finalize_kernel(const float* __res
   if (i < 3 * C3) gW4[i] = (float)s; else gb4[i - 3 * C3] = (float)s;
 }
 
-// P[b,c] = sum_n GY1[b,n,c] (blockIdx.y = 0) ; Q[n,c] = sum_b GY1[b,n,c] (blockIdx.y = 1); thread = channel
-__global__ __launch_bounds__(256) void l1_reduce_kernel(const float* __restrict__ GY1, int ld1, int B, int N, int C1,
-                                                        float* __restrict__ P, float* __restrict__ Q) {
+// P[b,c] = sum_n GY1[b,n,c] and Q[n,c] = sum_b GY1[b,n,c] from ONE read of GY1 (the largest tensor of the backward).
+// Block = (tile of 16*S vertices, group of 16 samples, 256 channels); thread = channel (coalesced rows).  Per 16-vertex
+// sub-tile a thread issues 16 independent loads per sample and keeps 16 vertex sums + 16 sample sums in registers;
+// partial results go to Qp[group][n][c] and Pp[tile][b][c] and are summed in index order by l1_reduce2 (deterministic).
+constexpr int L1_V = 16, L1_B = 16;
+__global__ __launch_bounds__(256) void l1_reduce_kernel(const float* __restrict__ GY1, int ld1, int B, int N, int C1, int S,
+                                                        float* __restrict__ Pp, float* __restrict__ Qp) {
   const int c = blockIdx.z * 256 + threadIdx.x;
   if (c >= C1) return;
-  if (blockIdx.y == 0) {
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    float a0 = 0.f, a1 = 0.f;
-    int n = 0;
-    for (; n + 1 < N; n += 2) {
-      a0 += GY1[((size_t)b * N + n) * ld1 + c];
-      a1 += GY1[((size_t)b * N + n + 1) * ld1 + c];
+  const int tile = blockIdx.x, g = blockIdx.y, b0 = g * L1_B;
+  float pb[L1_B];
+#pragma unroll
+  for (int k = 0; k < L1_B; ++k) pb[k] = 0.f;
+  for (int sub = 0; sub < S; ++sub) {
+    const int n0 = (tile * S + sub) * L1_V;
+    if (n0 >= N) break;
+    float q[L1_V];
+#pragma unroll
+    for (int i = 0; i < L1_V; ++i) q[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < L1_B; ++k) {
+      if (b0 + k < B) {
+        const float* src = GY1 + ((size_t)(b0 + k) * N + n0) * ld1 + c;
+        float v[L1_V];
+#pragma unroll
+        for (int i = 0; i < L1_V; ++i) v[i] = n0 + i < N ? src[(size_t)i * ld1] : 0.f;
+#pragma unroll
+        for (int i = 0; i < L1_V; ++i) { q[i] += v[i]; pb[k] += v[i]; }
+      }
     }
-    if (n < N) a0 += GY1[((size_t)b * N + n) * ld1 + c];
-    P[(size_t)b * ld1 + c] = a0 + a1;
+#pragma unroll
+    for (int i = 0; i < L1_V; ++i)
+      if (n0 + i < N) Qp[((size_t)g * N + n0 + i) * ld1 + c] = q[i];
+  }
+#pragma unroll
+  for (int k = 0; k < L1_B; ++k)
+    if (b0 + k < B) Pp[((size_t)tile * B + b0 + k) * ld1 + c] = pb[k];
+}
+// rows 0..B-1: P[b,c] = sum_tile Pp[tile][b][c]; rows B..B+N-1: Q[n,c] = sum_group Qp[group][n][c]
+__global__ __launch_bounds__(256) void l1_reduce2_kernel(const float* __restrict__ Pp, const float* __restrict__ Qp, int ld1, int B, int N,
+                                                         int C1, int tiles, int groups, float* __restrict__ P, float* __restrict__ Q) {
+  const int c = blockIdx.y * 256 + threadIdx.x, row = blockIdx.x;
+  if (c >= C1) return;
+  float s = 0.f;
+  if (row < B) {
+    for (int t = 0; t < tiles; ++t) s += Pp[((size_t)t * B + row) * ld1 + c];
+    P[(size_t)row * ld1 + c] = s;
   } else {
-    const int n = blockIdx.x;
-    if (n >= N) return;
-    float a0 = 0.f, a1 = 0.f;
-    int b = 0;
-    for (; b + 1 < B; b += 2) {
-      a0 += GY1[((size_t)b * N + n) * ld1 + c];
-      a1 += GY1[((size_t)(b + 1) * N + n) * ld1 + c];
-    }
-    if (b < B) a0 += GY1[((size_t)b * N + n) * ld1 + c];
-    Q[(size_t)n * ld1 + c] = a0 + a1;
+    const int n = row - B;
+    for (int g = 0; g < groups; ++g) s += Qp[((size_t)g * N + n) * ld1 + c];
+    Q[(size_t)n * ld1 + c] = s;
   }
 }
 
@@ -824,14 +1121,18 @@ using namespace dec;
 
 struct Dims {
   int B, N, C1, C2, C3, ld1, ld2, ld3, rb;  // rb = row blocks of the rows-GEMMs
+  int bf16;                                 // contraction on the bf16 matrix pipe (operands rounded to bf16, fp32 accumulate)
   long R;
 };
+inline int kpad(int K) { return (K + BK - 1) / BK * BK; }       // k extent of a bf16 weight image (zero padded)
+inline int wide_wn(int Nc) { return Nc > 128 ? 5 : 2; }          // 32-column MFMA tiles per wave of the bf16 kernels
 Dims dims_of(const obman_pointgen_params* p) {
   Dims d;
   d.B = p->B; d.N = p->N; d.C1 = p->C1; d.C2 = p->C1 / 2; d.C3 = p->C1 / 4;
   d.ld1 = pad16(d.C1); d.ld2 = pad16(d.C2); d.ld3 = pad16(d.C3);
   d.R = (long)d.B * d.N;
   d.rb = (int)((d.R + BM - 1) / BM);
+  d.bf16 = p->mfma_bf16 ? 1 : 0;
   return d;
 }
 constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 blocks at 64 x 642 points)
@@ -839,7 +1140,7 @@ constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gra
 
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
-  long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, total;
+  long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, wb2, wb3, total;
 };
 FwdWs fwd_ws(const Dims& d) {
   FwdWs w; long o = 0;
@@ -848,20 +1149,35 @@ FwdWs fwd_ws(const Dims& d) {
   w.H2 = take(d.R * d.ld2); w.mean2 = take(d.ld2); w.rstd2 = take(d.ld2); w.s2 = take(d.ld2); w.t2 = take(d.ld2);
   w.H3 = take(d.R * d.ld3); w.mean3 = take(d.ld3); w.rstd3 = take(d.ld3); w.s3 = take(d.ld3); w.t3 = take(d.ld3);
   w.moments = take((long)d.rb * d.C2 * 2 * 2);  // doubles
+  w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
+  w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
   w.total = o;
   return w;
 }
 // rows per split-K chunk: enough chunks that tiles x chunks covers the chip ~4x, never below 128 rows
-int tn_chunk_rows(int M, int Nc, long R) {
-  const long tiles = (long)((M + BM - 1) / BM) * ((Nc + BN - 1) / BN);
-  long want = (1024 + tiles - 1) / tiles;                 // chunks wanted
+int tn_chunk_rows(int M, int Nc, long R, int bn = BN) {
+  const long tiles = (long)((M + BM - 1) / BM) * ((Nc + bn - 1) / bn);
+  const long blocks = bn > BN ? 512 : 1024;               // wide (bf16) tiles: a block is 5x the work and writes 5x the partial
+  long want = (blocks + tiles - 1) / tiles;               // chunks wanted
   long rows = (R + want - 1) / want;
   rows = (rows + BK - 1) / BK * BK;
   if (rows < 128) rows = 128;
   return (int)rows;
 }
+// l1_reduce geometry: vertex sub-tiles per block such that tiles x sample-groups x channel-tiles ~ 1024 blocks
+struct L1Geo { int S, tiles, groups; };
+L1Geo l1_geo(const Dims& d) {
+  L1Geo g;
+  g.groups = (d.B + L1_B - 1) / L1_B;
+  const int sub = (d.N + L1_V - 1) / L1_V, ct = (d.C1 + 255) / 256;
+  const int want = 1024 / (g.groups * ct) > 0 ? 1024 / (g.groups * ct) : 1;
+  g.S = (sub + want - 1) / want;
+  if (g.S < 1) g.S = 1;
+  g.tiles = (sub + g.S - 1) / g.S;
+  return g;
+}
 struct BwdWs {
-  long GY2, GY1, sums, k, l4p, P, Q, dF, dG, tn, total;
+  long GY2, GY1, sums, k, l4p, P, Q, Pp, Qp, dF, dG, tn, wt2, wt3, total;
   int chunks;
 };
 BwdWs bwd_ws(const Dims& d) {
@@ -874,9 +1190,13 @@ BwdWs bwd_ws(const Dims& d) {
   w.k = take(3 * d.ld1);
   w.l4p = take((long)l4b * (3 * d.C3 + 4));
   w.P = take((long)d.B * d.ld1); w.Q = take((long)d.N * d.ld1); w.dF = take((long)d.B * d.ld1); w.dG = take((long)d.N * d.ld1);
+  {
+    const L1Geo g = l1_geo(d);
+    w.Pp = take((long)g.tiles * d.B * d.ld1); w.Qp = take((long)g.groups * d.N * d.ld1);
+  }
   {  // split-K partials: the largest of the three weight-gradient products
     auto need = [&](int M, int Nc, long R) {
-      const int rows = tn_chunk_rows(M, Nc, R);
+      const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * wide_wn(Nc) : BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
     };
     long a = need(d.C3, d.C2, d.R), b = need(d.C2, d.C1, d.R), c = need(d.C1, d.C1 - 3, d.B);
@@ -884,6 +1204,8 @@ BwdWs bwd_ws(const Dims& d) {
     if (c > a) a = c;
     w.tn = take(a);
   }
+  w.wt2 = take(d.bf16 ? ((long)d.C1 * kpad(d.C2) + 1) / 2 : 0);  // bf16 [C1][kpad(C2)] image of W2^T (dA GEMM of layer 2)
+  w.wt3 = take(d.bf16 ? ((long)d.C2 * kpad(d.C3) + 1) / 2 : 0);
   w.total = o;
   return w;
 }
@@ -906,6 +1228,51 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* out, hipStream_t st) {
+  const int Kp = kpad(K);
+  wcast_kernel<<<obman_cdiv((long)Nn * Kp / 2, 256), 256, 0, st>>>(W, ld, Nn, K, Kp, transposed, out);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+template <class AOp, class Epi, int WN>
+int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw);
+  static const int once = [] {
+    return (int)hipFuncSetAttribute((const void*)gemm_rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * (BM + 64 * WN) * LP * (int)sizeof(bfraw));
+  }();
+  if (once) return once;
+  dim3 grid((unsigned)((R + BM - 1) / BM), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
+  gemm_rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, kpad(K), K, Nc, e);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+template <class AOp, class Epi>
+int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
+  return wide_wn(Nc) == 5 ? launch_rows_bf16_wn<AOp, Epi, 5>(a, Wb, K, Nc, R, e, st) : launch_rows_bf16_wn<AOp, Epi, 2>(a, Wb, K, Nc, R, e, st);
+}
+template <class AOp, class BOp, int WN>
+int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, float* part, float* out, int ldo, int off, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw);
+  static const int once = [] {
+    return (int)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * (BM + 64 * WN) * LP * (int)sizeof(bfraw));
+  }();
+  if (once) return once;
+  const int chunk_rows = tn_chunk_rows(M, Nc, R, 64 * WN);
+  const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
+  dim3 grid((unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))), (unsigned)chunks);
+  gemm_tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, (int)R, chunk_rows, part);
+  OBMAN_LAUNCH_CHECK();
+  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+template <class AOp, class BOp>
+int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, float* part, float* out, int ldo, int off, hipStream_t st) {
+  return wide_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, part, out, ldo, off, st)
+                          : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, part, out, ldo, off, st);
 }
 bool params_ok(const obman_pointgen_params* p) {
   return p && p->B > 0 && p->N > 0 && p->C1 >= 8 && p->C1 / 4 <= 128 && p->grid && p->feat && p->w1 && p->w2 && p->w3 && p->w4;
@@ -940,7 +1307,14 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
     AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1};
     EpiStoreImpl e;
     e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
-    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
+    int rc;
+    if (d.bf16) {
+      bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
+      rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st);
+      if (!rc) rc = launch_rows_bf16<AGridFeat, EpiStoreImpl>(a, wb, d.C1, d.C2, d.R, e, st);
+    } else {
+      rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
+    }
     if (rc) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(moments, d.rb, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
                                                                p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
@@ -950,7 +1324,14 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
     ABnRelu a{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, (int)d.R, d.C2};
     EpiStoreImpl e;
     e.C = ws + w.H3; e.bias = p->b3; e.moments = tr ? moments : nullptr; e.ldc = d.ld3; e.R = (int)d.R; e.Nc = d.C3;
-    int rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
+    int rc;
+    if (d.bf16) {
+      bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb3);
+      rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st);
+      if (!rc) rc = launch_rows_bf16<ABnRelu, EpiStoreImpl>(a, wb, d.C2, d.C3, d.R, e, st);
+    } else {
+      rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
+    }
     if (rc) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(moments, d.rb, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
@@ -987,7 +1368,8 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
   int rc;
   {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
     ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
-    rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st);
+    rc = d.bf16 ? launch_tn_bf16<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, ws2 + v.tn, g->w3, d.C2, 0, st)
+                : launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st);
     if (rc) return rc;
   }
   {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
@@ -995,7 +1377,13 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
     e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
     e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N;
-    rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st);
+    if (d.bf16) {  // B[k = out channel][n = in channel] = W3[k][n]: the transposed image
+      bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt3);
+      rc = launch_wcast(p->w3, d.C2, d.C2, d.C3, 1, wt, st);
+      if (!rc) rc = launch_rows_bf16<AGradH3, EpiMaskStatsImpl>(gh3, wt, d.C3, d.C2, d.R, e, st);
+    } else {
+      rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st);
+    }
     if (rc) return rc;
   }
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sums, d.rb, d.R, d.C2, tr, p->bn_w[1], ws + w.rstd2, g->bn_w[1], g->bn_b[1],
@@ -1003,20 +1391,33 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
   OBMAN_LAUNCH_CHECK();
   AGradH gh2{ws2 + v.GY2, ws + w.H2, ws + w.mean2, ws + w.rstd2, k1, k2, k3, d.ld2, R, d.C2};
   AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1};
-  rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st);  // gW2[o,c]
+  rc = d.bf16 ? launch_tn_bf16<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, ws2 + v.tn, g->w2, d.C1, 0, st)  // gW2[o,c]
+              : launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st);
   if (rc) return rc;
   {  // gy1 = (gh2 W2) * (y1 > 0)
     EpiMaskStatsImpl e;
     e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
     e.H = e.s = e.t = e.mean = e.rstd = nullptr;
     e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N;
-    rc = launch_rows<AGradH, false, EpiMaskStatsImpl>(gh2, p->w2, d.C1, d.C2, d.C1, d.R, e, st);
+    if (d.bf16) {
+      bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt2);
+      rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st);
+      if (!rc) rc = launch_rows_bf16<AGradH, EpiMaskStatsImpl>(gh2, wt, d.C2, d.C1, d.R, e, st);
+    } else {
+      rc = launch_rows<AGradH, false, EpiMaskStatsImpl>(gh2, p->w2, d.C1, d.C2, d.C1, d.R, e, st);
+    }
     if (rc) return rc;
   }
   // ---- layer 1 in factored form
-  l1_reduce_kernel<<<dim3(d.B > d.N ? d.B : d.N, 2, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, ws2 + v.P,
-                                                                                            ws2 + v.Q);
-  OBMAN_LAUNCH_CHECK();
+  {
+    const L1Geo lg = l1_geo(d);
+    l1_reduce_kernel<<<dim3(lg.tiles, lg.groups, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, lg.S, ws2 + v.Pp,
+                                                                                         ws2 + v.Qp);
+    OBMAN_LAUNCH_CHECK();
+    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, lg.tiles, lg.groups,
+                                                                                ws2 + v.P, ws2 + v.Q);
+    OBMAN_LAUNCH_CHECK();
+  }
   l1_finalize_kernel<<<obman_cdiv(d.C1, 64), 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
                                                              ws + w.rstd1, p->grid, g->bn_w[0], g->bn_b[0], g->b1, g->w1, ws2 + v.dF, ws2 + v.dG);
   OBMAN_LAUNCH_CHECK();

@@ -34,6 +34,7 @@ class PointGenCon(nn.Module):
         super().__init__()
         c = int(bottleneck_size)
         self.bottleneck_size, self.use_tanh, self.out_factor = c, use_tanh, out_factor
+        self.mfma_dtype = "f32"  # extension: "bf16" runs decode()'s contractions on the bf16 matrix pipe (ops.pointgen_decode)
         self.conv1 = nn.Conv1d(c, c, 1)
         self.conv2 = nn.Conv1d(c, c // 2, 1)
         self.conv3 = nn.Conv1d(c // 2, c // 4, 1)

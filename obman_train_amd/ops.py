@@ -251,7 +251,7 @@ class _PointGen(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat, grid, w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3, running, cfg):
-        training, eps, momentum, out_factor = cfg
+        training, eps, momentum, out_factor, mfma_bf16 = cfg
         feat, grid = _dev(feat, "features"), _dev(grid, "grid")
         tensors = [_dev(t, "decoder parameter") for t in (w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3)]
         B, N, C1 = feat.shape[0], grid.shape[0], w1.shape[0]
@@ -260,6 +260,7 @@ class _PointGen(torch.autograd.Function):
         p = _lib.PointGenParams()
         p.B, p.N, p.C1, p.training = B, N, C1, int(training)
         p.eps, p.momentum, p.out_factor = float(eps), float(momentum), float(out_factor)
+        p.mfma_bf16 = int(bool(mfma_bf16))
         p.grid, p.feat = grid.data_ptr(), feat.data_ptr()
         for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4"), tensors[:8]):
             setattr(p, name, t.data_ptr())
@@ -301,8 +302,15 @@ class _PointGen(torch.autograd.Function):
         return (g_feat, None, *grads, None, None)
 
 
-def pointgen_decode(decoder, features, grid):
-    """decoder: PointGenCon-like module (conv1..4, bn1..3, out_factor); features [B,C], grid [N,3] -> [B,N,3]."""
+def pointgen_decode(decoder, features, grid, mfma_dtype=None):
+    """decoder: PointGenCon-like module (conv1..4, bn1..3, out_factor); features [B,C], grid [N,3] -> [B,N,3].
+
+    mfma_dtype (default: the module's ``mfma_dtype`` attribute, else "f32"): "f32" = exact fp32 MFMA contraction;
+    "bf16" = GEMM operands rounded to bf16 on the fly (fp32 master weights, fp32 accumulation, fp32 BatchNorm
+    statistics) on ``v_mfma_f32_32x32x16_bf16`` - the BASELINE configs[2] flavour."""
+    mfma_dtype = mfma_dtype or getattr(decoder, "mfma_dtype", "f32")
+    if mfma_dtype not in ("f32", "bf16"):
+        raise ValueError("mfma_dtype must be 'f32' or 'bf16', got %r" % (mfma_dtype,))
     bns = (decoder.bn1, decoder.bn2, decoder.bn3)
     training = decoder.training or any(bn.running_mean is None for bn in bns)
     running = []
@@ -321,7 +329,7 @@ def pointgen_decode(decoder, features, grid):
         args += [c.weight.view(c.weight.shape[0], c.weight.shape[1]), c.bias]
     for bn in bns:
         args += [bn.weight, bn.bias]
-    out = _PointGen.apply(features, grid, *args, tuple(running), (training, bns[0].eps, momentum, decoder.out_factor))
+    out = _PointGen.apply(features, grid, *args, tuple(running), (training, bns[0].eps, momentum, decoder.out_factor, mfma_dtype == "bf16"))
     if decoder.training:
         with torch.no_grad():
             for bn in bns:

@@ -155,8 +155,12 @@ def bench_decoder():
     from obman_train_amd.icosphere import multi_patch
     from obman_train_amd.networks.branches.atlasutils import PointGenCon
 
-    for B, patches in ((64, 1),):
+    cases = [(64, 1, "f32"), (64, 1, "bf16")]
+    if os.environ.get("OBMAN_KBENCH_C3"):  # configs[2]: 25 patches
+        cases += [(64, 25, "f32"), (64, 25, "bf16")]
+    for B, patches, mode in cases:
         dec = PointGenCon(bottleneck_size=515).cuda().train()
+        dec.mfma_dtype = mode
         grid = torch.from_numpy(multi_patch(3, patches)[0].astype(np.float32)).cuda()
         feats = torch.randn(B, 512, device="cuda").requires_grad_()
         t_f = kernel_us(lambda: ops.pointgen_decode(dec, feats, grid), 8, iters=10, warmup=3)
@@ -169,7 +173,7 @@ def bench_decoder():
         t_b = kernel_us(lambda: torch.autograd.grad(loss, params, retain_graph=True), 9, iters=10, warmup=3)
         R = B * grid.shape[0]
         flop_f = 2.0 * R * (515 * 257 + 257 * 128 + 128 * 3)
-        print(json.dumps(dict(kernel="decoder", B=B, N=int(grid.shape[0]), fwd_us=round(t_f, 1), bwd_us=round(t_b, 1),
+        print(json.dumps(dict(kernel="decoder", mfma=mode, B=B, N=int(grid.shape[0]), fwd_us=round(t_f, 1), bwd_us=round(t_b, 1),
                               fwd_TFLOPs=round(flop_f / t_f / 1e6, 1), bwd_TFLOPs=round(2 * flop_f / t_b / 1e6, 1))), flush=True)
 
 
