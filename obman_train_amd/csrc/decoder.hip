@@ -97,18 +97,21 @@ struct APlain {  // a[r,k] = X[r,k]
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const { return (w.ok && c.ok) ? x.x : 0.f; }
 };
 // d(loss)/d(h) of a BatchNorm'd layer from the masked upstream gradient gy = d/d(y) * (y>0):
-//   train: gh = k1 * (gy - k2 - xhat * k3),  k1 = gamma*rstd, k2 = mean_r(gy), k3 = mean_r(gy*xhat)
-//   eval : gh = k1 * gy                       (k2 = k3 = 0)
+//   train: gh = k1 * (gy - k2 - xhat * k3),  k1 = gamma*rstd, k2 = mean_r(gy), k3 = mean_r(gy*xhat),  xhat = (h - mean) * rstd
+//   eval : gh = k1 * gy
+// bn_bwd_finalize_kernel folds this per channel into the affine form gh = ka * gy + kb * h + kc
+//   ka = k1,  kb = -k1 * rstd * k3,  kc = k1 * (mean * rstd * k3 - k2)        (kb = kc = 0 in eval)
+// so an operand element costs two FMAs and three per-channel constants.
 struct AGradH {  // gy materialised
-  const float *GY, *H, *mean, *rstd, *k1, *k2, *k3;
+  const float *GY, *H, *ka, *kb, *kc_;
   int ld, R, K;
   struct Row { long o; bool ok; };
-  struct KC { float m, rs, k1, k2, k3; bool ok; };
+  struct KC { float a, b, c; bool ok; };
   struct Raw { float gy, h; };
   __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
   __device__ KC kc(int k) const {
     const bool ok = k < K; const int c = ok ? k : 0;
-    return KC{mean[c], rstd[c], k1[c], k2[c], k3[c], ok};
+    return KC{ka[c], kb[c], kc_[c], ok};
   }
   __device__ Raw raw(const Row& w, int k) const { const int c = k < K ? k : 0; return Raw{GY[w.o + c], H[w.o + c]}; }
   __device__ void raw4(const Row& w, int k, Raw* o) const {
@@ -117,16 +120,16 @@ struct AGradH {  // gy materialised
     o[0] = Raw{a.x, b.x}; o[1] = Raw{a.y, b.y}; o[2] = Raw{a.z, b.z}; o[3] = Raw{a.w, b.w};
   }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
-    const float v = c.k1 * (x.gy - c.k2 - (x.h - c.m) * c.rs * c.k3);
+    const float v = __fmaf_rn(c.a, x.gy, __fmaf_rn(c.b, x.h, c.c));
     return (w.ok && c.ok) ? v : 0.f;
   }
 };
 struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o] = f*(g[r,:].W4[:,o]) * (y3 > 0)
-  const float *G, *W4, *H, *s, *t, *mean, *rstd, *k1, *k2, *k3;
+  const float *G, *W4, *H, *s, *t, *ka, *kb, *kc_;
   float f;
   int ld, R, K;
   struct Row { long o; float g0, g1, g2; bool ok; };
-  struct KC { float s, t, m, rs, k1, k2, k3, w0, w1, w2; bool ok; };
+  struct KC { float s, t, a, b, c, w0, w1, w2; bool ok; };
   struct Raw { float h; };
   __device__ Row row(int r, int) const {
     const bool ok = r < R;
@@ -135,7 +138,7 @@ struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o
   }
   __device__ KC kc(int k) const {
     const bool ok = k < K; const int c = ok ? k : 0;
-    return KC{s[c], t[c], mean[c], rstd[c], k1[c], k2[c], k3[c], W4[c], W4[K + c], W4[2 * K + c], ok};
+    return KC{s[c], t[c], ka[c], kb[c], kc_[c], W4[c], W4[K + c], W4[2 * K + c], ok};
   }
   __device__ Raw raw(const Row& w, int k) const { return Raw{H[w.o + (k < K ? k : 0)]}; }
   __device__ void raw4(const Row& w, int k, Raw* o) const {
@@ -144,7 +147,7 @@ struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o
   }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
     const float gy = __fmaf_rn(c.s, x.h, c.t) > 0.f ? (w.g0 * c.w0 + w.g1 * c.w1 + w.g2 * c.w2) : 0.f;
-    const float v = c.k1 * (gy - c.k2 - (x.h - c.m) * c.rs * c.k3);
+    const float v = __fmaf_rn(c.a, gy, __fmaf_rn(c.b, x.h, c.c));
     return (w.ok && c.ok) ? v : 0.f;
   }
 };
@@ -314,34 +317,53 @@ struct EpiStoreImpl : EpiStore {
       }
     }
   }
-  // bf16 kernel: one 32-row tile per wave, four M-waves per block (fixed-order sum over the waves)
-  __device__ __forceinline__ void finish32(const f32x16& a, int r0, int c0, int lane, int wm, int wn, char* smem) const {
-    const int col = c0 + (lane & 31);
-    const float bv = (bias && col < Nc) ? bias[col] : 0.f;
-    double s1 = 0.0, s2 = 0.0;
+  // bf16 kernel: a wave owns 32 rows x WN column tiles (c0 + 32 j); four M-waves per block, summed in wave order.
+  // Row addresses are formed once per accumulator row and shared by the WN tiles.
+  template <int WN>
+  __device__ __forceinline__ void finish_wide(const f32x16 (&acc)[WN], int r0, int c0, int lane, int wm, int wn, char* smem) const {
+    const int cl = c0 + (lane & 31);
+    float bv[WN];
+    double s1[WN], s2[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) { bv[j] = (bias && cl + 32 * j < Nc) ? bias[cl + 32 * j] : 0.f; s1[j] = 0.0; s2[j] = 0.0; }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int r = r0 + acc_row(reg, lane);
-      const float v = a[reg] + bv;
-      if (r < R && col < Nc) {
-        C[(size_t)r * ldc + col] = v;
-        s1 += (double)v;
-        s2 += (double)v * (double)v;
+      if (r < R) {
+        float* crow = C + (size_t)r * ldc + cl;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          if (cl + 32 * j < Nc) {
+            const float v = acc[j][reg] + bv[j];
+            crow[32 * j] = v;
+            s1[j] += (double)v;
+            s2[j] += (double)v * (double)v;
+          }
+        }
       }
     }
     if (moments) {
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      double* red = reinterpret_cast<double*>(smem);
-      __syncthreads();
-      if (wm > 0 && lane < 32) { double* q = red + ((((wm - 1) * 2 + wn) * 32) + lane) * 2; q[0] = s1; q[1] = s2; }
-      __syncthreads();
-      if (wm == 0 && lane < 32 && col < Nc) {
-        double* dst = moments + ((size_t)blockIdx.x * Nc + col) * 2;
+      double* red = reinterpret_cast<double*>(smem);  // [3 waves][2 wn][WN][32 lanes][2]
 #pragma unroll
-        for (int w = 0; w < 3; ++w) { const double* q = red + (((w * 2 + wn) * 32) + lane) * 2; s1 += q[0]; s2 += q[1]; }
-        dst[0] = s1;
-        dst[1] = s2;
+      for (int j = 0; j < WN; ++j) { s1[j] += __shfl_xor(s1[j], 32, 64); s2[j] += __shfl_xor(s2[j], 32, 64); }
+      __syncthreads();
+      if (wm > 0 && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) { double* q = red + (((((wm - 1) * 2 + wn) * WN + j) * 32) + lane) * 2; q[0] = s1[j]; q[1] = s2[j]; }
+      }
+      __syncthreads();
+      if (wm == 0 && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          if (cl + 32 * j < Nc) {
+            double a = s1[j], b = s2[j];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) { const double* q = red + ((((w * 2 + wn) * WN + j) * 32) + lane) * 2; a += q[0]; b += q[1]; }
+            double* dst = moments + ((size_t)blockIdx.x * Nc + cl + 32 * j) * 2;
+            dst[0] = a;
+            dst[1] = b;
+          }
+        }
       }
     }
   }
@@ -410,24 +432,74 @@ struct EpiMaskStatsImpl : EpiMaskStats {
       dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
     }
   }
-  // bf16 kernel: wave tile = one 32-row tile, four M-waves per block (fixed-order sum over the waves)
-  __device__ __forceinline__ void finish32(const f32x16& a, int r0, int c0, int lane, int wm, int wn, char* smem) const {
-    const int col = c0 + (lane & 31);
-    const bool cok = col < Nc;
-    const Part p0 = tile(a, r0, col, cok, lane, consts(col, cok));
-    double s1 = (double)p0.s1, s2 = (double)p0.s2;
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    double* red = reinterpret_cast<double*>(smem);
-    __syncthreads();
-    if (wm > 0 && lane < 32) { double* q = red + ((((wm - 1) * 2 + wn) * 32) + lane) * 2; q[0] = s1; q[1] = s2; }
-    __syncthreads();
-    if (wm == 0 && lane < 32 && cok) {
-      double* dst = sums + ((size_t)blockIdx.x * Nc + col) * 2;
+  // bf16 kernel: a wave owns 32 rows x WN column tiles; row addresses and the (sample, vertex) split are formed once per
+  // accumulator row and shared by the WN tiles; one barrier pair for all tiles; four M-waves summed in wave order.
+  template <int WN>
+  __device__ __forceinline__ void finish_wide(const f32x16 (&acc)[WN], int r0, int c0, int lane, int wm, int wn, char* smem) const {
+    const int cl = c0 + (lane & 31);
+    Cst cst[WN];
+    float s1[WN], s2[WN];
 #pragma unroll
-      for (int w = 0; w < 3; ++w) { const double* q = red + (((w * 2 + wn) * 32) + lane) * 2; s1 += q[0]; s2 += q[1]; }
-      dst[0] = s1;
-      dst[1] = s2;
+    for (int j = 0; j < WN; ++j) { cst[j] = consts(cl + 32 * j, cl + 32 * j < Nc); s1[j] = 0.f; s2[j] = 0.f; }
+    const int rb = r0 + 4 * (lane >> 5);
+    int b = 0, n = 0;
+    if (mode != 0) { b = rb / N; n = rb - b * N; }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int off = (reg & 3) + 8 * (reg >> 2);
+      const int r = rb + off;
+      int bb = b, nn = n + off;
+      if (mode != 0) while (nn >= N) { nn -= N; ++bb; }
+      if (r < R) {
+        const size_t ro = (size_t)r * ldc + cl;
+        float* crow = C + ro;
+        const float* p0 = mode == 0 ? H + ro : Gx + (size_t)nn * ldc + cl;
+        const float* p1 = mode == 0 ? p0 : Fx + (size_t)bb * ldc + cl;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          if (cl + 32 * j < Nc) {
+            float xh, y;
+            if (mode == 0) {
+              const float h = p0[32 * j];
+              y = __fmaf_rn(cst[j].s, h, cst[j].t);
+              xh = (h - cst[j].m) * cst[j].r;
+            } else {
+              xh = p0[32 * j] + p1[32 * j];
+              y = __fmaf_rn(cst[j].s, xh, cst[j].t);
+            }
+            const float v = y > 0.f ? acc[j][reg] : 0.f;
+            crow[32 * j] = v;
+            s1[j] += v;
+            s2[j] = __fmaf_rn(v, xh, s2[j]);
+          }
+        }
+      }
+    }
+    double d1[WN], d2[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      d1[j] = (double)s1[j]; d2[j] = (double)s2[j];
+      d1[j] += __shfl_xor(d1[j], 32, 64); d2[j] += __shfl_xor(d2[j], 32, 64);
+    }
+    double* red = reinterpret_cast<double*>(smem);  // [3 waves][2 wn][WN][32 lanes][2]
+    __syncthreads();
+    if (wm > 0 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) { double* q = red + (((((wm - 1) * 2 + wn) * WN + j) * 32) + lane) * 2; q[0] = d1[j]; q[1] = d2[j]; }
+    }
+    __syncthreads();
+    if (wm == 0 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        if (cl + 32 * j < Nc) {
+          double a = d1[j], bsum = d2[j];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { const double* q = red + ((((w * 2 + wn) * WN + j) * 32) + lane) * 2; a += q[0]; bsum += q[1]; }
+          double* dst = sums + ((size_t)blockIdx.x * Nc + cl + 32 * j) * 2;
+          dst[0] = a;
+          dst[1] = bsum;
+        }
+      }
     }
   }
 };
@@ -637,8 +709,7 @@ __global__ __launch_bounds__(NTB) void gemm_rows_bf16_kernel(AOp aop, const bfra
     if (more) stash(cur ^ 1);
     __syncthreads();
   }
-#pragma unroll
-  for (int j = 0; j < WN; ++j) epi.finish32(acc[j], bm0 + wm * 32, bn0 + wn * 32 * WN + j * 32, lane, wm, wn, smem);
+  epi.template finish_wide<WN>(acc, bm0 + wm * 32, bn0 + wn * 32 * WN, lane, wm, wn, smem);
 }
 
 // Weight gradients on the bf16 pipe: C[M x Nc] = sum_r A[r,m] B[r,n].  The contraction index is the row, so a lane's
@@ -933,10 +1004,12 @@ __global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G
   }
 }
 
-// sums [blocks][C][2] -> g_gamma = S2, g_beta = S1, gh coefficients k1 = gamma*rstd, k2 = S1/R, k3 = S2/R (0 in eval),
+// sums [blocks][C][2] -> g_gamma = S2, g_beta = S1, and the affine gh coefficients (see AGradH): with k1 = gamma*rstd,
+// k2 = S1/R, k3 = S2/R (0 in eval):  ka = k1, kb = -k1*rstd*k3, kc = k1*(mean*rstd*k3 - k2), formed in fp64.
 // conv-bias gradient gb = sum_r gh = (train ? 0 : k1*S1).  One wave per channel.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ sums, int blocks, long R, int C, int training,
-                                                              const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
                                                               float* __restrict__ g_gamma, float* __restrict__ g_beta,
                                                               float* __restrict__ g_bias, float* __restrict__ k1,
                                                               float* __restrict__ k2, float* __restrict__ k3) {
@@ -949,9 +1022,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   g_gamma[c] = (float)s2;
   g_beta[c] = (float)s1;
   const float kk = gamma[c] * rstd[c];
-  k1[c] = kk;
-  k2[c] = training ? (float)(s1 / R) : 0.f;
-  k3[c] = training ? (float)(s2 / R) : 0.f;
+  const double m2 = training ? s1 / (double)R : 0.0, m3 = training ? s2 / (double)R : 0.0, rs = (double)rstd[c];
+  k1[c] = kk;                                                  // ka
+  k2[c] = (float)(-(double)kk * rs * m3);                      // kb
+  k3[c] = (float)((double)kk * ((double)mean[c] * rs * m3 - m2));  // kc
   if (g_bias) g_bias[c] = training ? 0.f : kk * (float)s1;
 }
 
@@ -1361,10 +1435,10 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
                                       L4_ROWS, sums, ws2 + v.l4p);
   OBMAN_LAUNCH_CHECK();
   l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 4), 256, 0, st>>>(ws2 + v.l4p, l4b, d.C3, g->w4, g->b4);
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sums, l4b, d.R, d.C3, tr, p->bn_w[2], ws + w.rstd3, g->bn_w[2], g->bn_b[2],
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sums, l4b, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2], g->bn_b[2],
                                                                  g->b3, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
-  AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, k1, k2, k3, f, d.ld3, R, d.C3};
+  AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
   int rc;
   {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
     ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
@@ -1386,10 +1460,10 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     }
     if (rc) return rc;
   }
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sums, d.rb, d.R, d.C2, tr, p->bn_w[1], ws + w.rstd2, g->bn_w[1], g->bn_b[1],
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sums, d.rb, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
-  AGradH gh2{ws2 + v.GY2, ws + w.H2, ws + w.mean2, ws + w.rstd2, k1, k2, k3, d.ld2, R, d.C2};
+  AGradH gh2{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, R, d.C2};
   AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1};
   rc = d.bf16 ? launch_tn_bf16<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, ws2 + v.tn, g->w2, d.C1, 0, st)  // gW2[o,c]
               : launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st);

@@ -158,6 +158,9 @@ def bench_decoder():
     cases = [(64, 1, "f32"), (64, 1, "bf16")]
     if os.environ.get("OBMAN_KBENCH_C3"):  # configs[2]: 25 patches
         cases += [(64, 25, "f32"), (64, 25, "bf16")]
+    if os.environ.get("OBMAN_KBENCH_DEC"):  # e.g. "bf16:25" = one case (for profiling)
+        mode, patches = os.environ["OBMAN_KBENCH_DEC"].split(":")
+        cases = [(64, int(patches), mode)]
     for B, patches, mode in cases:
         dec = PointGenCon(bottleneck_size=515).cuda().train()
         dec.mfma_dtype = mode
