@@ -183,15 +183,31 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
 // except on exact ties of positive values; ties at 0 carry no gradient through the ReLU either way).
 struct PoolGeo { int H, W, Ho, Wo; };
 
+// (sample, row, column) of a flat pixel index, advanced incrementally: the 64-bit div/mod per 16-byte access this
+// replaces cost more than the access (pool kernels ran at 2-3 TB/s).
+struct Pix { int b, h, w; };
+__device__ __forceinline__ Pix pix_of(long r, int H, int W) {
+  const int rr = (int)r, t = rr / W;
+  return Pix{t / H, t % H, rr - t * W};
+}
+__device__ __forceinline__ void pix_advance(Pix& p, int step, int H, int W) {
+  p.w += step;
+  while (p.w >= W) {
+    p.w -= W;
+    if (++p.h == H) { p.h = 0; ++p.b; }
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ X, const float* __restrict__ sc, const float* __restrict__ sh,
                                                        Geo g, PoolGeo pg, float* __restrict__ Yp) {
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.y * CT + cl * 4;
   const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);  // rows = pooled pixels
   const float4 vs = *reinterpret_cast<const float4*>(sc + c), vt = *reinterpret_cast<const float4*>(sh + c);
-  for (long r = r0 + rl; r < r1; r += 16) {
-    const int wo = (int)(r % pg.Wo), ho = (int)((r / pg.Wo) % pg.Ho);
-    const long b = r / ((long)pg.Wo * pg.Ho);
+  Pix px = pix_of(r0 + rl, pg.Ho, pg.Wo);
+  for (long r = r0 + rl; r < r1; r += 16, pix_advance(px, 16, pg.Ho, pg.Wo)) {
+    const int wo = px.w, ho = px.h;
+    const long b = px.b;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // relu >= 0 and the window centre is always in bounds
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
@@ -247,9 +263,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     k3 = *reinterpret_cast<const float4*>(k + 2 * g.C + c);
   }
   float4 a = make_float4(0, 0, 0, 0), bb = a;
-  for (long r = r0 + rl; r < r1; r += 16) {
-    const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
-    const long b = r / ((long)pg.W * pg.H);
+  Pix px = pix_of(r0 + rl, pg.H, pg.W);
+  for (long r = r0 + rl; r < r1; r += 16, pix_advance(px, 16, pg.H, pg.W)) {
+    const int w = px.w, h = px.h;
+    const long b = px.b;
     const size_t o = (size_t)r * g.C + c;
     const float4 x = *reinterpret_cast<const float4*>(X + o);
     const float4 y = make_float4(fmaxf(__fmaf_rn(vs.x, x.x, vt.x), 0.f), fmaxf(__fmaf_rn(vs.y, x.y, vt.y), 0.f),
@@ -356,6 +373,7 @@ int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float
 int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
                      int training, float eps, float momentum, float* y_pool, float* stats, float* ws, obman_stream_t stream) {
   if (!x || !y_pool || !stats || !ws || !gamma || !beta || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % bnact::CT) return -1;
+  if ((long)B * H * W >= (1L << 31)) return -1;  // pixel indices are 32-bit
   if (!training && (!rmean || !rvar)) return -2;
   hipStream_t st = (hipStream_t)stream;
   const long R = (long)B * H * W;
@@ -379,6 +397,7 @@ int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, floa
 int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, const float* gamma, const float* stats, int B, int H, int W,
                      int C, int training, float* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream) {
   if (!x || !y_pool || !d_pool || !stats || !ws || !dx || !dgamma || !dbeta || B <= 0 || C % bnact::CT) return -1;
+  if ((long)B * H * W >= (1L << 31)) return -1;  // pixel indices are 32-bit
   hipStream_t st = (hipStream_t)stream;
   const long R = (long)B * H * W;
   const bnact::Geo g = bnact::geo(R, C);

@@ -1,29 +1,37 @@
-"""rocprofv3 ``*_kernel_stats.csv`` -> small committed summary (markdown): every obman HIP kernel plus the
-top-N others.  ``python tools/summarize_rocprof.py gpurun_out/c2_kernel_stats.csv profiles/r01_c2_kernel_stats.md "cmd"``"""
+"""rocprofv3 ``*_kernel_stats.csv`` -> committed markdown summary: every obman HIP kernel plus the top-N others, per step.
+
+    python tools/summarize_rocprof.py gpurun_out/r01f_c2_kernel_stats.csv profiles/r01f_c2_kernel_stats.md 110 "command line"
+(110 = steps + warm-up launches of the profiled bench run; MIOpen's naive_conv find-phase kernels are excluded)"""
 import csv
 import sys
 
-OURS = ("pairmin", "rowmean2", "mano_", "contains_kernel", "contact_", "pointgen", "decoder_", "edge_")
+OURS = ("pairmin", "rowmean2", "mano_", "contains_kernel", "contact_", "dec::", "edge_", "laplacian", "bnact::", "imgstream", "blur_kernel",
+        "warp_kernel", "mean_kernel")
 
 
-def main(src, dst, cmd="", top=25):
-    rows = list(csv.DictReader(open(src)))
-    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+def main(src, dst, steps="1", cmd="", top=30):
+    steps = float(steps)
+    rows = [r for r in csv.DictReader(open(src)) if "naive_conv" not in r["Name"]]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
     ours = [r for r in rows if any(k in r["Name"] for k in OURS)]
-    others = [r for r in rows if r not in ours][:top]
+    others = [r for r in rows if r not in ours]
+    conv = [r for r in others if "igemm" in r["Name"] or "ck::" in r["Name"] or "_ZN2ck" in r["Name"] or "Cijk" in r["Name"]]
+
+    def ms(sel):
+        return sum(float(r["TotalDurationNs"]) for r in sel) / steps / 1e6
+
     with open(dst, "w") as fh:
-        fh.write("# rocprofv3 --kernel-trace --stats summary\n\n")
-        fh.write("command: `%s`\n\nsource: `%s` (%d distinct kernels, %.1f ms total kernel time incl. MIOpen find/tuning launches)\n\n"
-                 % (cmd, src, len(rows), tot / 1e6))
-        for title, sel in (("obman_train_amd HIP kernels", ours), ("top %d other kernels (MIOpen / PyTorch)" % top, others)):
-            fh.write("## %s\n\n| kernel | calls | total ms | avg us | min us | max us | %% |\n|---|---|---|---|---|---|---|\n" % title)
+        fh.write("# rocprofv3 --kernel-trace --stats, per training step\n\ncommand: `%s`\n\n" % cmd)
+        fh.write("%d distinct kernels; **%.2f ms of kernel time per step**: obman_train_amd HIP kernels %.2f ms, MIOpen/CK/rocBLAS "
+                 "convolutions + GEMMs %.2f ms, other PyTorch kernels %.2f ms.\n\n" % (len(rows), tot, ms(ours), ms(conv), ms(others) - ms(conv)))
+        for title, sel in (("obman_train_amd HIP kernels", ours), ("top %d other kernels (MIOpen / PyTorch)" % top, others[:top])):
+            fh.write("## %s\n\n| kernel | calls/step | avg us | ms/step |\n|---|---|---|---|\n" % title)
             for r in sel:
                 name = r["Name"].replace("(anonymous namespace)::", "").replace("|", "/")
-                fh.write("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %.3f |\n" % (
-                    name[:110], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
-                    float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["Percentage"])))
+                fh.write("| `%s` | %.1f | %.1f | %.3f |\n" % (name[:120], float(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3,
+                                                          float(r["TotalDurationNs"]) / steps / 1e6))
             fh.write("\n")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
