@@ -209,44 +209,42 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     const int wo = px.w, ho = px.h;
     const long b = px.b;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // relu >= 0 and the window centre is always in bounds
+    // branch-free: out-of-image taps are clamped onto a pixel of the same window (a duplicate cannot change a max), so all
+    // nine 16-byte loads are issued back to back
+    float4 xs[9];
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
-      const int h = 2 * ho + dy;
-      if (h < 0 || h >= pg.H) continue;
+      const int h = min(max(2 * ho + dy, 0), pg.H - 1);
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
-        const int w = 2 * wo + dx;
-        if (w < 0 || w >= pg.W) continue;
-        const float4 x = *reinterpret_cast<const float4*>(X + ((size_t)(b * pg.H + h) * pg.W + w) * g.C + c);
-        m.x = fmaxf(m.x, __fmaf_rn(vs.x, x.x, vt.x)); m.y = fmaxf(m.y, __fmaf_rn(vs.y, x.y, vt.y));
-        m.z = fmaxf(m.z, __fmaf_rn(vs.z, x.z, vt.z)); m.w = fmaxf(m.w, __fmaf_rn(vs.w, x.w, vt.w));
+        const int w = min(max(2 * wo + dx, 0), pg.W - 1);
+        xs[(dy + 1) * 3 + dx + 1] = *reinterpret_cast<const float4*>(X + ((size_t)(b * pg.H + h) * pg.W + w) * g.C + c);
       }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      m.x = fmaxf(m.x, __fmaf_rn(vs.x, xs[t].x, vt.x)); m.y = fmaxf(m.y, __fmaf_rn(vs.y, xs[t].y, vt.y));
+      m.z = fmaxf(m.z, __fmaf_rn(vs.z, xs[t].z, vt.z)); m.w = fmaxf(m.w, __fmaf_rn(vs.w, xs[t].w, vt.w));
     }
     *reinterpret_cast<float4*>(Yp + (size_t)r * g.C + c) = m;
   }
 }
 
 // d(loss)/d(relu output) of pixel (b,h,w): sum of the pooled gradients of the covering windows whose max this pixel is
-__device__ __forceinline__ float4 pool_dz(const float4 y, long b, int h, int w, const PoolGeo& pg, int C, int c,
-                                          const float* __restrict__ Yp, const float* __restrict__ Dp) {
-  float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int ho0 = h >> 1, nho = (h & 1) ? 2 : 1, wo0 = w >> 1, nwo = (w & 1) ? 2 : 1;
-  for (int i = 0; i < nho; ++i) {
-    const int ho = ho0 + i;
-    if (ho >= pg.Ho) continue;
-    for (int j = 0; j < nwo; ++j) {
-      const int wo = wo0 + j;
-      if (wo >= pg.Wo) continue;
-      const size_t o = ((size_t)(b * pg.Ho + ho) * pg.Wo + wo) * C + c;
-      const float4 yp = *reinterpret_cast<const float4*>(Yp + o), dp = *reinterpret_cast<const float4*>(Dp + o);
-      dz.x += (y.x > 0.f && y.x == yp.x) ? dp.x : 0.f; dz.y += (y.y > 0.f && y.y == yp.y) ? dp.y : 0.f;
-      dz.z += (y.z > 0.f && y.z == yp.z) ? dp.z : 0.f; dz.w += (y.w > 0.f && y.w == yp.w) ? dp.w : 0.f;
-    }
-  }
-  return dz;
+// Backward over 2 x 2 pixel quads.  The quad (2i..2i+1, 2j..2j+1) is covered by exactly the pooled windows
+// (i..i+1, j..j+1): pixel (2i,2j) only by (i,j), the two edge pixels by two windows, (2i+1,2j+1) by all four.  One thread
+// owns a quad x 4 channels: 4 x-loads + 4 (y_pool, d_pool) tap pairs, all issued together (12 independent 16-byte loads),
+// i.e. one tap pair per pixel instead of 2.25 in a per-pixel formulation.
+__device__ __forceinline__ float4 relu_bn(const float4 x, const float4 s, const float4 t) {
+  return make_float4(fmaxf(__fmaf_rn(s.x, x.x, t.x), 0.f), fmaxf(__fmaf_rn(s.y, x.y, t.y), 0.f), fmaxf(__fmaf_rn(s.z, x.z, t.z), 0.f),
+                     fmaxf(__fmaf_rn(s.w, x.w, t.w), 0.f));
+}
+__device__ __forceinline__ void route(float4& dz, const float4 y, const float4 yp, const float4 dp, bool ok) {
+  dz.x += (ok && y.x > 0.f && y.x == yp.x) ? dp.x : 0.f; dz.y += (ok && y.y > 0.f && y.y == yp.y) ? dp.y : 0.f;
+  dz.z += (ok && y.z > 0.f && y.z == yp.z) ? dp.z : 0.f; dz.w += (ok && y.w > 0.f && y.w == yp.w) ? dp.w : 0.f;
 }
 
-template <bool APPLY>  // false: per-block sums (dz, dz*xhat); true: dx = k1*(dz - k2 - xhat*k3)
+template <bool APPLY>  // false: per-block sums (dz, dz*xhat); true: dx = k1*(dz - k2 - xhat*k3).  g describes the QUAD rows.
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yp, const float* __restrict__ Dp,
                                                        const float* __restrict__ sc, const float* __restrict__ sh,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -254,7 +252,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ DX) {
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.y * CT + cl * 4;
-  const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);  // rows = input pixels
+  const int Hq = (pg.H + 1) / 2, Wq = (pg.W + 1) / 2;
+  const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);  // rows = quads
   const float4 vs = *reinterpret_cast<const float4*>(sc + c), vt = *reinterpret_cast<const float4*>(sh + c);
   const float4 vm = *reinterpret_cast<const float4*>(mean + c), vr = *reinterpret_cast<const float4*>(rstd + c);
   float4 k1 = make_float4(0, 0, 0, 0), k2 = k1, k3 = k1;
@@ -263,22 +262,41 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     k3 = *reinterpret_cast<const float4*>(k + 2 * g.C + c);
   }
   float4 a = make_float4(0, 0, 0, 0), bb = a;
-  Pix px = pix_of(r0 + rl, pg.H, pg.W);
-  for (long r = r0 + rl; r < r1; r += 16, pix_advance(px, 16, pg.H, pg.W)) {
-    const int w = px.w, h = px.h;
-    const long b = px.b;
-    const size_t o = (size_t)r * g.C + c;
-    const float4 x = *reinterpret_cast<const float4*>(X + o);
-    const float4 y = make_float4(fmaxf(__fmaf_rn(vs.x, x.x, vt.x), 0.f), fmaxf(__fmaf_rn(vs.y, x.y, vt.y), 0.f),
-                                 fmaxf(__fmaf_rn(vs.z, x.z, vt.z), 0.f), fmaxf(__fmaf_rn(vs.w, x.w, vt.w), 0.f));
-    const float4 d = pool_dz(y, b, h, w, pg, g.C, c, Yp, Dp);
-    const float4 xh = make_float4((x.x - vm.x) * vr.x, (x.y - vm.y) * vr.y, (x.z - vm.z) * vr.z, (x.w - vm.w) * vr.w);
-    if (APPLY) {
-      *reinterpret_cast<float4*>(DX + o) = make_float4(k1.x * (d.x - k2.x - xh.x * k3.x), k1.y * (d.y - k2.y - xh.y * k3.y),
-                                                       k1.z * (d.z - k2.z - xh.z * k3.z), k1.w * (d.w - k2.w - xh.w * k3.w));
-    } else {
-      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-      bb.x = __fmaf_rn(d.x, xh.x, bb.x); bb.y = __fmaf_rn(d.y, xh.y, bb.y); bb.z = __fmaf_rn(d.z, xh.z, bb.z); bb.w = __fmaf_rn(d.w, xh.w, bb.w);
+  Pix q = pix_of(r0 + rl, Hq, Wq);
+  for (long r = r0 + rl; r < r1; r += 16, pix_advance(q, 16, Hq, Wq)) {
+    const int h0 = 2 * q.h, w0 = 2 * q.w;
+    const bool ph = h0 + 1 < pg.H, pw = w0 + 1 < pg.W;          // does the quad's second row / column exist
+    const bool wh = q.h + 1 < pg.Ho, ww = q.w + 1 < pg.Wo;      // does the second window row / column exist
+    const int h1 = ph ? h0 + 1 : h0, w1 = pw ? w0 + 1 : w0, i1 = wh ? q.h + 1 : q.h, j1 = ww ? q.w + 1 : q.w;
+    const size_t xb = (size_t)q.b * pg.H, pb = (size_t)q.b * pg.Ho;
+    const size_t ox[4] = {((xb + h0) * pg.W + w0) * g.C + c, ((xb + h0) * pg.W + w1) * g.C + c, ((xb + h1) * pg.W + w0) * g.C + c,
+                          ((xb + h1) * pg.W + w1) * g.C + c};
+    const size_t op[4] = {((pb + q.h) * pg.Wo + q.w) * g.C + c, ((pb + q.h) * pg.Wo + j1) * g.C + c, ((pb + i1) * pg.Wo + q.w) * g.C + c,
+                          ((pb + i1) * pg.Wo + j1) * g.C + c};
+    float4 x[4], yp[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = *reinterpret_cast<const float4*>(X + ox[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { yp[t] = *reinterpret_cast<const float4*>(Yp + op[t]); dp[t] = *reinterpret_cast<const float4*>(Dp + op[t]); }
+    const bool pix_ok[4] = {true, pw, ph, ph && pw};
+    const bool win_ok[4] = {true, ww, wh, wh && ww};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (!pix_ok[t]) continue;  // uniform per quad position except at odd image borders
+      const float4 y = relu_bn(x[t], vs, vt);
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      route(d, y, yp[0], dp[0], true);                       // window (i, j) covers every pixel of the quad
+      if (t & 1) route(d, y, yp[1], dp[1], win_ok[1]);       // (i, j+1) covers the odd column
+      if (t & 2) route(d, y, yp[2], dp[2], win_ok[2]);       // (i+1, j) covers the odd row
+      if (t == 3) route(d, y, yp[3], dp[3], win_ok[3]);
+      const float4 xh = make_float4((x[t].x - vm.x) * vr.x, (x[t].y - vm.y) * vr.y, (x[t].z - vm.z) * vr.z, (x[t].w - vm.w) * vr.w);
+      if (APPLY) {
+        *reinterpret_cast<float4*>(DX + ox[t]) = make_float4(k1.x * (d.x - k2.x - xh.x * k3.x), k1.y * (d.y - k2.y - xh.y * k3.y),
+                                                             k1.z * (d.z - k2.z - xh.z * k3.z), k1.w * (d.w - k2.w - xh.w * k3.w));
+      } else {
+        a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+        bb.x = __fmaf_rn(d.x, xh.x, bb.x); bb.y = __fmaf_rn(d.y, xh.y, bb.y); bb.z = __fmaf_rn(d.z, xh.z, bb.z); bb.w = __fmaf_rn(d.w, xh.w, bb.w);
+      }
     }
   }
   if (APPLY) return;
@@ -287,11 +305,11 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   red[rl][cl * 4 + 0][1] = bb.x; red[rl][cl * 4 + 1][1] = bb.y; red[rl][cl * 4 + 2][1] = bb.z; red[rl][cl * 4 + 3][1] = bb.w;
   __syncthreads();
   if (tid < CT * 2) {
-    const int ch = tid >> 1, q = tid & 1;
-    double s = 0;
+    const int ch = tid >> 1, q2 = tid & 1;
+    double s2 = 0;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) s += (double)red[kk][ch][q];
-    partial[((size_t)(blockIdx.y * CT + ch) * g.nblk + blockIdx.x) * 2 + q] = s;
+    for (int kk = 0; kk < 16; ++kk) s2 += (double)red[kk][ch][q2];
+    partial[((size_t)(blockIdx.y * CT + ch) * g.nblk + blockIdx.x) * 2 + q2] = s2;
   }
 }
 
@@ -400,10 +418,10 @@ int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, c
   if ((long)B * H * W >= (1L << 31)) return -1;  // pixel indices are 32-bit
   hipStream_t st = (hipStream_t)stream;
   const long R = (long)B * H * W;
-  const bnact::Geo g = bnact::geo(R, C);
   const bnact::PoolGeo pg{H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+  const bnact::Geo g = bnact::geo((long)B * ((H + 1) / 2) * ((W + 1) / 2), C);  // rows of the backward = 2 x 2 pixel quads
   double* partial = reinterpret_cast<double*>(ws);
-  float* k = ws + (size_t)g.nblk * C * 2 * 2;
+  float* k = ws + (size_t)bnact::geo(R, C).nblk * C * 2 * 2;  // workspace is sized for the pixel geometry (>= quad geometry)
   const float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   dim3 grid(g.nblk, C / bnact::CT);
   bnact::pool_bwd_kernel<false><<<grid, 256, 0, st>>>(x, y_pool, d_pool, sc, sh, mean, rstd, nullptr, g, pg, partial, nullptr);

@@ -148,6 +148,23 @@ def bench_imgstream():
                                   host_pack_ms=round(t_pack * 1e3, 2))), flush=True)
 
 
+def bench_bnpool():
+    """Stem BatchNorm + ReLU + MaxPool(3,2,1) at the headline shape: 64 x 64 ch x 128 x 128 (268 MB activation)."""
+    from obman_train_amd import ops
+
+    bn = torch.nn.BatchNorm2d(64).cuda().train()
+    pool = torch.nn.MaxPool2d(3, stride=2, padding=1)
+    x = torch.randn(64, 64, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_()
+    t_f = timeit(lambda: ops.bn_relu_maxpool(bn, x, pool, count=False), iters=20, warmup=5)
+    y = ops.bn_relu_maxpool(bn, x, pool, count=False)
+    g = torch.randn_like(y)
+    t_b = timeit(lambda: torch.autograd.grad(y, (x, bn.weight, bn.bias), g, retain_graph=True), iters=20, warmup=5)
+    xb, yb = x.numel() * 4, y.numel() * 4
+    # fwd: x read twice (stats, pool) + pooled write; bwd: x read twice, pooled y + dy read twice, dx written
+    print(json.dumps(dict(kernel="bn_relu_maxpool", fwd_us=round(t_f * 1e6, 1), bwd_us=round(t_b * 1e6, 1),
+                          fwd_TBps=round((2 * xb + yb) / t_f / 1e12, 2), bwd_TBps=round((3 * xb + 4 * yb) / t_b / 1e12, 2))), flush=True)
+
+
 def bench_decoder():
     import numpy as np
 
@@ -191,6 +208,8 @@ if __name__ == "__main__":
         bench_mano()
     if which in ("contains", "all"):
         bench_contains()
+    if which in ("bnpool", "all"):
+        bench_bnpool()
     if which in ("imgstream", "all"):
         bench_imgstream()
     if which in ("decoder", "all"):
