@@ -1199,7 +1199,8 @@ struct Dims {
   long R;
 };
 inline int kpad(int K) { return (K + BK - 1) / BK * BK; }       // k extent of a bf16 weight image (zero padded)
-inline int wide_wn(int Nc) { return Nc > 128 ? 5 : 2; }          // 32-column MFMA tiles per wave of the bf16 kernels
+inline int wide_wn(int Nc) { return Nc > 320 ? 9 : (Nc > 128 ? 5 : 2); }  // 32-column MFMA tiles per wave of the bf16 rows kernel
+inline int tn_wn(int Nc) { return Nc > 128 ? 5 : 2; }                       // ... of the bf16 weight-gradient kernel
 Dims dims_of(const obman_pointgen_params* p) {
   Dims d;
   d.B = p->B; d.N = p->N; d.C1 = p->C1; d.C2 = p->C1 / 2; d.C3 = p->C1 / 4;
@@ -1270,7 +1271,7 @@ BwdWs bwd_ws(const Dims& d) {
   }
   {  // split-K partials: the largest of the three weight-gradient products
     auto need = [&](int M, int Nc, long R) {
-      const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * wide_wn(Nc) : BN);
+      const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * tn_wn(Nc) : BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
     };
     long a = need(d.C3, d.C2, d.R), b = need(d.C2, d.C1, d.R), c = need(d.C1, d.C1 - 3, d.B);
@@ -1324,7 +1325,11 @@ int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, long R, co
 }
 template <class AOp, class Epi>
 int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
-  return wide_wn(Nc) == 5 ? launch_rows_bf16_wn<AOp, Epi, 5>(a, Wb, K, Nc, R, e, st) : launch_rows_bf16_wn<AOp, Epi, 2>(a, Wb, K, Nc, R, e, st);
+  switch (wide_wn(Nc)) {
+    case 9: return launch_rows_bf16_wn<AOp, Epi, 9>(a, Wb, K, Nc, R, e, st);  // N = 515: one 576-wide block instead of two 320-wide ones
+    case 5: return launch_rows_bf16_wn<AOp, Epi, 5>(a, Wb, K, Nc, R, e, st);
+    default: return launch_rows_bf16_wn<AOp, Epi, 2>(a, Wb, K, Nc, R, e, st);
+  }
 }
 template <class AOp, class BOp, int WN>
 int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, float* part, float* out, int ldo, int off, hipStream_t st) {
@@ -1345,8 +1350,9 @@ int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, float* 
 }
 template <class AOp, class BOp>
 int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, float* part, float* out, int ldo, int off, hipStream_t st) {
-  return wide_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, part, out, ldo, off, st)
-                          : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, part, out, ldo, off, st);
+  // (9 column tiles per wave spill in this kernel: two generated operands are staged per thread)
+  return tn_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, part, out, ldo, off, st)
+                        : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, part, out, ldo, off, st);
 }
 bool params_ok(const obman_pointgen_params* p) {
   return p && p->B > 0 && p->N > 0 && p->C1 >= 8 && p->C1 / 4 <= 128 && p->grid && p->feat && p->w1 && p->w2 && p->w3 && p->w4;
