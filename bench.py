@@ -216,6 +216,8 @@ def main():
     opt = make_optimizer(model, "adam", lr=1e-4)
     buckets = GradientBuckets(model.parameters(), force=args.force_dist) if use_dist else None
     sample = make_batch(args.batch, dev, seed=rank, image_size=args.image_size)
+    # resident in the layout the input stream (DeviceImageStage(channels_last=True)) delivers: same [B,3,H,W] tensor, NHWC strides
+    sample[TransQueries.images] = sample[TransQueries.images].contiguous(memory_format=torch.channels_last)
 
     for _ in range(args.warmup):
         train_step(model, opt, sample, buckets)

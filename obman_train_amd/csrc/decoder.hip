@@ -174,6 +174,22 @@ __device__ __forceinline__ int rows_N(const AGridFeat& a) { return a.N; }
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Blocks that
+// share an operand (the column blocks of one row block; the output tiles of one row chunk) get consecutive slots on ONE XCD,
+// so the shared operand is fetched from HBM once and re-read from that L2 instead of once per block from HBM / MALL.
+// id -> (group, member): group = (slot / members) * 8 + xcd, member = slot % members; grids are padded to 8 * ceil(groups / 8).
+struct XcdOrder { int group, member; };
+__device__ __forceinline__ XcdOrder xcd_order(int id, int members, int aware = 1) {
+  if (!aware) return XcdOrder{id / members, id % members};  // OBMAN_DEC_XCD=0: plain group-major order (A/B knob)
+  const int xcd = id & 7, slot = id >> 3;
+  return XcdOrder{(slot / members) * 8 + xcd, slot % members};
+}
+inline int xcd_aware() {
+  static const int v = [] { const char* e = getenv("OBMAN_DEC_XCD"); return e ? atoi(e) : 1; }();
+  return v;
+}
+inline unsigned xcd_grid(long groups, int members) { return (unsigned)(((groups + 7) / 8) * 8 * members); }
+
 // LDS tiles (k-major, +1 pad): As[buf][k][m], Bs[buf][k][n]
 struct Tiles {
   float As[2][BK][BM + 1];
@@ -186,7 +202,9 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Tiles& T = *reinterpret_cast<Tiles*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const XcdOrder bo = xcd_order(blockIdx.x, (Nc + BN - 1) / BN, !(variant & 8));  // group = row block, member = column block
+  if ((long)bo.group * BM >= aop.R) return;
+  const int bm0 = bo.group * BM, bn0 = bo.member * BN;
 
   // A staging: thread = 4 consecutive k (one 16-byte load per source array) x 4 rows (rm, rm+32, rm+64, rm+96)
   const int kq = (tid & 7) * 4, rm = tid >> 3;
@@ -280,12 +298,12 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
     if (!(variant & 2)) __syncthreads();
   }
   if (variant & 4) { if (acc0[0] + acc1[3] == 123.456f) epi.C[0] = 1.f; return; }
-  epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, tid, smem);
+  epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, bo.group, smem);
 }
 
 // ---- epilogue bodies (members defined here to keep the kernel readable)
 struct EpiStoreImpl : EpiStore {
-  __device__ __forceinline__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
+  __device__ __forceinline__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int rblk, char* smem) const {
     const int col = c0 + (lane & 31);
     const float bv = (bias && col < Nc) ? bias[col] : 0.f;
     double s1 = 0.0, s2 = 0.0;
@@ -311,7 +329,7 @@ struct EpiStoreImpl : EpiStore {
       if (wm == 1 && lane < 32) { red[(wn * 32 + lane) * 2] = s1; red[(wn * 32 + lane) * 2 + 1] = s2; }
       __syncthreads();
       if (wm == 0 && lane < 32 && col < Nc) {
-        double* dst = moments + ((size_t)blockIdx.x * Nc + col) * 2;
+        double* dst = moments + ((size_t)rblk * Nc + col) * 2;
         dst[0] = s1 + red[(wn * 32 + lane) * 2];
         dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
       }
@@ -414,7 +432,7 @@ struct EpiMaskStatsImpl : EpiMaskStats {
     return c;
   }
   // fp32 kernel: wave tile = two stacked 32x32 tiles, two M-waves per block
-  __device__ __forceinline__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int tid, char* smem) const {
+  __device__ __forceinline__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int rblk, char* smem) const {
     const int col = c0 + (lane & 31);
     const bool cok = col < Nc;
     const Cst c = consts(col, cok);
@@ -427,7 +445,7 @@ struct EpiMaskStatsImpl : EpiMaskStats {
     if (wm == 1 && lane < 32) { red[(wn * 32 + lane) * 2] = s1; red[(wn * 32 + lane) * 2 + 1] = s2; }
     __syncthreads();
     if (wm == 0 && lane < 32 && cok) {
-      double* dst = sums + ((size_t)blockIdx.x * Nc + col) * 2;
+      double* dst = sums + ((size_t)rblk * Nc + col) * 2;
       dst[0] = s1 + red[(wn * 32 + lane) * 2];
       dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
     }
@@ -508,13 +526,15 @@ struct EpiMaskStatsImpl : EpiMaskStats {
 // C[M x Nc] (+)= sum_r Aop[r, m] * Bop[r, n] over a chunk of rows; partial results per row-chunk (split-K), summed
 // afterwards in chunk order (deterministic).  Tiles: the contraction index is the row r.
 template <class AOp, class BOp>
-__global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, int Nc, int R, int rows_per_chunk, float* __restrict__ part) {
+__global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, int Nc, int R, int rows_per_chunk, float* __restrict__ part, int order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Tiles& T = *reinterpret_cast<Tiles*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int mt = (M + BM - 1) / BM;
-  const int bm0 = (blockIdx.x % mt) * BM, bn0 = (blockIdx.x / mt) * BN;
-  const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
+  const int mt = (M + BM - 1) / BM, ntile = mt * ((Nc + BN - 1) / BN);
+  const XcdOrder bo = xcd_order(blockIdx.x, ntile, order);  // group = row chunk, member = output tile
+  if ((long)bo.group * rows_per_chunk >= R) return;
+  const int bm0 = (bo.member % mt) * BM, bn0 = (bo.member / mt) * BN;
+  const int rbeg = bo.group * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
   // staging: A tile [32 rows][128 m]: thread = 4 consecutive channels (16-byte loads) x rows (tid>>5) + 8p, p < 4;
   // B tile [32 rows][64 n]: 4 channels x rows (tid>>4) + 16p, p < 2.  A thread's channels are fixed for the whole
   // sweep: their constants are loaded once.
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     }
     __syncthreads();
   }
-  float* dst = part + (size_t)blockIdx.y * M * Nc;
+  float* dst = part + (size_t)bo.group * M * Nc;
   const int col = bn0 + wn * 32 + (lane & 31);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -1233,9 +1253,9 @@ FwdWs fwd_ws(const Dims& d) {
 int tn_chunk_rows(int M, int Nc, long R, int bn = BN) {
   const long tiles = (long)((M + BM - 1) / BM) * ((Nc + bn - 1) / bn);
   const long blocks = bn > BN ? 512 : 1024;               // wide (bf16) tiles: a block is 5x the work and writes 5x the partial
-  long want = (blocks + tiles - 1) / tiles;               // chunks wanted
+  long want = (blocks + tiles - 1) / tiles;               // chunks wanted ...
+  want = (want + 7) / 8 * 8;                              // ... a multiple of 8: whole chunks are dealt to the 8 XCDs
   long rows = (R + want - 1) / want;
-  rows = (rows + BK - 1) / BK * BK;
   if (rows < 128) rows = 128;
   return (int)rows;
 }
@@ -1287,9 +1307,9 @@ BwdWs bwd_ws(const Dims& d) {
 
 template <class AOp, bool B_NK, class Epi>
 int launch_rows(const AOp& a, const float* W, int ldb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
-  dim3 grid((unsigned)((R + BM - 1) / BM), (unsigned)((Nc + BN - 1) / BN));
+  dim3 grid(xcd_grid((R + BM - 1) / BM, (Nc + BN - 1) / BN));
   static const int variant = [] { const char* v = getenv("OBMAN_GEMM_VARIANT"); return v ? atoi(v) : 0; }();  // ablation knob
-  gemm_rows_kernel<AOp, B_NK, Epi><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e, variant);
+  gemm_rows_kernel<AOp, B_NK, Epi><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e, variant | (xcd_aware() ? 0 : 8));
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -1297,8 +1317,8 @@ template <class AOp, class BOp>
 int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* part, float* out, int ldo, int off, hipStream_t st) {
   const int chunk_rows = tn_chunk_rows(M, Nc, R);
   const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
-  dim3 grid((unsigned)(((M + BM - 1) / BM) * ((Nc + BN - 1) / BN)), (unsigned)chunks);
-  gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part);
+  dim3 grid(xcd_grid(chunks, ((M + BM - 1) / BM) * ((Nc + BN - 1) / BN)));
+  gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part, xcd_aware());
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
   OBMAN_LAUNCH_CHECK();
