@@ -1,22 +1,26 @@
-"""Area-weighted surface sampling of an object mesh (reference ``handobjectdatasets/vertexsample.py:6-30``): host numpy,
-global ``np.random`` draws in the reference's order (choice, rand, rand)."""
+"""Surface samples of an object mesh for the Chamfer ground truth.
+
+Behavioural mirror of ``points_from_mesh`` (reference ``handobjectdatasets/vertexsample.py:11-29``): triangles are drawn
+with probability proportional to their area, then a point is drawn uniformly inside each.  The global ``np.random`` stream
+is consumed exactly like the reference does (one ``choice`` of ``vertex_nb`` triangle ids, then two ``rand(vertex_nb, 1)``
+blocks) and the float arithmetic keeps its order, so a seeded run samples the very same points.
+"""
 import numpy as np
 
 
-def tri_area(v):
-    return 0.5 * np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1)
-
-
 def points_from_mesh(faces, vertices, vertex_nb=600, show_cloud=False):
+    """faces ``[F,3]`` int, vertices ``[V,3]`` -> ``[vertex_nb,3]`` points on the surface."""
     if show_cloud:
-        raise NotImplementedError("matplotlib preview of the sampled cloud is outside the hot path")
-    areas = tri_area(vertices[faces])
-    proba = areas / areas.sum()
-    rand_idxs = np.random.choice(range(areas.shape[0]), size=vertex_nb, p=proba)
-    u = np.random.rand(vertex_nb, 1)
-    v = np.random.rand(vertex_nb, 1)
-    outside = u + v > 1  # fold the unit square onto the lower triangle
-    u[outside] = 1 - u[outside]
-    v[outside] = 1 - v[outside]
-    tris = vertices[faces[rand_idxs]]
-    return tris[:, 0] + u * (tris[:, 1] - tris[:, 0]) + v * (tris[:, 2] - tris[:, 0])
+        raise NotImplementedError("the matplotlib preview of the sampled cloud is outside the hot path")
+    corners = vertices[faces]                                   # [F,3,3]
+    normals = np.cross(corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 0])
+    area = 0.5 * np.linalg.norm(normals, axis=1)
+    picked = np.random.choice(range(area.shape[0]), size=vertex_nb, p=area / area.sum())
+    # barycentric weights of the two edges leaving corner 0: uniform on the unit square, mirrored into the lower triangle
+    weights = [np.random.rand(vertex_nb, 1), np.random.rand(vertex_nb, 1)]
+    mirrored = weights[0] + weights[1] > 1
+    for w in weights:
+        w[mirrored] = 1 - w[mirrored]
+    tri = vertices[faces[picked]]
+    origin = tri[:, 0]
+    return origin + weights[0] * (tri[:, 1] - origin) + weights[1] * (tri[:, 2] - origin)
