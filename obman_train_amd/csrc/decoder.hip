@@ -1174,6 +1174,98 @@ __global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restri
   }
 }
 
+// The same computation for large templates (N > L1_SPLIT_N: 25 patches = 16 050 vertices), where nine 64-channel blocks
+// would crawl over N rows on nine CUs (0.86 ms at configs[2]).  Three launches over (row segment, 64 channels) blocks:
+//   l1_seg_stats : per segment  sum_n Gx*Q, sum_n Gx                               -> seg[segment][2][C]   (fp64)
+//   l1_seg_apply : every block re-derives the channel constants from seg[] (fixed order) and the B sample rows, then its
+//                  rows' dG . grid products                                        -> segw[segment][3][C]; segment 0 also
+//                  writes dF, g_b1, g_gamma1, g_beta1
+//   l1_seg_w     : gW1[:, 0:3] = sum_segment segw                                   (fixed order)
+constexpr int L1_SPLIT_N = 2048, L1_SEG_ROWS = 512;
+__global__ __launch_bounds__(1024) void l1_seg_stats_kernel(const float* __restrict__ Q, const float* __restrict__ Gx, int ld1, int N, int C1,
+                                                            double* __restrict__ seg) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const int n0 = blockIdx.y * L1_SEG_ROWS, n1 = min(N, n0 + L1_SEG_ROWS);
+  __shared__ double red[16][2][64];
+  double s2 = 0, sgx = 0;
+  if (c < C1)
+    for (int n = n0 + rg; n < n1; n += 16) {
+      const double gx = Gx[(size_t)n * ld1 + c];
+      s2 += gx * (double)Q[(size_t)n * ld1 + c];
+      sgx += gx;
+    }
+  red[rg][0][cl] = s2; red[rg][1][cl] = sgx;
+  __syncthreads();
+  if (rg == 0 && c < C1) {
+    s2 = sgx = 0;
+    for (int g = 0; g < 16; ++g) { s2 += red[g][0][cl]; sgx += red[g][1][cl]; }
+    seg[((size_t)blockIdx.y * 2) * C1 + c] = s2;
+    seg[((size_t)blockIdx.y * 2 + 1) * C1 + c] = sgx;
+  }
+}
+__global__ __launch_bounds__(1024) void l1_seg_apply_kernel(const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ Gx,
+                                                            const float* __restrict__ Fx, int ld1, int B, int N, int C1, int training,
+                                                            const float* __restrict__ gamma, const float* __restrict__ rstd1,
+                                                            const float* __restrict__ grid, const double* __restrict__ seg, int nseg,
+                                                            float* __restrict__ g_gamma, float* __restrict__ g_beta, float* __restrict__ g_b1,
+                                                            float* __restrict__ dF, float* __restrict__ segw) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const bool ok = c < C1;
+  const int n0 = blockIdx.y * L1_SEG_ROWS, n1 = min(N, n0 + L1_SEG_ROWS);
+  __shared__ double red[16][4][64];
+  __shared__ float redf[16][4][64];
+  // channel constants: sample rows split over the 16 row groups, segment partials summed in index order by every group
+  double s1 = 0, s2 = 0, sgx = 0, sfx = 0;
+  if (ok)
+    for (int b = rg; b < B; b += 16) {
+      const double p = P[(size_t)b * ld1 + c], fx = Fx[(size_t)b * ld1 + c];
+      s1 += p; s2 += p * fx; sfx += fx;
+    }
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2; red[rg][3][cl] = sfx;
+  __syncthreads();
+  s1 = s2 = sfx = 0;
+  for (int g = 0; g < 16; ++g) { s1 += red[g][0][cl]; s2 += red[g][1][cl]; sfx += red[g][3][cl]; }
+  if (ok)
+    for (int sg = 0; sg < nseg; ++sg) { s2 += seg[((size_t)sg * 2) * C1 + c]; sgx += seg[((size_t)sg * 2 + 1) * C1 + c]; }
+  const double R = (double)B * N;
+  const float k1 = ok ? gamma[c] * rstd1[c] : 0.f;
+  const float k2 = training ? (float)(s1 / R) : 0.f, k3 = training ? (float)(s2 / R) : 0.f;
+  float gb = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  if (ok) {
+    if (blockIdx.y == 0)
+      for (int b = rg; b < B; b += 16) {
+        const float v = k1 * (P[(size_t)b * ld1 + c] - N * k2 - k3 * ((float)sgx + N * Fx[(size_t)b * ld1 + c]));
+        dF[(size_t)b * ld1 + c] = v;
+        gb += v;
+      }
+    for (int n = n0 + rg; n < n1; n += 16) {
+      const float v = k1 * (Q[(size_t)n * ld1 + c] - B * k2 - k3 * (B * Gx[(size_t)n * ld1 + c] + (float)sfx));
+      w0 = __fmaf_rn(v, grid[n * 3], w0); w1 = __fmaf_rn(v, grid[n * 3 + 1], w1); w2 = __fmaf_rn(v, grid[n * 3 + 2], w2);
+    }
+  }
+  redf[rg][0][cl] = gb; redf[rg][1][cl] = w0; redf[rg][2][cl] = w1; redf[rg][3][cl] = w2;
+  __syncthreads();
+  if (rg == 0 && ok) {
+    gb = w0 = w1 = w2 = 0.f;
+    for (int g = 0; g < 16; ++g) { gb += redf[g][0][cl]; w0 += redf[g][1][cl]; w1 += redf[g][2][cl]; w2 += redf[g][3][cl]; }
+    float* dst = segw + (size_t)blockIdx.y * 3 * C1;
+    dst[c] = w0; dst[C1 + c] = w1; dst[2 * C1 + c] = w2;
+    if (blockIdx.y == 0) {
+      g_gamma[c] = (float)s2;
+      g_beta[c] = (float)s1;
+      g_b1[c] = gb;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void l1_seg_w_kernel(const float* __restrict__ segw, int nseg, int C1, float* __restrict__ gW1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // i = k * C1 + c, k < 3
+  if (i >= 3 * C1) return;
+  float s = 0.f;
+  for (int sg = 0; sg < nseg; ++sg) s += segw[(size_t)sg * 3 * C1 + i];
+  const int k = i / C1, c = i - k * C1;
+  gW1[(size_t)c * C1 + k] = s;
+}
+
 // g_feat[b,k] = sum_c dF[b,c] * W1[c, 3+k]: 64 samples x 512 features, contraction 515 - far too skinny for the tiled
 // MFMA kernel (one row block, 17 serial k-tiles); thread = (b, k), dF broadcast within the wave, W1 coalesced over k.
 __global__ __launch_bounds__(256) void gfeat_kernel(const float* __restrict__ dF, int ld1, const float* __restrict__ W1, int C1, int B,
@@ -1272,7 +1364,7 @@ L1Geo l1_geo(const Dims& d) {
   return g;
 }
 struct BwdWs {
-  long GY2, GY1, sums, k, l4p, P, Q, Pp, Qp, dF, dG, tn, wt2, wt3, total;
+  long GY2, GY1, sums, k, l4p, P, Q, Pp, Qp, dF, dG, seg, segw, tn, wt2, wt3, total;
   int chunks;
 };
 BwdWs bwd_ws(const Dims& d) {
@@ -1288,6 +1380,11 @@ BwdWs bwd_ws(const Dims& d) {
   {
     const L1Geo g = l1_geo(d);
     w.Pp = take((long)g.tiles * d.B * d.ld1); w.Qp = take((long)g.groups * d.N * d.ld1);
+  }
+  {  // large-template layer-1 finalize: per-segment partials
+    const long nseg = d.N > L1_SPLIT_N ? (d.N + L1_SEG_ROWS - 1) / L1_SEG_ROWS : 0;
+    w.seg = take(nseg * 2 * d.C1 * 2);  // doubles
+    w.segw = take(nseg * 3 * d.C1);
   }
   {  // split-K partials: the largest of the three weight-gradient products
     auto need = [&](int M, int Nc, long R) {
@@ -1518,9 +1615,22 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
                                                                                 ws2 + v.P, ws2 + v.Q);
     OBMAN_LAUNCH_CHECK();
   }
-  l1_finalize_kernel<<<obman_cdiv(d.C1, 64), 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
-                                                             ws + w.rstd1, p->grid, g->bn_w[0], g->bn_b[0], g->b1, g->w1, ws2 + v.dF, ws2 + v.dG);
-  OBMAN_LAUNCH_CHECK();
+  if (d.N > L1_SPLIT_N) {
+    const int nseg = obman_cdiv(d.N, L1_SEG_ROWS);
+    double* seg = reinterpret_cast<double*>(ws2 + v.seg);
+    const dim3 grid(obman_cdiv(d.C1, 64), nseg);
+    l1_seg_stats_kernel<<<grid, 1024, 0, st>>>(ws2 + v.Q, ws + w.Gx, d.ld1, d.N, d.C1, seg);
+    OBMAN_LAUNCH_CHECK();
+    l1_seg_apply_kernel<<<grid, 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0], ws + w.rstd1,
+                                                p->grid, seg, nseg, g->bn_w[0], g->bn_b[0], g->b1, ws2 + v.dF, ws2 + v.segw);
+    OBMAN_LAUNCH_CHECK();
+    l1_seg_w_kernel<<<obman_cdiv(3 * d.C1, 256), 256, 0, st>>>(ws2 + v.segw, nseg, d.C1, g->w1);
+    OBMAN_LAUNCH_CHECK();
+  } else {
+    l1_finalize_kernel<<<obman_cdiv(d.C1, 64), 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
+                                                               ws + w.rstd1, p->grid, g->bn_w[0], g->bn_b[0], g->b1, g->w1, ws2 + v.dF, ws2 + v.dG);
+    OBMAN_LAUNCH_CHECK();
+  }
   const int Cf = d.C1 - 3;
   {  // gW1[c, 3+k] = sum_b dF[b,c] feat[b,k]
     APlain adf{ws2 + v.dF, d.ld1, d.B, d.C1};
