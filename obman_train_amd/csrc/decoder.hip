@@ -931,6 +931,25 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// Pre-reduction of per-row-block partials when there are thousands of them (25-patch templates: 8 025 row blocks, 32 100
+// layer-4 blocks): out[seg][col] = sum of in[r][col] over the rows of segment seg, lanes along the contiguous columns,
+// fixed order.  The one-wave-per-channel finalize kernels below then see <= 64 rows instead of striding through megabytes.
+constexpr int PRE_SEGMENTS = 64, PRE_MIN_ROWS = 512;
+template <class T>
+__global__ __launch_bounds__(256) void colsum_segments_kernel(const T* __restrict__ in, long rows, int cols, int rows_per_seg,
+                                                              T* __restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const long r0 = (long)blockIdx.y * rows_per_seg, r1 = r0 + rows_per_seg < rows ? r0 + rows_per_seg : rows;
+  T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += in[r * cols + col]; a1 += in[(r + 1) * cols + col]; a2 += in[(r + 2) * cols + col]; a3 += in[(r + 3) * cols + col];
+  }
+  for (; r < r1; ++r) a0 += in[r * cols + col];
+  out[(size_t)blockIdx.y * cols + col] = (a0 + a1) + (a2 + a3);
+}
+
 // moments [blocks][C][2] (sum, sum sq over each row block) -> mean/rstd, affine (s,t) of y = s*h + t, running stats.
 // One wave per channel: lanes stride over the row blocks (fixed lane->block mapping + xor tree => deterministic).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ moments, int blocks, long R, int C, int training,
@@ -1327,7 +1346,7 @@ constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gra
 
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
-  long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, wb2, wb3, total;
+  long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
 };
 FwdWs fwd_ws(const Dims& d) {
   FwdWs w; long o = 0;
@@ -1336,6 +1355,7 @@ FwdWs fwd_ws(const Dims& d) {
   w.H2 = take(d.R * d.ld2); w.mean2 = take(d.ld2); w.rstd2 = take(d.ld2); w.s2 = take(d.ld2); w.t2 = take(d.ld2);
   w.H3 = take(d.R * d.ld3); w.mean3 = take(d.ld3); w.rstd3 = take(d.ld3); w.s3 = take(d.ld3); w.t3 = take(d.ld3);
   w.moments = take((long)d.rb * d.C2 * 2 * 2);  // doubles
+  w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
   w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
   w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
   w.total = o;
@@ -1364,7 +1384,7 @@ L1Geo l1_geo(const Dims& d) {
   return g;
 }
 struct BwdWs {
-  long GY2, GY1, sums, k, l4p, P, Q, Pp, Qp, dF, dG, seg, segw, tn, wt2, wt3, total;
+  long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, dF, dG, seg, segw, tn, wt2, wt3, total;
   int chunks;
 };
 BwdWs bwd_ws(const Dims& d) {
@@ -1374,8 +1394,10 @@ BwdWs bwd_ws(const Dims& d) {
   const int l4b = (int)((d.R + L4_ROWS - 1) / L4_ROWS);
   w.GY2 = take(d.R * d.ld2); w.GY1 = take(d.R * d.ld1);
   w.sums = take((long)(d.rb > l4b ? d.rb : l4b) * d.C1 * 2 * 2);
+  w.sred = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.C1 * 2 * 2 : 0);  // doubles
   w.k = take(3 * d.ld1);
   w.l4p = take((long)l4b * (3 * d.C3 + 4));
+  w.l4red = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * (3 * d.C3 + 4) : 0);
   w.P = take((long)d.B * d.ld1); w.Q = take((long)d.N * d.ld1); w.dF = take((long)d.B * d.ld1); w.dG = take((long)d.N * d.ld1);
   {
     const L1Geo g = l1_geo(d);
@@ -1471,6 +1493,17 @@ int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, float* par
   return tn_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, part, out, ldo, off, st)
                         : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, part, out, ldo, off, st);
 }
+// -> pointer / row count the finalize kernels should read: the partials themselves, or their 64-segment pre-reduction
+template <class T>
+int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) {
+  if (rows <= PRE_MIN_ROWS) return 0;
+  const int per = (rows + PRE_SEGMENTS - 1) / PRE_SEGMENTS, segs = (rows + per - 1) / per;
+  colsum_segments_kernel<T><<<dim3(obman_cdiv(cols, 256), segs), 256, 0, st>>>(part, rows, cols, per, scratch);
+  OBMAN_LAUNCH_CHECK();
+  part = scratch;
+  rows = segs;
+  return 0;
+}
 bool params_ok(const obman_pointgen_params* p) {
   return p && p->B > 0 && p->N > 0 && p->C1 >= 8 && p->C1 / 4 <= 128 && p->grid && p->feat && p->w1 && p->w2 && p->w3 && p->w4;
 }
@@ -1513,7 +1546,10 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
       rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
     }
     if (rc) return rc;
-    bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(moments, d.rb, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
+    const double* mom = moments;
+    int mrows = d.rb;
+    if (tr && (rc = pre_reduce<double>(mom, mrows, d.C2 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
+    bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(mom, mrows, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
                                                                p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
     OBMAN_LAUNCH_CHECK();
   }
@@ -1530,7 +1566,10 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
       rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
     }
     if (rc) return rc;
-    bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(moments, d.rb, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
+    const double* mom = moments;
+    int mrows = d.rb;
+    if (tr && (rc = pre_reduce<double>(mom, mrows, d.C3 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
+    bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(mom, mrows, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
     OBMAN_LAUNCH_CHECK();
   }
@@ -1557,12 +1596,20 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
   l4_bwd_kernel<<<l4b, 128, 0, st>>>(g_out, ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3,
                                       L4_ROWS, sums, ws2 + v.l4p);
   OBMAN_LAUNCH_CHECK();
-  l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 4), 256, 0, st>>>(ws2 + v.l4p, l4b, d.C3, g->w4, g->b4);
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sums, l4b, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2], g->bn_b[2],
+  int rc;
+  {
+    const float* lp = ws2 + v.l4p;
+    int lrows = l4b;
+    if ((rc = pre_reduce<float>(lp, lrows, 3 * d.C3 + 4, ws2 + v.l4red, st))) return rc;
+    l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 4), 256, 0, st>>>(lp, lrows, d.C3, g->w4, g->b4);
+  }
+  const double* sp = sums;
+  int srows = l4b;
+  if ((rc = pre_reduce<double>(sp, srows, d.C3 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sp, srows, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2], g->bn_b[2],
                                                                  g->b3, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
   AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
-  int rc;
   {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
     ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
     rc = d.bf16 ? launch_tn_bf16<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, ws2 + v.tn, g->w3, d.C2, 0, st)
@@ -1583,7 +1630,10 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     }
     if (rc) return rc;
   }
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sums, d.rb, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
+  sp = sums;
+  srows = d.rb;
+  if ((rc = pre_reduce<double>(sp, srows, d.C2 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
   AGradH gh2{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, R, d.C2};

@@ -36,7 +36,9 @@ def _oracle(dec, feats, grid, training, mfma_round=None):
 @pytest.mark.parametrize("c1,B,subdiv,training,patches", [(35, 3, 1, True, 1), (35, 2, 1, False, 1), (515, 4, 3, True, 1),
                                                           (515, 2, 2, False, 1), (131, 5, 2, True, 1), (515, 2, 1, True, 25),
                                                           # 4 050 template vertices: the segmented layer-1 finalize of large templates (N > 2048)
-                                                          (35, 2, 2, True, 25), (131, 3, 2, False, 25)])
+                                                          (35, 2, 2, True, 25), (131, 3, 2, False, 25),
+                                                          # 68 850 rows = 538 row blocks: the pre-reduction of the per-block BatchNorm partials (> 512 blocks)
+                                                          (35, 17, 2, True, 25)])
 def test_decoder_forward_backward_matches_oracle(c1, B, subdiv, training, patches):
     from obman_train_amd import ops
 
