@@ -299,9 +299,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+    else:
+        out = None
     if use_dist:
         dist.destroy_process_group()
+    if out is not None:
+        # the JSON line must be the LAST line on stdout: RCCL writes its version banner through C stdio, whose buffer would
+        # otherwise be flushed at process exit, after Python's print
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
