@@ -175,6 +175,53 @@ def input_stream_probe(batch, image_size, src_hw=(270, 480)):
             "note": "outside the timed region; integer/fp64 ALU-bound (exact PIL uint8 semantics), not HBM-bound"}
 
 
+def pcie_inclusive_probe(model, opt, sample, batch, image_size, train_step, steps=10):
+    """NOT the headline: the same train step when every batch starts in HOST memory, as the reference's DataLoader delivers it.
+    (a) pinned fp32 image tensors uploaded per step (50 MB at bs 64) - what `HandNet.forward` does with a CPU sample;
+    (b) uint8 source frames (480x270) staged + uploaded + rendered by the GPU input stream (K10) per step."""
+    import random
+
+    import numpy as np
+
+    from obman_train_amd.handobjectdatasets import HandDataset, SyntheticPoses
+    from obman_train_amd.queries import BaseQueries, TransQueries
+
+    out = {}
+    dev = sample[TransQueries.images].device
+    host = {k: (v.detach().cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in sample.items()}
+
+    def timed(step):
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def from_host_tensors():
+        dev_sample = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in host.items()}
+        train_step(model, opt, dev_sample)
+
+    t = timed(from_host_tensors)
+    out["host_fp32_tensors"] = {"ms_per_step": t * 1e3, "images_per_s": batch / t, "h2d_MB_per_step": batch * 3 * image_size * image_size * 4 / 1e6}
+    np.random.seed(1)
+    random.seed(1)
+    ds = HandDataset(SyntheticPoses(n=batch, src_hw=(270, 480)), inp_res=image_size, sides="left",
+                     queries=[TransQueries.images, BaseQueries.sides])
+    plans = [ds.get_sample(i)[TransQueries.images] for i in range(batch)]
+    stage = ds.image_stage(channels_last=True)
+    rest = {k: v for k, v in sample.items() if k is not TransQueries.images}
+
+    def from_frames():
+        train_step(model, opt, {**rest, TransQueries.images: stage(plans)})
+
+    t = timed(from_frames)
+    out["uint8_frames_gpu_input_stream"] = {"ms_per_step": t * 1e3, "images_per_s": batch / t, "h2d_MB_per_step": batch * 270 * 480 * 3 / 1e6}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -296,6 +343,7 @@ def main():
         }
         if world == 1:
             out["input_stream"] = input_stream_probe(args.batch, args.image_size)
+            out["pcie_inclusive"] = pcie_inclusive_probe(model, opt, sample, args.batch, args.image_size, train_step)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
