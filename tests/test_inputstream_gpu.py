@@ -146,6 +146,16 @@ def test_train_step_consumes_the_device_stream():
     ds = HandDataset(SyntheticPoses(n=4, src_hw=(135, 240)), inp_res=128, sides="left",
                      queries=[TransQueries.images, TransQueries.joints3d, TransQueries.verts3d, TransQueries.objpoints3d,
                               TransQueries.center3d, TransQueries.affinetrans, TransQueries.camintrs, BaseQueries.sides])
+    # the prefetching loader (side stream + event hand-over) must deliver the same bytes as the synchronous one
+    def images_of(prefetch):
+        np.random.seed(0)
+        random.seed(0)
+        return [b[TransQueries.images].clone() for b in DeviceBatchLoader(ds, batch_size=2, drop_last=True, channels_last=True, prefetch=prefetch)]
+
+    sync_imgs, pre_imgs = images_of(False), images_of(True)
+    assert len(sync_imgs) == len(pre_imgs) == 2 and all(torch.equal(a, b) for a, b in zip(sync_imgs, pre_imgs))
+    np.random.seed(0)
+    random.seed(0)
     loader = DeviceBatchLoader(ds, batch_size=2, num_workers=0, drop_last=True, channels_last=True)
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
