@@ -48,14 +48,32 @@ struct PmDir {
 // 4x more waves are in flight to hide the LDS latency (the r01a kernel ran ~1.2 waves/SIMD and was
 // latency-bound).  The four partial (min, group) pairs are merged through LDS lexicographically
 // (value, then lower group start => first index), then 64*QPT lanes resolve the exact index.
+struct PmGrid { int gx, gz, B, xcd; };  // query tiles (x reference splits) per direction, directions in this launch, samples
+
 template <int QPT>
-__global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir d1) {
-  const PmDir d = blockIdx.z == 0 ? d0 : d1;
+__global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir d1, PmGrid pg) {
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  All blocks
+  // of one sample (every query tile, both directions: they read the same two point sets) take consecutive slots on ONE XCD,
+  // so a sample's points are fetched from HBM by one L2 instead of by all eight (profiles/r01_chamfer_pmc.md: 3.5x the
+  // algorithmic bytes at 642 x 600 before).
+  int b, tile, dir;
+  if (pg.xcd) {
+    const int id = blockIdx.x, members = pg.gx * pg.gz, slot = id >> 3, m = slot % members;
+    b = (slot / members) * 8 + (id & 7);
+    dir = m / pg.gx;
+    tile = m - dir * pg.gx;
+  } else {
+    const int id = blockIdx.x, m = id % (pg.gx * pg.gz);
+    b = id / (pg.gx * pg.gz);
+    dir = m / pg.gx;
+    tile = m - dir * pg.gx;
+  }
+  if (b >= pg.B) return;
+  const PmDir d = dir == 0 ? d0 : d1;
   if (d.omin == nullptr) return;
-  const int tile = blockIdx.x;
   if (tile >= d.qtiles * d.rsplit) return;
   const int qt = tile % d.qtiles, rs = tile / d.qtiles;
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ qb = d.q + (size_t)b * d.nq * 3;
   const float* __restrict__ rb = d.r + (size_t)b * d.nr * 3;
 
@@ -279,7 +297,10 @@ int choose_qpt(int B, int nq, int nr) {
 
 template <int QPT>
 void launch_fwd_t(dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b) {
-  pairmin_fwd_kernel<QPT><<<grid, PM_THREADS, smem, st>>>(a, b);
+  static const int xcd = [] { const char* e = getenv("OBMAN_PM_XCD"); return e ? atoi(e) : 1; }();  // A/B knob
+  const PmGrid pg{(int)grid.x, (int)grid.z, (int)grid.y, xcd};
+  const unsigned blocks = (unsigned)(((pg.B + 7) / 8) * 8) * grid.x * grid.z;  // samples padded to a multiple of 8 (one group per XCD slot)
+  pairmin_fwd_kernel<QPT><<<dim3(blocks), PM_THREADS, smem, st>>>(a, b, pg);
 }
 void launch_fwd(int qpt, dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b) {
   ObmanProfScope prof(OBMAN_K_PAIRMIN_FWD, st);

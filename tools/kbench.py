@@ -45,6 +45,8 @@ def bench_chamfer():
     sizes = ((64, 642, 600), (64, 2562, 600), (64, 16050, 600), (64, 64050, 600))
     if os.environ.get("OBMAN_KBENCH_ONE"):
         sizes = ((64, 64050, 600),)
+    if os.environ.get("OBMAN_KBENCH_NPRED"):  # e.g. 642: one size (PMC passes)
+        sizes = ((64, int(os.environ["OBMAN_KBENCH_NPRED"]), 600),)
     for B, n_p, n_g in sizes:
         p = (torch.randn(B, n_p, 3, device="cuda") * 40).requires_grad_()
         g = torch.randn(B, n_g, 3, device="cuda") * 40
