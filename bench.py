@@ -319,13 +319,16 @@ def main():
         # Chamfer fwd algorithmic bytes 20*(N+M) per sample, ~10*N*M flop per sample
         alg_bytes = 20.0 * (n_pred + n_gt) * args.batch
         alg_flop = 10.0 * n_pred * n_gt * args.batch
-        avg_s = (pm_ms / max(pm_n, 1)) * 1e-3
+        # per Chamfer call: one launch at configs[1]; at asymmetric 25-patch sizes each direction is its own launch and the
+        # algorithmic bytes below are those of the whole call, so the durations of a call's launches are summed
+        avg_s = (pm_ms / max(args.steps, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if pm_n else None
         roof = {
             "kernel": "pairmin_fwd_kernel (Chamfer fwd, both directions, %d samples/launch)" % args.batch,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
-            "avg_launch_us": avg_s * 1e6, "launches": pm_n, "alg_bytes_per_launch": alg_bytes,
+            "avg_launch_us": avg_s * 1e6, "launches": pm_n, "launches_per_call": pm_n / max(args.steps, 1),
+            "alg_bytes_per_launch": alg_bytes,
             "valu": {"achieved_tflops": alg_flop / avg_s / 1e12 if pm_n else None, "peak_tflops": VALU_PEAK_TFLOPS,
                      "frac": (alg_flop / avg_s / 1e12 / VALU_PEAK_TFLOPS) if pm_n else None,
                      "note": "binding bound: intensity N*M/(2(N+M)) = %.0f flop/B >> 20 flop/B ridge"
