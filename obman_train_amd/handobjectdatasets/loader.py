@@ -23,7 +23,10 @@ class DeviceBatchLoader:
     def __init__(self, dataset, batch_size=1, shuffle=False, num_workers=0, drop_last=False, device="cuda",
                  channels_last=False, stage=None, prefetch=True, **loader_kwargs):
         self.dataset = dataset
-        self.stage = stage if stage is not None else dataset.image_stage(device=device, channels_last=channels_last)
+        inner = dataset
+        while not hasattr(inner, "image_stage") and hasattr(inner, "dataset"):  # torch.utils.data.Subset (get_dataset's limit_size)
+            inner = inner.dataset
+        self.stage = stage if stage is not None else inner.image_stage(device=device, channels_last=channels_last)
         self.prefetch = bool(prefetch)
         self.loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
                                                   drop_last=drop_last, collate_fn=_as_list, **loader_kwargs)

@@ -146,3 +146,32 @@ def test_device_batch_loader_batches_like_the_reference_dataloader(workers):
     assert b[TransQueries.images].shape == (4, 3, 32, 32) and b[TransQueries.verts3d].shape == (4, 778, 3)
     assert b[TransQueries.objpoints3d].shape == (4, 600, 3) and b[TransQueries.objpoints3d].dtype == torch.float32
     assert b[BaseQueries.sides] == ["left"] * 4
+
+
+def test_get_dataset_factory_mirrors_the_reference_arguments():
+    """netscripts/get_datasets.get_dataset (reference get_datasets.py:11-139): query intersection, jitter ranges, limit_size
+    subsetting; readers come from the reference package (absent here -> a clear ImportError), 'synthetic' is the stand-in."""
+    import warnings
+
+    from torch.utils.data import Subset
+
+    from obman_train_amd.handobjectdatasets import DeviceBatchLoader
+    from obman_train_amd.netscripts.get_datasets import get_dataset
+
+    ds = get_dataset("synthetic", "train", sides="left", meta={"size": 12, "src_hw": (40, 60)},
+                     max_queries=[TransQueries.images, TransQueries.joints3d, TransQueries.objverts3d, BaseQueries.sides])
+    assert isinstance(ds, HandDataset) and len(ds) == 12
+    assert ds.queries == [TransQueries.images, TransQueries.joints3d, BaseQueries.sides]  # objverts3d: not offered by the reader
+    assert (ds.scale_jittering, ds.center_jittering, ds.max_rot, ds.as_obj_only) == (0.3, 0.2, np.pi, False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sub = get_dataset("synthetic", "train", meta={"size": 12, "src_hw": (40, 60)}, limit_size=5)
+    assert isinstance(sub, Subset) and len(sub) == 5
+    stage = _CountingStage(256)
+    assert len(list(DeviceBatchLoader(sub, batch_size=2, stage=stage))) == 3 and stage.batches == [2, 2, 1]
+    with pytest.raises(ValueError):
+        get_dataset("imagenet", "train")
+    with pytest.raises(ValueError):
+        get_dataset("fhbhands_feet", "train", meta={"fhbhands_split_type": "", "fhbhands_split_choice": ""})
+    with pytest.raises(ImportError):
+        get_dataset("obman", "train", meta={"mode": "all", "override_scale": False})
