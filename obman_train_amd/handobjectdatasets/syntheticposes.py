@@ -9,8 +9,11 @@ from ..queries import BaseQueries, TransQueries
 
 
 class SyntheticPoses:
-    def __init__(self, n=256, src_hw=(270, 480), seed=0, n_obj=600, frame_pool=8):
+    name = "synthetic"
+
+    def __init__(self, n=256, src_hw=(270, 480), seed=0, n_obj=600, frame_pool=8, split="train"):
         self.n, self.src_hw, self.seed, self.n_obj = int(n), tuple(src_hw), int(seed), int(n_obj)
+        self.split = split
         self._frames = {}  # a real reader decodes a JPEG here; the stand-in cycles through a few cached random frames
         self._frame_pool = int(frame_pool)
         self.all_queries = [BaseQueries.images, BaseQueries.joints2d, BaseQueries.joints3d, BaseQueries.verts3d, BaseQueries.sides,

@@ -31,7 +31,8 @@ def _reference_readers():
 
 def _pose_dataset(dat_name, split, mini_factor, meta, use_cache):
     if dat_name == "synthetic":
-        return SyntheticPoses(n=int(meta.get("size", 256)), src_hw=tuple(meta.get("src_hw", (270, 480))), seed=int(meta.get("seed", 0)))
+        return SyntheticPoses(n=int(meta.get("size", 256)), src_hw=tuple(meta.get("src_hw", (270, 480))), seed=int(meta.get("seed", 0)),
+                              split=split)
     known = dat_name in ("obman", "core50", "yanademo", "stereohands") or "fhbhands" in dat_name
     if not known:
         raise ValueError("Unrecognized dataset name {}".format(dat_name))

@@ -175,3 +175,25 @@ def test_get_dataset_factory_mirrors_the_reference_arguments():
         get_dataset("fhbhands_feet", "train", meta={"fhbhands_split_type": "", "fhbhands_split_choice": ""})
     with pytest.raises(ImportError):
         get_dataset("obman", "train", meta={"mode": "all", "override_scale": False})
+
+
+def test_concat_dataloader_round_robin_and_tags():
+    """datautils.ConcatDataloader (reference datautils.py:5-39): alternates loaders, stops with the shortest, tags batches."""
+    import warnings
+
+    from obman_train_amd.datautils import ConcatDataloader
+    from obman_train_amd.handobjectdatasets import DeviceBatchLoader
+    from obman_train_amd.netscripts.get_datasets import get_dataset
+
+    q = [TransQueries.images, TransQueries.joints3d, BaseQueries.sides]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = get_dataset("synthetic", "train", meta={"size": 6, "src_hw": (40, 60)}, max_queries=q, sides="left")
+        b = get_dataset("synthetic", "val", meta={"size": 9, "src_hw": (40, 60), "seed": 1}, max_queries=q, sides="left", limit_size=8)
+    loaders = [DeviceBatchLoader(a, batch_size=2, stage=_CountingStage(256)), DeviceBatchLoader(b, batch_size=2, stage=_CountingStage(256))]
+    cat = ConcatDataloader(loaders)
+    assert len(cat) == 2 * 3
+    batches = list(cat)
+    assert [x["split"] for x in batches] == ["train", "val"] * 3          # a has 3 batches, b has 4: stops with the shorter
+    assert all(x["dataset"] == "synthetic" and x["root"] == "wrist" and x["use_stereohands"] is False for x in batches)
+    assert batches[0][TransQueries.joints3d].shape == (2, 21, 3)
