@@ -170,3 +170,35 @@ def test_train_step_consumes_the_device_stream():
         assert results["verts"].shape == (2, 778, 3)
         seen += 1
     assert seen == 2
+
+
+def test_epoch_pass_over_the_whole_input_pipeline():
+    """get_dataset -> DeviceBatchLoader (prefetch) -> ConcatDataloader -> epoch_pass: the wiring of traineval.py:200-330 on this
+    package end to end, one training epoch and one validation epoch over two synthetic 'datasets'."""
+    import warnings
+
+    from obman_train_amd.datautils import ConcatDataloader
+    from obman_train_amd.handobjectdatasets import DeviceBatchLoader
+    from obman_train_amd.netscripts.epochpass3d import epoch_pass
+    from obman_train_amd.netscripts.get_datasets import get_dataset
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.synthetic import CONFIGS
+    from obman_train_amd.trainer import make_optimizer
+
+    np.random.seed(0)
+    random.seed(0)
+    torch.manual_seed(0)
+    loaders = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for seed in (0, 1):
+            ds = get_dataset("synthetic", "train", sides="left", meta={"size": 4, "src_hw": (135, 240), "seed": seed})
+            ds.inp_res = 128
+            loaders.append(DeviceBatchLoader(ds, batch_size=2, drop_last=True, channels_last=True))
+    model = HandNet(**CONFIGS["c2"]).cuda()
+    opt = make_optimizer(model)
+    meters, _ = epoch_pass(ConcatDataloader(loaders), model, epoch=0, optimizer=opt, train=True, debug=False)
+    vals = {k: m.avg for k, m in meters.average_meters.items()}
+    assert vals and all(np.isfinite(v) for v in vals.values()), vals
+    meters, _ = epoch_pass(ConcatDataloader(loaders), model, epoch=0, train=False, debug=False)
+    assert all(np.isfinite(m.avg) for m in meters.average_meters.values())
