@@ -23,20 +23,28 @@ class GradientBuckets:
     gradient of a bucket has arrived its post-accumulate hook packs the whole bucket with ONE ``torch._foreach_copy_``
     launch, re-points every ``.grad`` at its slice of the flat buffer (strided like the parameter: fused optimizers need
     grad.layout == param.layout, conv filters are channels_last) and starts the asynchronous all-reduce (``AVG`` on RCCL,
-    so no scaling pass).  ``finish()`` waits before the optimizer step.  Parameters without a gradient in a step
-    (``base_net.fc``) contribute zeros and keep ``grad = None``."""
+    so no scaling pass).  ``finish()`` waits before the optimizer step.
 
-    def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None, force=False):
+    The collective sequence is STATIC: buckets are all-reduced strictly in index order (a bucket that completes early waits
+    for its predecessors), so ranks whose autograd graphs differ in a step (a data-dependent branch active on one rank only)
+    still issue identical collectives.  A parameter without a gradient in a step contributes zeros and - like every other
+    parameter of its bucket - ends the step with ``.grad`` = the averaged view on EVERY rank, so the optimizer applies the
+    same update everywhere.  Parameters that can never receive a gradient (``base_net.fc``, unused by the feature
+    extractor) are passed in ``exclude``: they are left out of the buckets and keep ``grad = None`` as in the reference."""
+
+    def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None, force=False, exclude=()):
         self.group = group
         live = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if live else 1
-        self.params = [p for p in params if p.requires_grad]
+        skip = {id(p) for p in exclude}
+        self.params = [p for p in params if p.requires_grad and id(p) not in skip]
         self.enabled = self.world > 1 or (force and live)  # force: single-rank self-test of the whole mechanism
         self.buckets = []      # (flat buffer, [(param, offset, numel)])
         self._where = {}
         self._pending = []
         self._works = []
         self._seen = set()
+        self._next = 0         # next bucket to all-reduce (index order)
         if not self.enabled:
             return
         self._avg = dist.get_backend(group) == "nccl"  # RCCL averages in the collective; gloo has no AVG
@@ -84,35 +92,37 @@ class GradientBuckets:
             else:
                 views.append(v)
                 grads.append(p.grad)
+            p.grad = v
         if views:
             torch._foreach_copy_(views, grads)
-            for (p, off, n), v in zip([s for s in slots if s[0].grad is not None], views):
-                p.grad = v
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._works.append((b, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
+
+    def _drain(self, everything=False):
+        while self._next < len(self.buckets) and (everything or self._pending[self._next] == 0):
+            self._launch(self._next)
+            self._next += 1
 
     def _on_grad(self, p):
         if p in self._seen:  # a second accumulation into the same parameter in one step (not on this path)
             return
         self._seen.add(p)
-        b = self._where[p]
-        self._pending[b] -= 1
-        if self._pending[b] == 0:
-            self._launch(b)
+        self._pending[self._where[p]] -= 1
+        self._drain()
 
     def finish(self):
-        """Wait for every bucket (launching the ones left open by gradient-less parameters).  Call before ``optimizer.step()``."""
+        """Wait for every bucket (launching, in index order, the ones left open by gradient-less parameters).  Call before
+        ``optimizer.step()``."""
         if not self.enabled:
             return
-        for b, left in enumerate(self._pending):
-            if left > 0:
-                self._launch(b)
+        self._drain(everything=True)
         for b, work in self._works:
             work.wait()
             if not self._avg:
                 self.buckets[b][0].mul_(1.0 / self.world)
         self._works = []
         self._seen = set()
+        self._next = 0
         self._pending = [len(slots) for _, slots in self.buckets]
 
 

@@ -102,6 +102,13 @@ class HandNet(nn.Module):
         if self.atlas_loss.lambda_laplacian is not None:
             self.atlas_loss.lambda_laplacian = gamma * self.atlas_loss.lambda_laplacian
 
+    def unused_parameters(self):
+        """Parameters that can never receive a gradient: the encoders' ImageNet classifier heads (``fc`` is part of the
+        checkpoint layout but the feature extractor never calls it, resnet.py:184-186).  ``dp.GradientBuckets(exclude=...)``
+        leaves them out of the all-reduce; they keep ``grad = None`` exactly as in the reference."""
+        nets = [self.base_net] + ([self.atlas_base_net] if self.atlas_separate_encoder else [])
+        return [p for net in nets for p in net.fc.parameters()]
+
     def _device(self):
         return next(self.base_net.parameters()).device
 

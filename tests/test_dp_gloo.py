@@ -48,7 +48,7 @@ def _worker(rank, world, port, out_dir):
             for p in net.parameters():
                 p.add_(1.0)
     broadcast_parameters(net)
-    buckets = GradientBuckets(net.parameters(), bucket_bytes=256)
+    buckets = GradientBuckets(net.parameters(), bucket_bytes=256, exclude=net.unused.parameters())
     assert len(buckets.buckets) >= 3
     x, y = _data()
     shard = slice(rank * 4, rank * 4 + 4)
@@ -82,6 +82,57 @@ def test_bucketed_allreduce_matches_full_batch(tmp_path):
                 assert got[k] is None
             else:
                 torch.testing.assert_close(got[k], g, rtol=1e-5, atol=1e-6)
+
+
+class _Branchy(nn.Module):
+    """``side`` only contributes when asked: a data-dependent branch (like the atlas / contact branches)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a, self.side, self.b = nn.Linear(6, 6), nn.Linear(6, 6), nn.Linear(6, 2)
+
+    def forward(self, x, use_side):
+        h = torch.relu(self.a(x))
+        if use_side:
+            h = h + self.side(h)
+        return self.b(h)
+
+
+def _branchy_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from obman_train_amd.dp import GradientBuckets
+
+    torch.manual_seed(0)
+    net = _Branchy()
+    buckets = GradientBuckets(net.parameters(), bucket_bytes=64)  # several buckets; `side` sits in the middle
+    x = torch.ones(3, 6) * (rank + 1)
+    buckets.zero_grad()
+    net(x, use_side=(rank == 0)).sum().backward()  # rank 1 never touches `side`: its hooks never fire there
+    buckets.finish()
+    torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, os.path.join(out_dir, "branchy_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_rank_divergent_graphs_issue_identical_collectives(tmp_path):
+    """A branch active on one rank only: the static bucket order keeps the collectives matched (no hang, no mismatched
+    sizes) and every rank ends with the same averaged gradient for every bucketed parameter."""
+    world, port = 2, _free_port()
+    mp.start_processes(_branchy_worker, args=(world, port, str(tmp_path)), nprocs=world, start_method="spawn")
+    torch.manual_seed(0)
+    net = _Branchy()
+    want = {}
+    for rank in range(world):
+        net.zero_grad()
+        net(torch.ones(3, 6) * (rank + 1), use_side=(rank == 0)).sum().backward()
+        for k, p in net.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            want[k] = want.get(k, 0) + g / world
+    got0 = torch.load(os.path.join(str(tmp_path), "branchy_0.pt"))
+    got1 = torch.load(os.path.join(str(tmp_path), "branchy_1.pt"))
+    for k in want:
+        torch.testing.assert_close(got0[k], want[k], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got1[k], got0[k], rtol=0, atol=0)
 
 
 def test_single_process_is_a_noop():
