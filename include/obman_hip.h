@@ -91,6 +91,12 @@ int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const 
  * exterior <=> hits even (contactutils.py:158).  No gradient (inputs are detached, contactloss.py:170). */
 int obman_mesh_contains_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
                             int F, int* hits, obman_stream_t stream);
+/* Multi-patch templates (extension of this build, BASELINE.json configs 3/5; no reference counterpart): faces = G <= 32
+ * consecutive groups of group_faces triangles, each a closed patch surface -> parity_bits [B,P] int32, bit g = parity of
+ * the crossings with patch g.  Inside the union of the patches <=> parity_bits != 0 (the OR of the per-patch tests of
+ * contactutils.py:158; the parity of the TOTAL count would call a point inside two overlapping patches exterior). */
+int obman_mesh_contains_groups_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
+                                   int F, int group_faces, int* parity_bits, obman_stream_t stream);
 
 /* ---- K5: contact / penetration loss tail ---------------------------------------------------------
  * Replaces contactloss.py:173-308 (after pair-min and inside test).  hand [B,V,3], obj [B,N,3],

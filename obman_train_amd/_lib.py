@@ -20,6 +20,7 @@ _SIGNATURES = {
     "obman_chamfer_fwd": (_c_int, "ppiiipppppp" "plp"),
     "obman_chamfer_bwd": (_c_int, "ppiiipppppp" "p"),
     "obman_mesh_contains_fwd": (_c_int, "ppp" "iiii" "pp"),
+    "obman_mesh_contains_groups_fwd": (_c_int, "ppp" "iiii" "i" "pp"),
     "obman_contact_fwd": (_c_int, "ppppp" "iii" "pp" "ii" "ifif" "ppppp" "p"),
     "obman_contact_bwd": (_c_int, "pppppppp" "iii" "ifif" "i" "pp" "p"),
     "obman_pointgen_ws_floats": (_c_long, "pi"),

@@ -10,6 +10,12 @@
 // Same constants/inequalities as the reference (App. C #8): fixed direction, tol 1e-7, strict
 // u>0,u<1,v>0,u+v<1, t>=tol, exterior <=> even hit count.
 // Bound: fp32 VALU; algorithmic bytes B*(P*12 + Nv*12 + F*12 + P*4).
+//
+// Grouped mode (multi-patch templates, an extension of this build: BASELINE.json configs 3/5): the face list is G
+// consecutive groups of `group_faces` triangles, each a closed patch surface.  "Inside the union of the patches" is the OR
+// of the per-patch parities, not the parity of the total count (a point inside two overlapping patches must stay
+// interior), so the kernel folds each group's count into bit g of a per-point word; blocks that share a group merge with
+// atomicXor (commutative => deterministic).  Triangle tiles never straddle a group boundary.
 #include "common.h"
 #include "prof.h"
 #include "../../include/obman_hip.h"
@@ -29,7 +35,8 @@ template <int PPT>
 __global__ __launch_bounds__(MC_THREADS) void contains_kernel(const float* __restrict__ points,
                                                               const float* __restrict__ verts,
                                                               const int* __restrict__ faces, int P, int Nv, int F,
-                                                              int ptiles, int tchunk, int tsplit, int* __restrict__ hits) {
+                                                              int ptiles, int tchunk, int tsplit, int group_faces,
+                                                              int* __restrict__ hits) {
   const int b = blockIdx.y, tid = threadIdx.x;
   const int pt = blockIdx.x % ptiles, ts = blockIdx.x / ptiles;
   const float* __restrict__ pb = points + (size_t)b * P * 3;
@@ -48,8 +55,14 @@ __global__ __launch_bounds__(MC_THREADS) void contains_kernel(const float* __res
     cnt[k] = 0;
   }
   const int tbeg = ts * tchunk, tend = min(F, tbeg + tchunk);
-  for (int base = tbeg; base < tend; base += MC_TRI_TILE) {
-    const int n = min(MC_TRI_TILE, tend - base);
+  int bits[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) bits[k] = 0;
+  int n = 0;
+  for (int base = tbeg; base < tend; base += n) {
+    n = min(MC_TRI_TILE, tend - base);
+    const int grp = group_faces ? base / group_faces : 0;
+    if (group_faces) n = min(n, (grp + 1) * group_faces - base);  // stop at the patch boundary
     for (int t = tid; t < n; t += MC_THREADS) {
       const int* f = faces + (size_t)(base + t) * 3;
       const float* a = vb + (size_t)f[0] * 3;
@@ -90,24 +103,32 @@ __global__ __launch_bounds__(MC_THREADS) void contains_kernel(const float* __res
       }
     }
     __syncthreads();
+    if (group_faces) {  // fold this tile's parity into the patch's bit
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) { bits[k] ^= (cnt[k] & 1) << grp; cnt[k] = 0; }
+    }
   }
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int pi = pt * (MC_THREADS * PPT) + k * MC_THREADS + tid;
     if (pi >= P) continue;
     int* dst = hits + (size_t)b * P + pi;
-    if (tsplit == 1) *dst = cnt[k];
+    if (group_faces) {
+      if (tsplit == 1) *dst = bits[k];
+      else if (bits[k]) atomicXor(dst, bits[k]);
+    } else if (tsplit == 1) *dst = cnt[k];
     else if (cnt[k]) atomicAdd(dst, cnt[k]);
   }
 }
 
 }  // namespace
 
-extern "C" int obman_mesh_contains_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
-                                       int F, int* hits, obman_stream_t stream) {
+namespace {
+int contains_launch(const float* points, const float* verts, const int* faces, int B, int P, int Nv, int F, int group_faces,
+                    int* hits, hipStream_t st) {
   if (B < 0 || P < 0 || Nv <= 0 || F < 0 || !hits) return -1;
+  if (group_faces < 0 || (group_faces > 0 && (F % group_faces != 0 || F / group_faces > 32))) return -1;
   if (B == 0 || P == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   if (F == 0) return (int)hipMemsetAsync(hits, 0, sizeof(int) * (size_t)B * P, st);
   int ppt = 4;
   while (ppt > 1 && MC_THREADS * (ppt / 2) >= P) ppt >>= 1;  // smallest PPT whose tile still covers P
@@ -130,10 +151,22 @@ extern "C" int obman_mesh_contains_fwd(const float* points, const float* verts, 
   dim3 grid(ptiles * tsplit, B);
   ObmanProfScope prof(OBMAN_K_CONTAINS, st);
   switch (ppt) {
-    case 4: contains_kernel<4><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;
-    case 2: contains_kernel<2><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;
-    default: contains_kernel<1><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, hits); break;
+    case 4: contains_kernel<4><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, group_faces, hits); break;
+    case 2: contains_kernel<2><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, group_faces, hits); break;
+    default: contains_kernel<1><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, group_faces, hits); break;
   }
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int obman_mesh_contains_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
+                                       int F, int* hits, obman_stream_t stream) {
+  return contains_launch(points, verts, faces, B, P, Nv, F, 0, hits, (hipStream_t)stream);
+}
+
+extern "C" int obman_mesh_contains_groups_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
+                                              int F, int group_faces, int* parity_bits, obman_stream_t stream) {
+  if (group_faces <= 0) return -1;
+  return contains_launch(points, verts, faces, B, P, Nv, F, group_faces, parity_bits, (hipStream_t)stream);
 }

@@ -7,9 +7,13 @@ are 12/42/162/642/2562 for 0..4 subdivisions, faces 20*4**s.  The vertex
 *order* is this generator's own: anything that compares ``objpoints3d``
 element-wise must feed the same template to both sides.
 
-``multi_patch`` builds the P-patch template of BASELINE.json configs 3/5:
-P copies of the sphere, faces offset per patch (union of closed spheres, so
-the ray-parity inside test stays well defined).
+``multi_patch`` builds the P-patch template of BASELINE.json configs 3/5 (an
+extension; the reference has one sphere): P unit spheres at DISTINCT centres of
+the decoder's input domain (patch 0 at the origin = the reference's template,
+the others on a Fibonacci lattice of radius 3), faces offset per patch.  The
+shared PointGenCon therefore maps every patch to its own surface (distinct
+inputs), and each patch stays a closed surface, so the inside test is the OR of
+the per-patch ray parities (``ops.mesh_contains_hits(..., patches=P)``).
 """
 from functools import lru_cache
 
@@ -71,12 +75,29 @@ def icosphere(subdivisions=3):
     return v.copy(), f.copy()
 
 
+PATCH_RING_RADIUS = 3.0  # unit spheres centred >= ~2.1 apart for P <= 25: disjoint in the decoder's input domain
+
+
+def patch_centres(patches):
+    """[P,3] float64: patch 0 at the origin, patches 1..P-1 on a Fibonacci lattice of radius PATCH_RING_RADIUS."""
+    c = np.zeros((patches, 3), dtype=np.float64)
+    m = patches - 1
+    if m > 0:
+        k = np.arange(m, dtype=np.float64) + 0.5
+        z = 1.0 - 2.0 * k / m
+        r = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+        phi = k * (np.pi * (3.0 - 5.0 ** 0.5))
+        c[1:] = PATCH_RING_RADIUS * np.stack([r * np.cos(phi), r * np.sin(phi), z], 1)
+    return c
+
+
 def multi_patch(subdivisions=3, patches=1):
-    """P-patch template: verts [P*n,3], faces [P*f,3] (vertex ids offset per patch)."""
+    """P-patch template: verts [P*n,3] (unit sphere + patch centre), faces [P*f,3] (vertex ids offset per patch)."""
     v, f = icosphere(subdivisions)
     if patches == 1:
         return v, f
     n = v.shape[0]
-    vs = np.concatenate([v] * patches, 0)
+    centres = patch_centres(patches)
+    vs = np.concatenate([v + centres[p] for p in range(patches)], 0)
     fs = np.concatenate([f + p * n for p in range(patches)], 0)
     return vs, fs

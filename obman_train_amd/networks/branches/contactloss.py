@@ -72,7 +72,9 @@ def _faces_on(obj_faces, device):
 
 def compute_contact_loss(hand_verts_pt, hand_faces, obj_verts_pt, obj_faces, contact_thresh=5, contact_mode="dist_sq",
                          collision_thresh=10, collision_mode="dist_sq", contact_target="all", contact_sym=False,
-                         contact_zones="all"):
+                         contact_zones="all", obj_patches=1):
+    """``obj_patches`` (extension, default = the reference's single closed mesh): the object mesh is that many closed patch
+    surfaces (equal consecutive face groups); penetration = inside any patch."""
     if contact_target not in ops.TARGETS:
         raise ValueError("contact_target {} not in [all|obj|hand]".format(contact_target))
     if contact_mode not in ops.MODES:
@@ -85,7 +87,7 @@ def compute_contact_loss(hand_verts_pt, hand_faces, obj_verts_pt, obj_faces, con
         raise NotImplementedError("contact_sym is never enabled by HandNet (handnet.py:336-347)")
     dev = hand_verts_pt.device
     mins21, idx21, _, _ = ops.pairmin(hand_verts_pt.detach(), obj_verts_pt.detach(), want_y=False)
-    exterior, hits = mesh_exterior(hand_verts_pt, obj_verts_pt, _faces_on(obj_faces, dev))
+    exterior, hits = mesh_exterior(hand_verts_pt, obj_verts_pt, _faces_on(obj_faces, dev), patches=obj_patches)
     if contact_zones == "all":
         ids, off, nz, zmode = None, None, 0, 0
     else:

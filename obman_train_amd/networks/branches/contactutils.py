@@ -11,9 +11,10 @@ import torch
 from obman_train_amd import ops
 
 
-def mesh_exterior(points, obj_verts, faces_dev):
-    """points [B,P,3], obj_verts [B,Nv,3], faces_dev [F,3] int32 -> (exterior bool [B,P], hits int32)."""
-    hits = ops.mesh_contains_hits(points, obj_verts, faces_dev)
+def mesh_exterior(points, obj_verts, faces_dev, patches=1):
+    """points [B,P,3], obj_verts [B,Nv,3], faces_dev [F,3] int32 -> (exterior bool [B,P], hits int32 with the inside test in
+    its parity).  ``patches > 1``: faces are that many equal groups, each a closed surface; interior = inside any of them."""
+    hits = ops.mesh_contains_hits(points, obj_verts, faces_dev, patches=patches)
     return (hits & 1) == 0, hits
 
 

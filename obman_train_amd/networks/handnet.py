@@ -160,7 +160,7 @@ class HandNet(nn.Module):
                     self.atlas_branch.test_faces_dev, contact_thresh=self.contact_thresh,
                     contact_mode=self.contact_mode, collision_thresh=self.collision_thresh,
                     collision_mode=self.collision_mode, contact_target=self.contact_target,
-                    contact_zones=self.contact_zones)
+                    contact_zones=self.contact_zones, obj_patches=self.atlas_branch.patches)
                 if not no_loss:
                     if TransQueries.verts3d in sample and TransQueries.objpoints3d in sample:
                         dist_h2o_gt = ops.pairmin(sample[TransQueries.verts3d], sample[TransQueries.objpoints3d],

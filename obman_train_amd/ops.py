@@ -183,18 +183,28 @@ def mano_lbs(pose, betas, blob_right, blob_left=None, side=None, ncomps=30, use_
     return _ManoLBS.apply(pose, betas, blob_right, blob_left, side, ncomps, use_pca, center_idx, root_palm)
 
 
-def mesh_contains_hits(points, verts, faces):
-    """points [B,P,3], verts [B,Nv,3], faces [F,3] int32 (device) -> hits [B,P] int32 (ray/triangle
-    crossings along the reference's fixed direction; exterior <=> even).  No gradient."""
+def mesh_contains_hits(points, verts, faces, patches=1):
+    """points [B,P,3], verts [B,Nv,3], faces [F,3] int32 (device) -> hits [B,P] int32 whose PARITY is the inside test
+    (exterior <=> even).  ``patches == 1`` (the reference's single closed mesh): ray/triangle crossings along the
+    reference's fixed direction.  ``patches > 1`` (multi-patch template, faces = ``patches`` equal consecutive groups, each a
+    closed surface): 1 where the point is inside ANY patch (OR of the per-patch parities), else 0.  No gradient."""
     points, verts = _dev(points.detach(), "points"), _dev(verts.detach(), "verts")
     faces = _dev(faces, "faces", torch.int32)
     if points.dim() != 3 or verts.dim() != 3 or faces.dim() != 2 or faces.shape[1] != 3:
         raise ValueError("expected points [B,P,3], verts [B,Nv,3], faces [F,3]")
     B, P, Nv, F = points.shape[0], points.shape[1], verts.shape[1], faces.shape[0]
     hits = torch.empty((B, P), dtype=torch.int32, device=points.device)
-    _lib.check(_lib.lib().obman_mesh_contains_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P, Nv, F,
-                                                  hits.data_ptr(), _stream()), "obman_mesh_contains_fwd")
-    return hits
+    patches = int(patches)
+    if patches <= 1:
+        _lib.check(_lib.lib().obman_mesh_contains_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P, Nv, F,
+                                                      hits.data_ptr(), _stream()), "obman_mesh_contains_fwd")
+        return hits
+    if F % patches != 0 or patches > 32:
+        raise ValueError("multi-patch inside test needs <= 32 equal face groups, got F=%d patches=%d" % (F, patches))
+    _lib.check(_lib.lib().obman_mesh_contains_groups_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P, Nv, F,
+                                                         F // patches, hits.data_ptr(), _stream()),
+               "obman_mesh_contains_groups_fwd")
+    return (hits != 0).to(torch.int32)
 
 
 MODES = {"dist_sq": 0, "dist": 1, "dist_tanh": 2}
@@ -386,18 +396,17 @@ def bn_act(bn, x, skip=None, relu=True, count=True):
     fused = (x.is_cuda and x.dtype == torch.float32 and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
              and (skip is None or (_is_nhwc(skip) and skip.dtype == torch.float32 and skip.shape == x.shape)))
     training = bn.training or bn.running_mean is None
-    if not fused:
-        y = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
-                                           0.0 if bn.momentum is None else bn.momentum, bn.eps)
-        if skip is not None:
-            y = y + skip
-        return torch.relu(y) if relu else y
     if count and bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1  # callers with many layers pass count=False and bump all counters in one launch
     if bn.momentum is None:
         momentum = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
     else:
         momentum = bn.momentum
+    if not fused:  # stock ops, same bookkeeping as nn.BatchNorm2d.forward (counter bumped above, cumulative momentum)
+        y = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, momentum, bn.eps)
+        if skip is not None:
+            y = y + skip
+        return torch.relu(y) if relu else y
     return _BNAct.apply(x, skip, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum, relu)
 
 

@@ -111,16 +111,26 @@ def _penalty(mode, thresh, anchor_dists, sq_vals, what):
 def compute_contact_loss(
     hand_verts, hand_faces, obj_verts, obj_faces, zones=None,
     contact_thresh=5, contact_mode="dist_sq", collision_thresh=10, collision_mode="dist_sq",
-    contact_target="all", contact_sym=False, contact_zones="all",
+    contact_target="all", contact_sym=False, contact_zones="all", obj_patches=1,
 ):
     """contactloss.py:149-308.  ``zones`` = {zone: [vertex ids]} (the reference loads it from
-    assets/contact_zones.pkl at :262-265).  Returns (missed_loss, penetr_loss, contact_info, metrics)."""
+    assets/contact_zones.pkl at :262-265).  Returns (missed_loss, penetr_loss, contact_info, metrics).
+
+    ``obj_patches`` > 1 (the build's multi-patch extension, no reference counterpart): the faces are that many equal
+    consecutive groups, each a closed surface; the reference's inside test (:169-171) is applied per patch and a hand vertex
+    is interior when it is inside ANY patch."""
     dists = batch_pairwise_dist(hand_verts, obj_verts)  # [B,V,N]
     mins12, _ = dists.min(1)       # per obj vertex  [B,N]
     mins21, idx21 = dists.min(2)   # per hand vertex [B,V]
     faces_t = torch.as_tensor(np.asarray(obj_faces).astype(np.int64))
-    triangles = obj_verts[:, faces_t]
-    exterior = mesh_contains_points(hand_verts.detach(), triangles.detach())
+    if obj_patches > 1:
+        exterior = None
+        for grp in faces_t.chunk(obj_patches, 0):
+            ext = mesh_contains_points(hand_verts.detach(), obj_verts[:, grp].detach())
+            exterior = ext if exterior is None else (exterior & ext)
+    else:
+        triangles = obj_verts[:, faces_t]
+        exterior = mesh_contains_points(hand_verts.detach(), triangles.detach())
     penetr_mask = ~exterior
     closest = batch_index_select(obj_verts, 1, idx21)
     if contact_target == "all":

@@ -27,7 +27,7 @@ DEFAULTS = dict(  # HandNet.__init__ defaults, handnet.py:20-63
     contact_lambda=0, contact_thresh=25, contact_mode="dist_sq", collision_thresh=25, collision_mode="dist_sq",
     collision_lambda=0, resnet_version=50, mano_comps=6, mano_use_shape=False, mano_lambda_pose_reg=0,
     mano_use_pca=True, mano_center_idx=9, mano_lambda_joints3d=None, mano_lambda_verts=None,
-    mano_lambda_shape=None,
+    mano_lambda_shape=None, atlas_patches=1,
 )
 
 
@@ -82,6 +82,7 @@ def handnet_forward(named, cfg, sample, keys, packs, template_verts, template_fa
                 contact_thresh=c["contact_thresh"], contact_mode=c["contact_mode"],
                 collision_thresh=c["collision_thresh"], collision_mode=c["collision_mode"],
                 contact_target=c["contact_target"], contact_zones=c["contact_zones"],
+                obj_patches=int(c.get("atlas_patches", 1)),
             )
             if not no_loss:
                 if keys.verts3d in sample and keys.objpoints3d in sample:

@@ -41,9 +41,11 @@ def mano_lbs(pose, betas, blob_right, blob_left=None, side=None, ncomps=30, use_
     return verts, joints
 
 
-def mesh_contains_hits(points, verts, faces):
-    tri = verts.detach()[:, faces.long()]
-    exterior = ocontact.mesh_contains_points(points.detach(), tri)
+def mesh_contains_hits(points, verts, faces, patches=1):
+    exterior = None
+    for grp in faces.long().chunk(max(int(patches), 1), 0):
+        ext = ocontact.mesh_contains_points(points.detach(), verts.detach()[:, grp])
+        exterior = ext if exterior is None else (exterior & ext)
     return (~exterior).int()
 
 

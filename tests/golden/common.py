@@ -79,3 +79,13 @@ def pack_bits(mask):
 def unpack_bits(bits, shape):
     n = int(np.prod(shape))
     return np.unpackbits(bits)[:n].reshape(shape).astype(bool)
+
+
+def subsample(a, limit=8192):
+    """Every k-th element of the flattened array, k = the smallest odd stride that fits ``limit`` (how large gradients
+    are stored in ``resnet.npz``; the generator and the tests share this rule)."""
+    flat = np.asarray(a).reshape(-1)
+    k = 1
+    while flat.size // k > limit:
+        k += 2
+    return flat[::k].copy()

@@ -72,6 +72,38 @@ def test_contains_matches_oracle(B, P, subdiv, patches):
     assert ok.float().mean() > 0.98
     np.testing.assert_array_equal(got[ok].numpy(), want[ok].numpy())
     assert 0.02 < (~want).float().mean() < 0.98 or P == 1  # both classes present
+    if patches > 1:  # grouped mode: interior = inside ANY patch (OR of the per-patch parities)
+        inside_any = ops.mesh_contains_hits(origins.cuda(), verts.cuda(), T(faces).cuda(), patches=patches).cpu()
+        assert set(np.unique(inside_any.numpy()).tolist()) <= {0, 1}
+        want_any = torch.zeros_like(want)
+        for grp in T(faces.astype(np.int64)).chunk(patches, 0):
+            want_any |= ~ocontact.mesh_contains_points(origins, verts[:, grp])
+        np.testing.assert_array_equal((inside_any != 0)[ok].numpy(), want_any[ok].numpy())
+
+
+def test_grouped_inside_test_on_overlapping_patches():
+    """Two concentric closed spheres as one 2-patch mesh (what duplicated or overlapping AtlasNet patches look like): a point
+    inside both crosses an even number of triangles in total - the plain parity calls it exterior - but is interior in
+    grouped mode; between the shells both agree; far away both say exterior.  Also with a triangle split (large B x P)."""
+    from obman_train_amd import ops
+
+    v, f = icosphere(2)
+    verts = np.concatenate([v * 30.0, v * 60.0], 0)[None].astype(np.float32)
+    faces = np.concatenate([f, f + v.shape[0]], 0).astype(np.int32)
+    pts = np.array([[[1.0, 2.0, 3.0], [40.0, 5.0, -3.0], [500.0, 0.0, 0.0]]], dtype=np.float32)
+    for B in (1, 70):
+        vv, pp = T(np.repeat(verts, B, 0)).cuda(), T(np.repeat(pts, B, 0)).cuda()
+        plain = ops.mesh_contains_hits(pp, vv, T(faces).cuda()).cpu().numpy()
+        grouped = ops.mesh_contains_hits(pp, vv, T(faces).cuda(), patches=2).cpu().numpy()
+        assert (plain[:, 0] % 2 == 0).all() and (grouped[:, 0] == 1).all()   # inside both shells
+        assert (plain[:, 1] % 2 == 1).all() and (grouped[:, 1] == 1).all()   # between the shells
+        assert (plain[:, 2] == 0).all() and (grouped[:, 2] == 0).all()       # outside
+    # the loss sees it: penetration mask through compute_contact_loss(obj_patches=2)
+    from obman_train_amd.networks.branches.contactloss import compute_contact_loss
+
+    hand = T(np.repeat(pts, 2, 0)).cuda()
+    _, _, info, _ = compute_contact_loss(hand, None, T(np.repeat(verts, 2, 0)).cuda(), faces, obj_patches=2)
+    np.testing.assert_array_equal(info["repulsion_masks"].cpu().numpy(), np.array([[True, True, False]] * 2))
 
 
 def test_contains_full_size_properties():

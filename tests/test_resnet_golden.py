@@ -1,0 +1,82 @@
+"""the image encoder against the REFERENCE's own module.
+
+``tests/golden/resnet.npz`` was produced by importing ``mano_train/networks/bases/resnet.py`` (it imports as-is) with
+seeded weights (``tests/golden/make_golden_resnet.py``).  The CPU test pins the architecture of this package's
+``networks/bases/resnet.py`` (stock torch ops off-device) at fp32 round-off; the GPU test holds the product path
+(MIOpen convolutions in channels_last + the fused NHWC BatchNorm / ReLU / max-pool kernels of ``csrc/bnact.hip``) to the
+same vectors."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.common import load_seeded, subsample
+from tests.golden.make_golden_resnet import PROBES, SEED, STATS
+
+
+def _run(name, mode, g, device):
+    from obman_train_amd.networks.bases import resnet
+
+    net = load_seeded(getattr(resnet, name)(pretrained=False), SEED[name]).to(device)
+    net.train(mode == "train")
+    x = torch.from_numpy(g[name + "_x"]).to(device).requires_grad_()
+    cot = torch.from_numpy(g[name + "_cot"]).to(device)
+    feats, extra = net(x)
+    assert extra == {}
+    (feats * cot).sum().backward()
+    return net, x, feats
+
+
+def _check(name, mode, g, net, x, feats, tol_f, tol_g):
+    tag = "%s_%s_" % (name, mode)
+
+    def close(got, want, tol, what):
+        got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+        assert err <= tol, "%s %s: max error %.3g of the largest entry (tolerance %.1g)" % (tag, what, err, tol)
+        return err
+
+    errs = {"features": close(feats.detach().cpu().numpy(), g[tag + "features"], tol_f, "features"),
+            "gx": close(x.grad.cpu().numpy(), g[tag + "gx"], tol_g, "input gradient")}
+    params = dict(net.named_parameters())
+    for p in PROBES[name]:
+        errs[p] = close(subsample(params[p].grad.detach().cpu().numpy()), g[tag + "g:" + p], tol_g, "grad " + p)
+    assert params["fc.weight"].grad is None
+    sd = net.state_dict()
+    for s in STATS[name]:
+        close(sd[s + ".running_mean"].cpu().numpy(), g[tag + "rm:" + s], tol_f, "running_mean " + s)
+        close(sd[s + ".running_var"].cpu().numpy(), g[tag + "rv:" + s], tol_f, "running_var " + s)
+        assert int(sd[s + ".num_batches_tracked"]) == int(g[tag + "nbt:" + s])
+    return errs
+
+
+@pytest.mark.parametrize("name", ["resnet18", "resnet50"])
+def test_state_dict_layout_is_the_references(name, golden):
+    from obman_train_amd.networks.bases import resnet
+
+    g = golden("resnet")
+    sd = getattr(resnet, name)(pretrained=False).state_dict()
+    mine = ["%s %s" % (k, "x".join(str(d) for d in v.shape)) for k, v in sd.items()]
+    assert mine == [str(s) for s in g[name + "_layout"]]  # same keys, same shapes, same ORDER (optimizer state indices)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("name", ["resnet18", "resnet50"])
+def test_architecture_matches_reference_on_cpu(name, mode, golden):
+    g = golden("resnet")
+    torch.set_num_threads(4)
+    net, x, feats = _run(name, mode, g, "cpu")
+    _check(name, mode, g, net, x, feats, tol_f=2e-5, tol_g=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("name", ["resnet18", "resnet50"])
+def test_hip_encoder_matches_reference_golden(name, mode, golden):
+    """MIOpen convolutions (channels_last) + fused BN/ReLU/pool kernels vs the reference's CPU outputs.  Tolerances: 1e-4 of
+    the largest entry for features and running statistics (north_star), gradients 1e-3 (train-mode BatchNorm over 12..48
+    values per channel in the last stages amplifies the convolution round-off difference MIOpen-vs-oneDNN)."""
+    g = golden("resnet")
+    torch.backends.cudnn.benchmark = False
+    net, x, feats = _run(name, mode, g, "cuda")
+    errs = _check(name, mode, g, net, x, feats, tol_f=1e-4, tol_g=1e-3)
+    print(name, mode, {k: "%.2g" % v for k, v in errs.items()})
