@@ -9,13 +9,25 @@ kernel evaluates (exactly rounded differences, no cancellation).
 import torch
 
 
+LOWMEM_POINTS = 4096
+
+
 def batch_pairwise_dist(x, y):
-    """x [B,Nx,3], y [B,Ny,3] -> P [B,Nx,Ny] squared distances, expanded form (atlasutils.py:20-39)."""
-    gram_x = torch.bmm(x, x.transpose(2, 1))
-    gram_y = torch.bmm(y, y.transpose(2, 1))
+    """x [B,Nx,3], y [B,Ny,3] -> P [B,Nx,Ny] squared distances, expanded form (atlasutils.py:20-39).
+
+    The reference takes |x_i|^2 from the diagonal of the Nx x Nx Gram matrix ``bmm(x, x^T)`` (:24-33), which is 1 GB per
+    sample at the 16 050 points of BASELINE configs[2] and 16 GB at configs[4] (the reference formulation
+    cannot run those sizes).  Above LOWMEM_POINTS points the squared norms are summed directly - the same three products
+    per point, without the Gram matrix - so the oracle can check the full-size configurations; below it the reference's
+    formulation is restated as is."""
+    if max(x.shape[1], y.shape[1]) > LOWMEM_POINTS:
+        sq_x, sq_y = (x * x).sum(2), (y * y).sum(2)
+    else:
+        gram_x = torch.bmm(x, x.transpose(2, 1))
+        gram_y = torch.bmm(y, y.transpose(2, 1))
+        sq_x = torch.diagonal(gram_x, dim1=1, dim2=2)  # |x_i|^2  [B,Nx]
+        sq_y = torch.diagonal(gram_y, dim1=1, dim2=2)  # |y_j|^2  [B,Ny]
     cross = torch.bmm(x, y.transpose(2, 1))
-    sq_x = torch.diagonal(gram_x, dim1=1, dim2=2)  # |x_i|^2  [B,Nx]
-    sq_y = torch.diagonal(gram_y, dim1=1, dim2=2)  # |y_j|^2  [B,Ny]
     return sq_x.unsqueeze(2) + sq_y.unsqueeze(1) - 2 * cross
 
 

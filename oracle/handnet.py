@@ -37,17 +37,22 @@ def _sub(named, prefix):
 
 
 def handnet_forward(named, cfg, sample, keys, packs, template_verts, template_faces, zones=None,
-                    resnet_shell=None, training=True, bn_training=None, no_loss=False):
+                    resnet_shell=None, training=True, bn_training=None, no_loss=False, features=None):
     """``keys`` = namespace with images/verts3d/joints3d/objpoints3d/sides keys of ``sample``.
-    ``bn_training``: BN mode (defaults to ``training``; False = --freeze_batchnorm, epochpass3d.py:48-52)."""
+    ``bn_training``: BN mode (defaults to ``training``; False = --freeze_batchnorm, epochpass3d.py:48-52).
+    ``features`` (test hook): encoder output [B,C] used instead of running the ResNet, so everything downstream of the encoder
+    can be compared at tight tolerance, free of convolution-library round-off."""
     c = dict(DEFAULTS)
     c.update(cfg)
     bn_train = training if bn_training is None else bn_training
     results, losses = {}, {}
     total = None
     image = sample[keys.images]
-    resnet_shell.train(bn_train)
-    feats, _ = functional_call(resnet_shell, _sub(named, "base_net."), (image,))
+    if features is not None:
+        feats = features
+    else:
+        resnet_shell.train(bn_train)
+        feats, _ = functional_call(resnet_shell, _sub(named, "base_net."), (image,))
     if c["atlas_separate_encoder"]:
         atlas_feats, _ = functional_call(resnet_shell, _sub(named, "atlas_base_net."), (image,))
     mano_lambdas = bool(c["mano_lambda_verts"] or c["mano_lambda_joints3d"])

@@ -1,0 +1,212 @@
+"""Full-size parity (BASELINE.json configs[2] = 25 x 642 points + contact, configs[4] = 25 x 2562 points) through the C-ABI
+against the CPU oracle at small batch (B = 2; the oracle's N x M matrices stay in host memory).
+
+* decoder c1 = 515 at N = 16 050 and N = 64 050 (fp32: outputs 2e-4 of the output scale; gradients 1e-3 relative L2 on a
+  coherent cotangent - at 30 M pre-activations some sit within fp32 rounding of a ReLU edge for ANY evaluation order, the
+  fp32 and fp64 runs of the oracle itself differ by 1e-4 there) and the bf16 flavour at its documented tolerances;
+* compute_contact_loss forward + backward at 778 hand x 16 050 object vertices, 32 000 faces in 25 patches: losses 1e-4,
+  masks bit-exact (points whose ray grazes a triangle border within fp32 round-off excluded by an fp64 margin), hand-side
+  and object-side gradients (owner scan over 16 050 arg-mins) 1e-3 of the largest entry;
+* the whole configs[2] model (CONFIGS["c3"], fp32) forward + backward at B = 2 vs oracle.handnet_forward, with the real
+  ResNet18 (convolution-library tolerance) and with injected encoder features (everything downstream held to 1e-4)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import atlas as oatlas
+from oracle import contact as ocontact
+from obman_train_amd.contactzones import hand_template, load_contacts
+from obman_train_amd.icosphere import multi_patch
+from tests.golden.common import load_seeded, synth_hand_object
+from tests.test_decoder_gpu import _decoder, _oracle
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _rel_l2(g, w):
+    return ((g.detach().cpu().double() - w.double()).norm() / w.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("subdiv,flavour", [(3, "f32"), (3, "bf16"), (4, "f32")])
+def test_decoder_full_size(subdiv, flavour):
+    from obman_train_amd import ops
+
+    c1, B, patches = 515, 2, 25
+    grid = T(multi_patch(subdiv, patches)[0].astype(np.float32))
+    assert grid.shape[0] == (16050 if subdiv == 3 else 64050)
+    rng = np.random.RandomState(100)
+    feats = T(rng.normal(0, 1, size=(B, c1 - 3)).astype(np.float32))
+    cot = T((np.abs(rng.normal(0, 1, size=(B, grid.shape[0], 3))) + 0.5).astype(np.float32))
+    dec = _decoder(c1, 7).train()
+    want32, f_o, params = _oracle(dec, feats, grid, True)
+    (want32 * cot).sum().backward()
+    dec_g = _decoder(c1, 7).cuda().train()
+    dec_g.mfma_dtype = flavour
+    f_g = feats.cuda().requires_grad_()
+    got = ops.pointgen_decode(dec_g, f_g, grid.cuda())
+    (got * cot.cuda()).sum().backward()
+    if flavour == "f32":
+        scale = want32.abs().max().item()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want32.detach().numpy(), rtol=2e-4, atol=2e-4 * scale)
+        tol = 1e-3
+    else:
+        want_bf, _, _ = _oracle(dec, feats, grid, True, mfma_round=lambda t: t.bfloat16().float())
+        scale = want_bf.abs().max().item()
+        assert (got.detach().cpu() - want_bf.detach()).abs().max().item() <= 4e-3 * scale
+        tol = 8e-2
+    worst = {"features": _rel_l2(f_g.grad, f_o.grad)}
+    for name, prm in dec_g.named_parameters():
+        if name.startswith("conv") and name.endswith("bias") and name != "conv4.bias":
+            continue  # exactly-zero gradient before a train-mode BatchNorm
+        worst[name] = _rel_l2(prm.grad, params["decoder." + name].grad.reshape(prm.grad.shape))
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, (bad, worst)
+    for k in (1, 2, 3):
+        bn = getattr(dec_g, "bn%d" % k)
+        rtol = 1e-4 if flavour == "f32" else 2e-2
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), params["decoder.bn%d.running_var" % k].numpy(), rtol=rtol, atol=1e-5)
+
+
+def _graze_free(origins, verts, faces, patches):
+    """fp64: points whose ray does not graze any triangle border (same margins as tests/test_contact_gpu._margin_ok), evaluated
+    patch by patch so the [B,P,F] temporaries stay small."""
+    from tests.test_contact_gpu import _margin_ok
+
+    ok = None
+    for grp in np.array_split(faces, patches, 0):
+        m = _margin_ok(origins, verts, grp)
+        ok = m if ok is None else (ok & m)
+    return ok
+
+
+def _c3_scene(B, seed):
+    """Hand vertices (mm) around a 25-patch object (blobs of ~40 mm spread over ~+-150 mm): some vertices inside patches."""
+    from tests.test_contact_gpu import _blob
+
+    obj, faces = _blob(3, B, seed, radius=38.0, patches=25)
+    hand, _, _ = synth_hand_object(B, 600, seed + 1, hand_template()[0])
+    hand = hand * 1.2
+    return hand, obj, faces
+
+
+@pytest.mark.parametrize("cmode,kmode,zones,target", [("dist_tanh", "dist_tanh", "zones", "all"), ("dist_sq", "dist", "all", "obj")])
+def test_contact_loss_full_size(cmode, kmode, zones, target):
+    from obman_train_amd.networks.branches.contactloss import compute_contact_loss
+
+    B, patches = 2, 25
+    hand, obj, faces = _c3_scene(B, 12)  # graze-free under the fp64 margin (seed 11 has one grazing vertex)
+    assert obj.shape[1] == 16050 and faces.shape[0] == 32000
+    kw = dict(contact_thresh=10, contact_mode=cmode, collision_thresh=20, collision_mode=kmode, contact_target=target,
+              contact_zones=zones)
+    h_o, o_o = hand.clone().requires_grad_(), obj.clone().requires_grad_()
+    w_missed, w_pen, w_info, w_metrics = ocontact.compute_contact_loss(h_o, None, o_o, faces, zones=load_contacts()[1],
+                                                                       obj_patches=patches, **kw)
+    (w_missed + 2.0 * w_pen).sum().backward()
+    h_g, o_g = hand.cuda().requires_grad_(), obj.cuda().requires_grad_()
+    missed, pen, info, metrics = compute_contact_loss(h_g, None, o_g, faces, obj_patches=patches, **kw)
+    (missed + 2.0 * pen).sum().backward()
+
+    ok = _graze_free(hand, obj, faces, patches)
+    assert bool(ok.all()), "pick another seed: %d hand vertices graze a triangle border" % int((~ok).sum())
+    rep = info["repulsion_masks"].cpu()
+    np.testing.assert_array_equal(rep.numpy(), w_info["repulsion_masks"].numpy())
+    assert 0.01 < rep.float().mean() < 0.9  # both classes present
+    np.testing.assert_array_equal(info["attraction_masks"].cpu().numpy() != 0, w_info["attraction_masks"].numpy() != 0)
+    # squared minima: the oracle's expanded form carries ~eps*|x|^2 absolute error (coordinates up to ~250 mm)
+    np.testing.assert_allclose(info["min_dists"].cpu().numpy(), w_info["min_dists"].detach().numpy(), rtol=1e-4, atol=2e-2)
+    d_got = (info["contact_points"].cpu() - hand).norm(dim=2)
+    d_want = (w_info["contact_points"].detach() - hand).norm(dim=2)
+    np.testing.assert_allclose(d_got.numpy(), d_want.numpy(), rtol=1e-4, atol=1e-2)  # tie-tolerant: distance, not index
+    np.testing.assert_allclose(float(missed), float(w_missed), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(pen), float(w_pen), rtol=1e-4, atol=1e-6)
+    for k in ("max_penetr", "mean_penetr"):
+        np.testing.assert_allclose(float(metrics[k]), float(w_metrics[k]), rtol=1e-4, atol=1e-6)
+    for name, got, want in (("hand", h_g.grad, h_o.grad), ("obj", o_g.grad, o_o.grad)):
+        if want is None or float(want.abs().max()) == 0.0:
+            assert got is None or float(got.abs().max()) == 0.0, name
+            continue
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 1e-3 * want.abs().max().item(), (name, err, want.abs().max().item())
+        assert int((want.abs().sum(2) > 0).sum()) == int((got.cpu().abs().sum(2) > 0).sum()), name  # same support
+
+
+class _FixedFeatures(torch.nn.Module):
+    """Encoder stand-in returning a given feature tensor (a Parameter, so its gradient can be compared)."""
+
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = torch.nn.Parameter(feats.clone())
+        self.fc = torch.nn.Linear(1, 1)  # HandNet.unused_parameters() looks for the classifier head
+
+    def forward(self, image):
+        return self.feats, {}
+
+
+@pytest.mark.parametrize("inject", [True, False])
+def test_configs2_model_matches_oracle_at_full_size(inject):
+    """CONFIGS["c3"] (25 x 642 points, trans + scale heads, shape, contact + penetration) fp32, B = 2, 64 x 64 images."""
+    from oracle import handnet as ohandnet
+    from oracle import mano as omano
+    from obman_train_amd.mano_params import synthetic_mano
+    from obman_train_amd.networks.bases import resnet
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.queries import BaseQueries, TransQueries
+    from obman_train_amd.synthetic import CONFIGS
+
+    import warnings
+    warnings.simplefilter("ignore")
+    cfg = dict(CONFIGS["c3"])
+    torch.manual_seed(0)
+    model = HandNet(**cfg)
+    with torch.no_grad():
+        model.atlas_branch.decoder.conv4.weight.mul_(0.2)
+    model.train()
+    B = 2
+    gtv, gtj, gto = synth_hand_object(B, 600, 5, hand_template()[0])
+    images = torch.rand(B, 3, 64, 64) - 0.5
+    feats = torch.randn(B, 512) * 0.5 if inject else None
+    named = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, v in named.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_()
+    keys = SimpleNamespace(images=TransQueries.images, verts3d=TransQueries.verts3d, joints3d=TransQueries.joints3d,
+                           objpoints3d=TransQueries.objpoints3d, sides=BaseQueries.sides)
+    sample = {TransQueries.images: images, TransQueries.verts3d: gtv, TransQueries.joints3d: gtj,
+              TransQueries.objpoints3d: gto, BaseQueries.sides: ["left", "right"], "root": "wrist"}
+    packs = {s: omano.pack_to_torch(synthetic_mano(s)) for s in ("right", "left")}
+    f_o = feats.clone().requires_grad_() if inject else None
+    o_total, o_res, o_losses = ohandnet.handnet_forward(
+        named, cfg, dict(sample), keys, packs, model.atlas_branch.test_verts.clone(), model.atlas_branch.test_faces,
+        zones=load_contacts()[1], resnet_shell=resnet.resnet18(), training=True, features=f_o)
+    o_total.backward()
+    if inject:
+        model.base_net = _FixedFeatures(feats)
+    model.cuda()
+    total, res, losses = model.forward(sample)
+    total.backward()
+    tol, gtol = (1e-4, 1e-3) if inject else (1e-3, 2e-2)
+    np.testing.assert_allclose(float(total), float(o_total), rtol=tol)
+    for k, v in o_losses.items():
+        if v is None:
+            assert losses[k] is None
+        else:
+            np.testing.assert_allclose(float(losses[k]), float(v), rtol=2 * tol, atol=1e-5, err_msg=k)
+    assert res["objpoints3d"].shape == (B, 16050, 3)
+    for k, atol in (("verts", 0.02), ("objpoints3d", 0.02)):
+        np.testing.assert_allclose(res[k].detach().cpu().numpy(), o_res[k].detach().numpy(), rtol=tol, atol=atol if inject else 0.05)
+    np.testing.assert_array_equal(res["contact_info"]["repulsion_masks"].cpu().numpy(),
+                                  o_res["contact_info"]["repulsion_masks"].numpy())
+    names = ["mano_branch.pose_reg.weight", "atlas_branch.decoder.conv2.weight", "atlas_branch.decode_scale.2.weight"]
+    if not inject:
+        names.append("base_net.layer4.1.conv2.weight")
+    got_params = dict(model.named_parameters())
+    for name in names:
+        got, want = got_params[name].grad.cpu().numpy(), named[name].grad.numpy()
+        err = np.abs(got - want).max()
+        assert err <= gtol * np.abs(want).max(), (name, err, np.abs(want).max())
+    if inject:
+        err = (model.base_net.feats.grad.cpu() - f_o.grad).abs().max().item()
+        assert err <= gtol * f_o.grad.abs().max().item(), ("features", err)
