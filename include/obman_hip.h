@@ -66,7 +66,9 @@ int obman_chamfer_bwd(const float* preds, const float* gts, int B, int Np, int N
  * model_right / model_left: packed fp32 model blobs of obman_mano_model_floats() floats each (layout
  * in csrc/mano_lbs.hip, built by obman_train_amd/mano_model.py).  side [B] int32: 0 -> right model,
  * 1 -> left model (NULL = all right; replaces the boolean-mask split/re-assembly of
- * manobranch.py:133-207).  pose [B, 3+ncomps] (use_pca) or [B,48]; betas [B,10] or NULL (zeros).
+ * manobranch.py:133-207).  use_pca selects the pose input: 1 -> pose [B, 3+ncomps] (root axis-angle + PCA coefficients),
+ * 0 -> [B,48] axis-angle, 2 -> [B,16,3,3] rotation matrices used as given (the reference's mano_use_pca=False path,
+ * manobranch.py:52-54,126-128); betas [B,10] or NULL (zeros).
  * center_idx in [-1,20] (-1 = no centring); verts [B,778,3] mm, joints [B,21,3] mm; state
  * [B, OBMAN_MANO_STATE_FLOATS] is saved for the backward (NULL = inference only). */
 #define OBMAN_MANO_STATE_FLOATS 2768
@@ -76,7 +78,7 @@ int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const 
                        const float* betas, int B, int ncomps, int use_pca, int center_idx, int root_palm,
                        float* verts, float* joints, float* state, obman_stream_t stream);
 
-/* Backward: g_verts [B,778,3] / g_joints [B,21,3] (either NULL = zeros) -> g_pose [B,npose],
+/* Backward: g_verts [B,778,3] / g_joints [B,21,3] (either NULL = zeros) -> g_pose [B,npose] (npose = 3+ncomps | 48 | 144),
  * g_betas [B,10] (NULL = not wanted).  scratch: obman_mano_bwd_scratch_floats(B) floats (per-tile partial sums).
  * Deterministic (fixed reduction trees, no atomics). */
 int obman_mano_bwd_scratch_floats(int B);

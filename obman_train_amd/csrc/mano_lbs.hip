@@ -4,7 +4,9 @@
 // (a chain of ~60 small torch ops: launch-latency bound on a GPU) with ONE fused kernel per
 // direction: PCA -> axis-angle -> quaternion Rodrigues -> shape/pose blend shapes -> joint
 // regression -> 16-joint kinematic chain -> rest-pose removal -> skinning -> 21 joints -> centring
-// -> x1000.  The model (1.4 MB, shared by every sample) is one packed fp32 blob with
+// -> x1000.  Pose input modes (`use_pca` argument of the launchers): 1 = root axis-angle + ncomps PCA
+// coefficients, 0 = root + 45 axis-angle values, 2 = sixteen 3x3 rotation matrices used as given (manobranch.py:52-54,
+// 126-128: ManoLayer(use_pca=False) fed [b,16,3,3]).  The model (1.4 MB, shared by every sample) is one packed fp32 blob with
 // blend-shape bases stored k-major so that lane e reads element e of every basis: fully coalesced;
 // it stays L2 / Infinity-Cache resident.  Per-sample state (local/global rotations, joints, posed
 // rest shape: 2766 floats) is saved for the backward, which therefore never re-reads posedirs for
@@ -100,15 +102,23 @@ __device__ __forceinline__ void mano_pose_phase(const float* __restrict__ M, con
                                                 float* s_pm, float* s_J, float* s_GR, float* s_Gt, float* s_trel, float* s_tab) {
   // Small model tables go through LDS first (one coalesced pass): a serial loop of dependent L2 loads (30 PCA steps) costs
   // ~0.7 us per step otherwise.  s_tab: [ncomps*45 PCA rows | 48 pose coefficients]
-  const int npose = 3 + (use_pca ? ncomps : 45);
-  if (use_pca)
+  const int npose = use_pca == 2 ? 0 : 3 + (use_pca ? ncomps : 45);
+  if (use_pca == 1)
     for (int i = tid; i < ncomps * 45; i += nthreads) s_tab[i] = M[OFF_COMPS + i];
   for (int i = tid; i < npose; i += nthreads) s_tab[45 * 45 + i] = p[i];
   if (tid < 10) s_beta[tid] = betas_b ? betas_b[tid] : 0.f;
+  if (use_pca == 2) {  // rotation matrices given: no PCA, no Rodrigues
+    for (int i = tid; i < 144; i += nthreads) {
+      const float r = p[i];
+      s_R[i] = r;
+      if (i >= 9) { const int k = i % 9; s_pm[i - 9] = r - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f); }
+    }
+    if (tid < 48) s_aa[tid] = 0.f;
+  }
   __syncthreads();
   const float* sp = s_tab + 45 * 45;
-  if (tid < 3) s_aa[tid] = sp[tid];
-  if (tid >= 64 && tid < 109) {
+  if (use_pca != 2 && tid < 3) s_aa[tid] = sp[tid];
+  if (use_pca != 2 && tid >= 64 && tid < 109) {
     const int m = tid - 64;
     float h = M[OFF_MEAN + m];
     if (use_pca) {
@@ -126,7 +136,7 @@ __device__ __forceinline__ void mano_pose_phase(const float* __restrict__ M, con
     s_aa[3 + m] = h;
   }
   __syncthreads();
-  if (tid < NJ) {
+  if (use_pca != 2 && tid < NJ) {
     float R[9];
     rodrigues(&s_aa[tid * 3], R);
 #pragma unroll
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(64) void mano_bwd_chain_kernel(const float* __restr
   __shared__ float s_root[5][16];
   __shared__ float s_gpm[NPM + 10], s_gaa[48];
   __shared__ float s_comps[45 * 45], s_js[480];  // small model tables: staged once, coalesced (serial L2 loads are ~0.7 us each)
-  if (use_pca)
+  if (use_pca == 1)
     for (int i = tid; i < ncomps * 45; i += 64) s_comps[i] = M[OFF_COMPS + i];
   if (g_betas)
     for (int i = tid; i < 480; i += 64) s_js[i] = M[OFF_JS + i];
@@ -524,6 +534,11 @@ __global__ __launch_bounds__(64) void mano_bwd_chain_kernel(const float* __restr
     for (int e = 0; e < 48; ++e) g = __fmaf_rn(s_js[tid * 48 + e], s_gJ[e], g);
     g_betas[(size_t)b * 10 + tid] = g;
   }
+  float* gp = g_pose + (size_t)b * npose;
+  if (use_pca == 2) {  // rotation-matrix input: d/dR_i = chain gradient + pose-blend-shape gradient (R_i - I enters pose_map)
+    for (int k = tid; k < 144; k += 64) gp[k] = s_gR[k] + (k >= 9 ? s_gpm[k - 9] : 0.f);
+    return;
+  }
   // phase 7: Rodrigues backward
   if (tid >= 32 && tid < 32 + NJ) {
     const int i = tid - 32;
@@ -534,7 +549,6 @@ __global__ __launch_bounds__(64) void mano_bwd_chain_kernel(const float* __restr
     s_gaa[i * 3] = ga[0]; s_gaa[i * 3 + 1] = ga[1]; s_gaa[i * 3 + 2] = ga[2];
   }
   __syncthreads();
-  float* gp = g_pose + (size_t)b * npose;
   if (tid < 3) gp[tid] = s_gaa[tid];
   if (use_pca) {
     for (int k = tid; k < ncomps; k += 64) {
@@ -558,11 +572,11 @@ int obman_mano_lbs_fwd(const float* model_right, const float* model_left, const 
                        const float* betas, int B, int ncomps, int use_pca, int center_idx, int root_palm,
                        float* verts, float* joints, float* state, obman_stream_t stream) {
   if (B < 0 || !model_right || !pose || !verts || !joints) return -1;
-  if (use_pca ? (ncomps < 0 || ncomps > 45) : 0) return -2;
+  if (use_pca < 0 || use_pca > 2 || (use_pca == 1 && (ncomps < 0 || ncomps > 45))) return -2;
   if (center_idx < -1 || center_idx > 20) return -3;
   if (side && !model_left) return -4;
   if (B == 0) return 0;
-  const int npose = 3 + (use_pca ? ncomps : 45);
+  const int npose = use_pca == 2 ? 144 : 3 + (use_pca ? ncomps : 45);
   ObmanProfScope prof(OBMAN_K_MANO_FWD, (hipStream_t)stream);
   mano_fwd_kernel<<<dim3(NTILE, B), FT, 0, (hipStream_t)stream>>>(model_right, model_left, side, pose, betas, npose, ncomps, use_pca,
                                                        center_idx, root_palm, verts, joints, state);
@@ -574,10 +588,10 @@ int obman_mano_lbs_bwd(const float* model_right, const float* model_left, const 
                        const float* g_verts, const float* g_joints, int B, int ncomps, int use_pca, int center_idx,
                        int root_palm, float* g_pose, float* g_betas, float* scratch, obman_stream_t stream) {
   if (B < 0 || !model_right || !state || !g_pose || !scratch) return -1;
-  if (use_pca ? (ncomps < 0 || ncomps > 45) : 0) return -2;
+  if (use_pca < 0 || use_pca > 2 || (use_pca == 1 && (ncomps < 0 || ncomps > 45))) return -2;
   if (side && !model_left) return -4;
   if (B == 0) return 0;
-  const int npose = 3 + (use_pca ? ncomps : 45);
+  const int npose = use_pca == 2 ? 144 : 3 + (use_pca ? ncomps : 45);
   hipStream_t st = (hipStream_t)stream;
   ObmanProfScope prof(OBMAN_K_MANO_BWD, st);
   mano_bwd_tile_kernel<<<dim3(NTILE, B), FT, 0, st>>>(model_right, model_left, side, state, g_verts, g_joints, center_idx, root_palm,

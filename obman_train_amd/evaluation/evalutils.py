@@ -40,3 +40,28 @@ class AverageMeters:
         for name, val in values.items():
             self.add_loss_value(name, val, n=n)
         return values
+
+    def add_loss_window(self, window):
+        """A list of per-step loss dicts (device tensors) -> every step enters the running means exactly as if it had been
+        added on its own (a key counts only the steps where it was not None), with ONE device->host transfer for the whole
+        window.  Returns the last step's values (what the reference prints)."""
+        import torch
+
+        slots, parts = [], []
+        for step, losses in enumerate(window):
+            for name, val in losses.items():
+                if val is None:
+                    continue
+                if torch.is_tensor(val):
+                    slots.append((step, name, len(parts)))
+                    parts.append(val.detach().reshape(-1)[0].float())
+                else:
+                    slots.append((step, name, float(val)))
+        flat = torch.stack(parts).cpu().tolist() if parts else []
+        last = {}
+        for step, name, ref in slots:
+            val = flat[ref] if isinstance(ref, int) else ref
+            self.add_loss_value(name, val)
+            if step == len(window) - 1:
+                last[name] = val
+        return last

@@ -127,9 +127,22 @@ def load_mano_pickle(path, side="right", flat_hand_mean=True):
     return pack
 
 
+SYNTHETIC_ROOT = "synthetic"
+
+
 def get_mano_pack(mano_root="misc/mano", side="right"):
-    """Real pickle under ``mano_root`` if present (reference layout ``manobranch.py:92-105``), else synthetic."""
+    """The hand model the reference's ``ManoLayer(mano_root=...)`` would load (``manobranch.py:92-105``):
+    ``<mano_root>/MANO_{RIGHT,LEFT}.pkl``.  A missing file raises ``FileNotFoundError`` exactly as manopth's ``open`` does -
+    a wrong ``mano_root`` (or the default resolved from another working directory) must not silently train on a fake hand.
+    The seeded synthetic stand-in is used only when asked for: ``mano_root="synthetic"`` (bench, smoke, CONFIGS), or the
+    environment variable ``OBMAN_MANO_SYNTHETIC=1`` as the fallback for a missing file (set by the test suite)."""
+    if mano_root == SYNTHETIC_ROOT:
+        return synthetic_mano(side)
     fname = os.path.join(mano_root or "", "MANO_%s.pkl" % side.upper())
     if os.path.exists(fname):
         return load_mano_pickle(fname, side=side)
-    return synthetic_mano(side)
+    if os.environ.get("OBMAN_MANO_SYNTHETIC") == "1":
+        return synthetic_mano(side)
+    raise FileNotFoundError(
+        "%s not found: download the MANO models (README of hassony2/manopth) into mano_root, or pass "
+        "mano_root=\"synthetic\" for the seeded stand-in model (NOT a real hand)" % fname)

@@ -2,9 +2,14 @@
 ``checkpoint.pth.tar`` = ``{"epoch", "network", "state_dict", "best_score", "optimizer"}``, snapshots every
 ``snapshot`` epochs, ``model_best.pth.tar``; ``load_checkpoint`` accepts state dicts with or without the
 ``module.`` prefix of ``nn.DataParallel`` (adapting to what the model in hand expects), the ``load_atlas`` remap
-(``base_net`` -> ``atlas_base_net``), warns about - instead of failing on - keys such as the reference's
-``mano_branch.mano_layer_*`` buffers that this implementation does not hold, and ``load_checkpoints`` averages several
-checkpoints."""
+(``base_net`` -> ``atlas_base_net``), and ``load_checkpoints`` averages several checkpoints.
+
+``strict`` is honoured exactly as ``nn.Module.load_state_dict`` defines it (missing or unexpected keys raise when it is
+True, the reference's behaviour), with one exception: the ``mano_branch.mano_layer_{right,left}.*`` buffers of manopth
+that reference checkpoints carry are dropped before loading - the MANO model lives in a device blob here, not in module
+buffers.  Compatibility is therefore one-directional under ``strict=True``: reference checkpoints load here; checkpoints
+written here lack those buffers, so the reference loads them only with ``strict=False`` (what ``traineval.py:139-141``
+passes anyway)."""
 import os
 import shutil
 import traceback
@@ -33,7 +38,7 @@ def _load_filtered(model, state_dict, strict):
     if manopth:
         warnings.warn("Ignoring {} manopth layer buffers stored in the checkpoint".format(len(manopth)))
         state_dict = {k: v for k, v in state_dict.items() if k not in manopth}
-    model.load_state_dict(state_dict, strict=strict and not missing)
+    model.load_state_dict(state_dict, strict=strict)
 
 
 def load_checkpoints(model, resume_paths, strict=True):

@@ -3,8 +3,9 @@ what drives the model - mode switching incl. ``freeze_batchnorm`` (:48-52), forw
 ``step`` (:80-91), per-loss running averages (:111-121), joint errors fed to the PCK evaluator (:141-151) and the
 ``(avg_meters, pck_info)`` return with ``pck_info = {auc, thres, pck_curve, epe_mean, epe_median, evaluator}`` (:168-196) -
 without the reference's display / image / pickle side effects (matplotlib, MANO pickles, ``progress``).
-Differences by design: losses are read back once per step in a single transfer (or every ``log_freq`` steps), and an
-optional ``GradientBuckets`` averages gradients across ranks before the optimizer step."""
+Differences by design: losses are read back once per step in a single transfer (or, with ``log_freq`` > 1, the whole
+window of steps in one transfer - every step still enters the running means, as in the reference), and an optional
+``GradientBuckets`` averages gradients across ranks before the optimizer step."""
 import time
 
 import os
@@ -28,7 +29,7 @@ def epoch_pass(loader, model, epoch, optimizer=None, debug=True, freeze_batchnor
         model.eval()
     net = model.module if hasattr(model, "module") else model
     end = time.time()
-    pending = None
+    window = []  # loss dicts of the steps since the last read-back (device tensors)
     idxs = list(range(21)) if idxs is None else idxs
     joint_errs, joint_vis = [], []  # device tensors; copied to the host once, after the loop
     for batch_idx, sample in enumerate(loader):
@@ -54,16 +55,16 @@ def epoch_pass(loader, model, epoch, optimizer=None, debug=True, freeze_batchnor
             joint_errs.append((pred - gt).pow(2).sum(2).sqrt())
             vis = sample.get("vis")
             joint_vis.append(None if vis is None else torch.as_tensor(vis)[:, idxs].bool())
-        pending = model_losses
+        window.append({k: (v.detach() if torch.is_tensor(v) else v) for k, v in model_losses.items()})
         if (batch_idx + 1) % log_freq == 0:
-            values = avg_meters.add_loss_dict(pending)
-            pending = None
+            values = avg_meters.add_loss_window(window)
+            window = []
             if verbose:
                 print("epoch {} batch {} loss {:.4f}".format(epoch, batch_idx + 1, values.get("total_loss", float("nan"))))
         time_meters.add_loss_value("batch_time", time.time() - end)
         end = time.time()
-    if pending is not None:
-        avg_meters.add_loss_dict(pending)
+    if window:
+        avg_meters.add_loss_window(window)
     avg_meters.time_meters = time_meters
     pck_info = {}
     if joint_errs:

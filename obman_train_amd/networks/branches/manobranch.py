@@ -23,9 +23,6 @@ class ManoBranch(nn.Module):
         super().__init__()
         if use_trans:
             raise NotImplementedError("use_trans: HandNet always builds ManoBranch(use_trans=False) (handnet.py:134)")
-        if not use_pca:
-            raise NotImplementedError("rotation-matrix pose regression (mano_use_pca=False) needs the SVD projection "
-                                      "of manopth's rot6d path; not on any BASELINE config")
         self.adapt_skeleton, self.use_trans, self.use_shape, self.use_pca = adapt_skeleton, use_trans, use_shape, use_pca
         self.ncomps, self.center_idx = ncomps, center_idx
         layers = []
@@ -34,7 +31,15 @@ class ManoBranch(nn.Module):
                 layers.append(nn.Dropout(p=dropout))
             layers += [nn.Linear(cin, cout), nn.ReLU()]
         self.base_layer = nn.Sequential(*layers)
-        self.pose_reg = nn.Linear(base_neurons[-1], ncomps + 3)
+        # PCA coefficients + 3 global axis-angle values, or 15 joint + 1 global rotation matrices (manobranch.py:49-54)
+        self.pose_reg = nn.Linear(base_neurons[-1], ncomps + 3 if use_pca else 16 * 9)
+        if not use_pca:
+            # start at the identity pose: zero bias, only the diagonal entries of every 3x3 keep |weights| (:71-81)
+            with torch.no_grad():
+                self.pose_reg.bias.fill_(0)
+                diag = torch.eye(3).view(9).repeat(16).unsqueeze(1)
+                self.pose_reg.weight.copy_(torch.abs(diag * self.pose_reg.weight))
+        self.robust_rot = False  # manopth's optional SVD projection of rotation-matrix poses (its default: off)
         if use_shape:
             self.shape_reg = nn.Sequential(nn.Linear(base_neurons[-1], 10))
         self._models = {s: ManoModelBlob(get_mano_pack(mano_root, s)) for s in ("right", "left")}
@@ -65,8 +70,13 @@ class ManoBranch(nn.Module):
         shape = self.shape_reg(base) if self.use_shape else None
         B, dev = inp.shape[0], inp.device
         side = self._side_tensor(list(sides), B, dev)
+        mano_pose = pose
+        if not self.use_pca:  # reshape to rotation matrices (manobranch.py:126-128)
+            mano_pose = pose.reshape(B, 16, 3, 3)
+            if self.robust_rot:
+                mano_pose = ops.project_rotations(mano_pose)
         verts, joints = ops.mano_lbs(
-            pose, shape, self._models["right"].on(dev), self._models["left"].on(dev) if side is not None else None,
+            mano_pose, shape, self._models["right"].on(dev), self._models["left"].on(dev) if side is not None else None,
             side, ncomps=self.ncomps, use_pca=self.use_pca, center_idx=self.center_idx, root_palm=root_palm)
         if self.adapt_skeleton:  # per-side 21x21 joint re-mixing (manobranch.py:183-192)
             jt = joints.permute(0, 2, 1)

@@ -133,12 +133,18 @@ def chamfer(preds, gts):
 
 class _ManoLBS(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pose, betas, blob_right, blob_left, side, ncomps, use_pca, center_idx, root_palm):
+    def forward(ctx, pose, betas, blob_right, blob_left, side, ncomps, pose_mode, center_idx, root_palm):
         pose = _dev(pose, "pose")
         B = pose.shape[0]
-        npose = 3 + (ncomps if use_pca else 45)
-        if pose.dim() != 2 or pose.shape[1] != npose:
-            raise ValueError("pose must be [B,%d], got %s" % (npose, tuple(pose.shape)))
+        in_shape = tuple(pose.shape)
+        if pose_mode == 2:
+            if in_shape[1:] not in ((16, 3, 3), (144,)):
+                raise ValueError("rotation-matrix pose must be [B,16,3,3], got %s" % (in_shape,))
+            npose = 144
+        else:
+            npose = 3 + (ncomps if pose_mode == 1 else 45)
+            if pose.dim() != 2 or pose.shape[1] != npose:
+                raise ValueError("pose must be [B,%d], got %s" % (npose, in_shape))
         if betas is not None:
             betas = _dev(betas, "betas")
             if tuple(betas.shape) != (B, 10):
@@ -153,16 +159,16 @@ class _ManoLBS(torch.autograd.Function):
         cidx = -1 if center_idx is None else int(center_idx)
         _lib.check(_lib.lib().obman_mano_lbs_fwd(
             blob_right.data_ptr(), _ptr(blob_left), _ptr(side), pose.data_ptr(), _ptr(betas), B, int(ncomps),
-            int(bool(use_pca)), cidx, int(bool(root_palm)), verts.data_ptr(), joints.data_ptr(), _ptr(state),
+            int(pose_mode), cidx, int(bool(root_palm)), verts.data_ptr(), joints.data_ptr(), _ptr(state),
             _stream()), "obman_mano_lbs_fwd")
         ctx.save_for_backward(state, blob_right, blob_left, side)
-        ctx.cfg = (B, int(ncomps), int(bool(use_pca)), cidx, int(bool(root_palm)), npose, betas is not None)
+        ctx.cfg = (B, int(ncomps), int(pose_mode), cidx, int(bool(root_palm)), npose, betas is not None, in_shape)
         return verts, joints
 
     @staticmethod
     def backward(ctx, g_verts, g_joints):
         state, blob_right, blob_left, side = ctx.saved_tensors
-        B, ncomps, use_pca, cidx, root_palm, npose, has_betas = ctx.cfg
+        B, ncomps, pose_mode, cidx, root_palm, npose, has_betas, in_shape = ctx.cfg
         g_verts = g_verts.contiguous() if g_verts is not None else None
         g_joints = g_joints.contiguous() if g_joints is not None else None
         o = dict(device=state.device, dtype=torch.float32)
@@ -171,16 +177,31 @@ class _ManoLBS(torch.autograd.Function):
         scratch = torch.empty(_lib.lib().obman_mano_bwd_scratch_floats(B), **o)
         _lib.check(_lib.lib().obman_mano_lbs_bwd(
             blob_right.data_ptr(), _ptr(blob_left), _ptr(side), state.data_ptr(), _ptr(g_verts), _ptr(g_joints), B,
-            ncomps, use_pca, cidx, root_palm, g_pose.data_ptr(), _ptr(g_betas), scratch.data_ptr(), _stream()),
+            ncomps, pose_mode, cidx, root_palm, g_pose.data_ptr(), _ptr(g_betas), scratch.data_ptr(), _stream()),
             "obman_mano_lbs_bwd")
-        return g_pose, g_betas, None, None, None, None, None, None, None
+        return g_pose.view(in_shape), g_betas, None, None, None, None, None, None, None
 
 
 def mano_lbs(pose, betas, blob_right, blob_left=None, side=None, ncomps=30, use_pca=True, center_idx=0,
              root_palm=False):
-    """ManoLayer.forward replacement: pose [B,3+ncomps], betas [B,10]|None -> (verts [B,778,3] mm,
-    joints [B,21,3] mm).  ``side`` int32 [B] picks right(0)/left(1) model blob per sample."""
-    return _ManoLBS.apply(pose, betas, blob_right, blob_left, side, ncomps, use_pca, center_idx, root_palm)
+    """ManoLayer.forward replacement -> (verts [B,778,3] mm, joints [B,21,3] mm).
+
+    pose [B,3+ncomps] with ``use_pca`` (root axis-angle + PCA coefficients); without it either [B,48] axis-angle or - the
+    reference's ``mano_use_pca=False`` path (manobranch.py:126-128) - [B,16,3,3] rotation matrices, used as given.
+    betas [B,10]|None.  ``side`` int32 [B] picks right(0)/left(1) model blob per sample."""
+    pose_mode = 1 if use_pca else (2 if pose.dim() == 4 else 0)
+    return _ManoLBS.apply(pose, betas, blob_right, blob_left, side, ncomps, pose_mode, center_idx, root_palm)
+
+
+def project_rotations(mats):
+    """[...,3,3] -> closest rotation matrices (orthogonal Procrustes via SVD, det = +1): manopth's optional ``robust_rot``
+    pre-processing of rotation-matrix poses.  A 3x3 SVD per joint on the device (rocSOLVER through torch.linalg), autograd
+    supplies the backward; the skinning itself stays in ``csrc/mano_lbs.hip``."""
+    u, _, vh = torch.linalg.svd(mats)
+    det = torch.det(u @ vh)
+    fix = torch.ones_like(mats[..., 0])
+    fix[..., 2] = det
+    return (u * fix.unsqueeze(-2)) @ vh
 
 
 def mesh_contains_hits(points, verts, faces, patches=1):
@@ -256,29 +277,35 @@ def contact_tail(hand, obj, idx21, mins21, hits, zone_ids, zone_off, n_zones, zo
                               contact_thresh, collision_mode, collision_thresh, target)
 
 
+def _pointgen_params(feat, grid, tensors, running, cfg):
+    """obman_pointgen_params over tensors the caller keeps alive (raw pointers: valid only while those tensors live)."""
+    training, eps, momentum, out_factor, mfma_bf16 = cfg
+    p = _lib.PointGenParams()
+    p.B, p.N, p.C1, p.training = feat.shape[0], grid.shape[-2], tensors[0].shape[0], int(training)
+    p.eps, p.momentum, p.out_factor = float(eps), float(momentum), float(out_factor)
+    p.mfma_bf16 = int(bool(mfma_bf16))
+    p.grid, p.feat = grid.data_ptr(), feat.data_ptr()
+    for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4"), tensors[:8]):
+        setattr(p, name, t.data_ptr())
+    for k in range(3):
+        p.bn_w[k], p.bn_b[k] = tensors[8 + 2 * k].data_ptr(), tensors[9 + 2 * k].data_ptr()
+        rm, rv = running[k] if running is not None else (None, None)
+        p.bn_rm[k] = rm.data_ptr() if rm is not None else None
+        p.bn_rv[k] = rv.data_ptr() if rv is not None else None
+    return p
+
+
 class _PointGen(torch.autograd.Function):
     """PointGenCon over (template grid x per-sample feature) without the [B,C,N] concat (csrc/decoder.hip)."""
 
     @staticmethod
     def forward(ctx, feat, grid, w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3, running, cfg):
-        training, eps, momentum, out_factor, mfma_bf16 = cfg
         feat, grid = _dev(feat, "features"), _dev(grid, "grid")
         tensors = [_dev(t, "decoder parameter") for t in (w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3)]
         B, N, C1 = feat.shape[0], grid.shape[0], w1.shape[0]
         if feat.shape[1] != C1 - 3 or grid.shape[1] != 3:
             raise ValueError("features must be [B,%d] and grid [N,3]" % (C1 - 3))
-        p = _lib.PointGenParams()
-        p.B, p.N, p.C1, p.training = B, N, C1, int(training)
-        p.eps, p.momentum, p.out_factor = float(eps), float(momentum), float(out_factor)
-        p.mfma_bf16 = int(bool(mfma_bf16))
-        p.grid, p.feat = grid.data_ptr(), feat.data_ptr()
-        for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4"), tensors[:8]):
-            setattr(p, name, t.data_ptr())
-        for k in range(3):
-            p.bn_w[k], p.bn_b[k] = tensors[8 + 2 * k].data_ptr(), tensors[9 + 2 * k].data_ptr()
-            rm, rv = running[k]
-            p.bn_rm[k] = rm.data_ptr() if rm is not None else None
-            p.bn_rv[k] = rv.data_ptr() if rv is not None else None
+        p = _pointgen_params(feat, grid, tensors, running, cfg)
         lib = _lib.lib()
         n_ws = lib.obman_pointgen_ws_floats(_ct.addressof(p), 0)
         if n_ws <= 0:
@@ -286,16 +313,19 @@ class _PointGen(torch.autograd.Function):
         ws = torch.empty(n_ws, dtype=torch.float32, device=feat.device)
         out = torch.empty((B, N, 3), dtype=torch.float32, device=feat.device)
         _lib.check(lib.obman_pointgen_fwd(_ct.addressof(p), out.data_ptr(), ws.data_ptr(), _stream()), "obman_pointgen_fwd")
+        # Everything the backward dereferences goes through save_for_backward: the tensors stay alive AND autograd's version
+        # check refuses a backward after an in-place change (optimizer step, load_state_dict) of a weight between the two
+        # calls.  No raw pointer outlives this call; the backward rebuilds its parameter block from the saved tensors and
+        # never touches the BatchNorm running buffers (a .to() / re-allocation of those in between is harmless).
         ctx.save_for_backward(feat, grid, ws, *tensors)
-        ctx.params = p  # holds raw pointers of tensors kept alive by save_for_backward / the module buffers
-        ctx.running = running
+        ctx.cfg = cfg
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         feat, grid, ws = ctx.saved_tensors[:3]
         tensors = ctx.saved_tensors[3:]
-        p = ctx.params
+        p = _pointgen_params(feat, grid, tensors, None, ctx.cfg)
         lib = _lib.lib()
         g_out = g_out.contiguous()
         ws2 = torch.empty(lib.obman_pointgen_ws_floats(_ct.addressof(p), 1), dtype=torch.float32, device=feat.device)

@@ -12,6 +12,7 @@ CONFIGS = {
     # BASELINE.json configs[0]/[1]: flags --atlas_mesh --mano_use_pca --atlas_lambda 0.167 + CLI defaults
     "c2": dict(
         resnet_version=18, atlas_mesh=True, mano_use_pca=True, mano_comps=30, mano_neurons=[1024, 256],
+        mano_root="synthetic",  # no MANO files here (licence-gated): the seeded stand-in model, asked for explicitly
         mano_center_idx=0, atlas_lambda=0.167, atlas_final_lambda=0.167, atlas_trans_weight=0.167,
         atlas_scale_weight=0.167, mano_lambda_verts=0.167, mano_lambda_joints3d=0.167, mano_lambda_pose_reg=0.167,
         contact_thresh=10, collision_thresh=20, contact_mode="dist_tanh", collision_mode="dist_tanh",

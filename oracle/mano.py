@@ -57,15 +57,18 @@ def pack_to_torch(pack, dtype=torch.float32):
 
 def mano_lbs(pk, pose, betas=None, ncomps=30, center_idx=0, root_palm=False, use_pca=True):
     """pose [b,3+ncomps] (axis-angle root + PCA coeffs) , betas [b,10]|None ->
-    verts [b,778,3] mm, joints [b,21,3] mm."""
+    verts [b,778,3] mm, joints [b,21,3] mm.  A 4-D ``pose`` [b,16,3,3] is taken as rotation matrices."""
     b = pose.shape[0]
     dtype = pose.dtype
-    if use_pca:
-        hand = pk["hands_mean"] + pose[:, 3:3 + ncomps] @ pk["hands_components"][:ncomps]
+    if pose.dim() == 4:  # ManoLayer(use_pca=False) fed rotation matrices (manobranch.py:126-128): used as given
+        R = pose
     else:
-        hand = pk["hands_mean"] + pose[:, 3:48]
-    full_pose = torch.cat([pose[:, :3], hand], 1)  # [b,48]
-    R = axisang_to_rotmat(full_pose.reshape(b * 16, 3)).view(b, 16, 3, 3)
+        if use_pca:
+            hand = pk["hands_mean"] + pose[:, 3:3 + ncomps] @ pk["hands_components"][:ncomps]
+        else:
+            hand = pk["hands_mean"] + pose[:, 3:48]
+        full_pose = torch.cat([pose[:, :3], hand], 1)  # [b,48]
+        R = axisang_to_rotmat(full_pose.reshape(b * 16, 3)).view(b, 16, 3, 3)
     eye = torch.eye(3, dtype=dtype)
     pose_map = (R[:, 1:] - eye).reshape(b, 135)
     if betas is None:
@@ -115,6 +118,7 @@ def mano_branch(params, features, sides, packs, ncomps=30, center_idx=0, use_sha
         h = F.relu(F.linear(h, params["base_layer.%d.weight" % k], params["base_layer.%d.bias" % k]))
         k += 2
     pose = F.linear(h, params["pose_reg.weight"], params["pose_reg.bias"])
+    mano_pose = pose if use_pca else pose.reshape(pose.shape[0], 16, 3, 3)  # manobranch.py:126-130
     shape = F.linear(h, params["shape_reg.0.weight"], params["shape_reg.0.bias"]) if use_shape else None
     B = features.shape[0]
     is_right = torch.tensor([s == "right" for s in sides][:B], dtype=torch.bool)
@@ -123,7 +127,7 @@ def mano_branch(params, features, sides, packs, ncomps=30, center_idx=0, use_sha
     for side, mask in (("right", is_right), ("left", ~is_right)):
         if int(mask.sum()) == 0:
             continue
-        v, j = mano_lbs(packs[side], pose[mask], shape[mask] if shape is not None else None,
+        v, j = mano_lbs(packs[side], mano_pose[mask], shape[mask] if shape is not None else None,
                         ncomps=ncomps, center_idx=center_idx, root_palm=root_palm, use_pca=use_pca)
         verts[mask] = v
         joints[mask] = j

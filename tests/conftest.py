@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+# no MANO files in any test environment: HandNet(mano_root="misc/mano") falls back to the seeded synthetic model here only
+os.environ.setdefault("OBMAN_MANO_SYNTHETIC", "1")
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

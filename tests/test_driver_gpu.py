@@ -1,0 +1,90 @@
+"""GPU: the callers either side of the hot path as the reference drives them.
+
+* ``traineval.py:130`` wraps the model in ``nn.DataParallel`` and ``epochpass3d.py:80-82`` calls ``model.forward(sample)`` on the
+  WRAPPER with a host-resident sample (scatter moves it).  With one visible GPU - the case this box can run - the wrapper
+  must give exactly what the bare module gives, and ``model.module.*`` attribute access (``traineval.py:404``) must work.
+* SURVEY §8f row 4 on the device: ``epoch_pass(save_results=True)`` dumps device ``results`` in the reference's pickle layout
+  (``savemano.py:57-82``) and feeds device joints to the PCK evaluator (``zimeval.py:21-129``)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_and_sample(batch=3, seed=2):
+    import warnings
+
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.synthetic import CONFIGS, make_batch
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    model = HandNet(**CONFIGS["c3p1"]).cuda().eval()  # eval: BatchNorm on running statistics, repeatable across calls
+    sample = make_batch(batch, "cpu", seed=seed, image_size=64)  # host-resident, as default_collate delivers it
+    return model, sample
+
+
+def test_single_gpu_dataparallel_wrapper_call_shape():
+    model, sample = _model_and_sample()
+    with torch.no_grad():
+        want_total, want_res, want_losses = model.forward(dict(sample))
+    wrapped = torch.nn.DataParallel(model)  # traineval.py:130
+    with torch.no_grad():
+        total, res, losses = wrapped.forward(dict(sample))  # epochpass3d.py:80-82
+    assert total.is_cuda and tuple(total.shape) == (1,)
+    assert float(total) == float(want_total)
+    assert set(res) == set(want_res) and set(losses) == set(want_losses)
+    assert torch.equal(res["verts"], want_res["verts"]) and torch.equal(res["objpoints3d"], want_res["objpoints3d"])
+    assert isinstance(res["objfaces"], np.ndarray)
+    wrapped.module.decay_regul(gamma=0.5)  # traineval.py:403-404
+    assert wrapped.module.mano_branch.faces.shape == (1538, 3)
+    # and a training step through the wrapper
+    from obman_train_amd.trainer import make_optimizer
+
+    wrapped.train()
+    opt = make_optimizer(wrapped.module, "adam", lr=1e-4)
+    total, _, _ = wrapped.forward(dict(sample))
+    opt.zero_grad()
+    total.backward()
+    opt.step()
+    assert torch.isfinite(total).all() and wrapped.module.base_net.conv1.weight.grad is not None
+
+
+def test_result_dumps_and_pck_from_device_results(tmp_path):
+    from obman_train_amd.netscripts import savemano
+    from obman_train_amd.netscripts.epochpass3d import epoch_pass
+    from obman_train_amd.queries import TransQueries
+
+    model, sample = _model_and_sample(batch=4, seed=6)
+    with torch.no_grad():
+        _, want, _ = model.forward(dict(sample))
+    meters, pck = epoch_pass([dict(sample), dict(sample)], model, epoch=2, train=False, save_results=True, save_path=str(tmp_path))
+    for idx in (0, 1):
+        path = os.path.join(str(tmp_path), "save_results", "val", "epoch_2", "batch_{:06d}.pkl".format(idx))
+        data = savemano.load_batch(path)
+        assert set(data) == {"sample", "results"}
+        res = data["results"]
+        # what the reference's load_batch_info reads (savemano.py:13-17): numpy, host-side, same numbers as the device tensors
+        for key in ("verts", "joints", "objpoints3d", "objtrans", "objscale"):
+            assert isinstance(res[key], np.ndarray)
+            np.testing.assert_array_equal(res[key], want[key].cpu().numpy())
+        assert res["objfaces"].shape == (1280, 3)
+        masks = res["contact_info"]["repulsion_masks"]
+        assert masks.shape == (4, 778) and masks.dtype == np.bool_
+        np.testing.assert_array_equal(masks, want["contact_info"]["repulsion_masks"].cpu().numpy())
+        assert data["sample"]["sides"] == ["left"] * 4 and data["sample"][TransQueries.images.value].shape == (4, 3, 64, 64)
+    # PCK evaluator fed from device joints: same measures as computing the distances on the host
+    from obman_train_amd.evaluation.zimeval import EvalUtil
+
+    ev = EvalUtil(num_kp=21)
+    d = np.sqrt(((want["joints"].cpu().numpy() - sample[TransQueries.joints3d].numpy()) ** 2).sum(2))
+    ev.feed_batch(np.concatenate([d, d]), None)
+    epe_mean, _, epe_median, auc, curve, _ = ev.get_measures(0, 50, 20)
+    np.testing.assert_allclose(pck["epe_mean"], epe_mean, rtol=1e-5)
+    np.testing.assert_allclose(pck["epe_median"], epe_median, rtol=1e-5)
+    np.testing.assert_allclose(pck["auc"], auc, rtol=1e-6)
+    np.testing.assert_allclose(pck["pck_curve"], curve, rtol=1e-6)
+    assert meters.average_meters["total_loss"].count == 2

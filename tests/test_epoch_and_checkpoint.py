@@ -35,6 +35,48 @@ def test_epoch_pass_trains_and_averages(golden, monkeypatch):
     assert meters2.average_meters["total_loss"].avg == pytest.approx(first, rel=1e-4)
 
 
+def test_log_freq_window_keeps_every_step_in_the_running_means(golden, monkeypatch):
+    """log_freq > 1 reads the losses back once per window but every step must still enter the averages (the reference adds
+    each step, epochpass3d.py:111-121): same sums and counts as log_freq = 1, incl. the trailing partial window."""
+    fake_ops.install(monkeypatch)
+    from obman_train_amd.netscripts.epochpass3d import epoch_pass
+    from obman_train_amd.trainer import make_optimizer
+
+    g = golden("handnet_eval")
+    out = {}
+    for log_freq in (1, 3):
+        model, _ = build_fixture_model(g, monkeypatch, train_mode=True)
+        opt = make_optimizer(model, "adam", lr=1e-3)
+        meters, _ = epoch_pass([fixture_sample(g) for _ in range(5)], model, epoch=0, optimizer=opt, train=True,
+                               freeze_batchnorm=True, log_freq=log_freq)
+        out[log_freq] = {k: (m.sum, m.count) for k, m in meters.average_meters.items()}
+    assert out[1]["total_loss"][1] == 5 and set(out[1]) == set(out[3])
+    for k in out[1]:
+        assert out[3][k][1] == out[1][k][1], k
+        assert out[3][k][0] == pytest.approx(out[1][k][0], rel=1e-6), k
+    assert len({round(v, 3) for v in [out[1]["total_loss"][0]]}) == 1
+
+
+def test_strict_loading_is_honoured(golden, monkeypatch, tmp_path):
+    """strict=True raises on a missing model key (as the reference does); only manopth's buffers are filtered out."""
+    fake_ops.install(monkeypatch)
+    from obman_train_amd.modelutils import modelio
+
+    g = golden("handnet_eval")
+    model, _ = build_fixture_model(g, monkeypatch, train_mode=False)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["mano_branch.mano_layer_left.th_weights"] = torch.zeros(778, 16)  # reference-only buffer: ignored, not an error
+    torch.save({"epoch": 1, "state_dict": sd, "best_score": 0.0}, str(tmp_path / "full.pth.tar"))
+    with pytest.warns(UserWarning):
+        modelio.load_checkpoint(model, str(tmp_path / "full.pth.tar"), strict=True)
+    del sd["mano_branch.pose_reg.bias"]
+    torch.save({"epoch": 1, "state_dict": sd, "best_score": 0.0}, str(tmp_path / "partial.pth.tar"))
+    with pytest.warns(UserWarning), pytest.raises(RuntimeError):
+        modelio.load_checkpoint(model, str(tmp_path / "partial.pth.tar"), strict=True)
+    with pytest.warns(UserWarning):
+        modelio.load_checkpoint(model, str(tmp_path / "partial.pth.tar"), strict=False)  # what traineval.py passes
+
+
 def test_checkpoint_roundtrip_and_reference_layout(golden, monkeypatch, tmp_path):
     fake_ops.install(monkeypatch)
     from obman_train_amd.modelutils import modelio
