@@ -626,207 +626,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 }
 
 
-// ================================================================================================ bf16 MFMA flavour
-// Same operand generators and epilogues, but the tiles live in LDS as bf16 and the contraction runs on
-// v_mfma_f32_32x32x16_bf16 (16x the fp32-input rate, fp32 accumulate).  With the matrix pipe that cheap the cost moves to
-// operand generation, so a block covers 128 rows x (64*WN) output columns: the generated A tile is reused by every
-// column of the layer (N = 257 -> one 320-wide block instead of five 64-wide ones).  LDS tiles are [row][k] with k
-// contiguous and an 80-byte pitch: 16-byte aligned rows, and each 16-lane service group of a ds_read_b128 fragment read
-// ({0-3,12-15,20-27}, ...) lands on 16 disjoint 4-bank slots (20 r mod 64).  Weights are cast to bf16 [n][k] images once
-// per call (wcast_kernel), so B staging is a 16-byte copy.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef unsigned short bfraw;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vectors stay in registers (HIP's uint4 class went to scratch)
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int LP = 40;  // LDS row pitch in bf16 elements (32 k + 8 pad)
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
-  const f32x2v v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-// out[n][k] (pitch Kp, zero beyond K) = transposed ? W[k][n] : W[n][k]
-__global__ __launch_bounds__(256) void wcast_kernel(const float* __restrict__ W, int ld, int Nn, int K, int Kp, int transposed,
-                                                    bfraw* __restrict__ out) {
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
-  if (i >= (long)Nn * Kp) return;
-  const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
-  auto at = [&](int kk) { return kk < K ? (transposed ? W[(size_t)kk * ld + n] : W[(size_t)n * ld + kk]) : 0.f; };
-  *reinterpret_cast<unsigned*>(out + i) = pack_bf16(at(k), at(k + 1));
-}
-
-constexpr int NTB = 512;  // 8 waves: 4 along M x 2 along N, wave tile 32 x (32*WN) -> <= 256 registers, two waves per SIMD
-
-template <class AOp, class Epi, int WN>
-__global__ __launch_bounds__(NTB) void gemm_rows_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int K, int Nc, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BNW = 64 * WN;
-  constexpr int BCH = (256 * WN + NTB - 1) / NTB;  // 16-byte B chunks per thread
-  bfraw* As = reinterpret_cast<bfraw*>(smem);  // [2][BM][LP]
-  bfraw* Bs = As + 2 * BM * LP;                // [2][BNW][LP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BNW;
-  const int kq = (tid & 7) * 4, rm = tid >> 3;  // A staging: 4 consecutive k x rows rm, rm + 64
-  typename AOp::Row rows[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int r = bm0 + rm + 64 * p;
-    rows[p] = aop.row(r, (r < aop.R ? r : aop.R - 1) / rows_N(aop));
-  }
-  typename AOp::Raw ra[2][4];
-  typename AOp::KC kcur[4];
-  u32x4 rb[BCH];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kcur[j] = aop.kc(k0 + kq + j);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) aop.raw4(rows[p], k0 + kq, ra[p]);
-#pragma unroll
-    for (int j = 0; j < BCH; ++j) {  // B tile = BNW rows x 4 chunks of 8 k (16 bytes)
-      const int c = tid + NTB * j, n = bn0 + (c >> 2);
-      if (c < 256 * WN) rb[j] = *reinterpret_cast<const u32x4*>(Wb + (size_t)(n < Nc ? n : Nc - 1) * Kp + k0 + (c & 3) * 8);
-    }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      u32x2 w;
-      w.x = pack_bf16(aop.fin(rows[p], kcur[0], ra[p][0]), aop.fin(rows[p], kcur[1], ra[p][1]));
-      w.y = pack_bf16(aop.fin(rows[p], kcur[2], ra[p][2]), aop.fin(rows[p], kcur[3], ra[p][3]));
-      *reinterpret_cast<u32x2*>(As + ((size_t)buf * BM + rm + 64 * p) * LP + kq) = w;
-    }
-#pragma unroll
-    for (int j = 0; j < BCH; ++j) {
-      const int c = tid + NTB * j;
-      if (c < 256 * WN) *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + (c >> 2)) * LP + (c & 3) * 8) = rb[j];
-    }
-  };
-  f32x16 acc[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const int nk = (K + BK - 1) / BK;
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  const int fk = (lane >> 5) * 8, fr = lane & 31;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) fetch((kt + 1) * BK);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((size_t)cur * BM + wm * 32 + fr) * LP + ks * 16 + fk);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((size_t)cur * BNW + wn * 32 * WN + j * 32 + fr) * LP + ks * 16 + fk);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-      }
-    }
-    if (more) stash(cur ^ 1);
-    __syncthreads();
-  }
-  epi.template finish_wide<WN>(acc, bm0 + wm * 32, bn0 + wn * 32 * WN, lane, wm, wn, smem);
-}
-
-// Weight gradients on the bf16 pipe: C[M x Nc] = sum_r A[r,m] B[r,n].  The contraction index is the row, so a lane's
-// fragment is 8 consecutive ROWS of one channel: each thread generates a column strip (A: one channel x 8 rows, B: WN
-// channels x 4 rows; loads stay coalesced along the channel), packs row pairs and writes 16- / 8-byte pieces of the
-// [channel][row] tile.  Row descriptors are wave-uniform (scalar registers).
-template <class AOp, class BOp, int WN>
-__global__ __launch_bounds__(NTB) void gemm_tn_bf16_kernel(AOp aop, BOp bop, int M, int Nc, int R, int rows_per_chunk, float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BNW = 64 * WN;
-  bfraw* As = reinterpret_cast<bfraw*>(smem);  // [2][BM][LP]   (m, r)
-  bfraw* Bs = As + 2 * BM * LP;                // [2][BNW][LP]  (n, r)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int mt = (M + BM - 1) / BM;
-  const int bm0 = (blockIdx.x % mt) * BM, bn0 = (blockIdx.x / mt) * BNW;
-  const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
-  const int qa = __builtin_amdgcn_readfirstlane(tid >> 7);  // A: rows qa*8 .. +7 of the 32-row k-tile
-  const int gb = __builtin_amdgcn_readfirstlane(tid >> 6);  // B: rows gb*4 .. +3
-  const int ma = tid & 127, nbl = tid & 63;
-  const typename AOp::KC kca = aop.kc(bm0 + ma);
-  typename BOp::KC kcb[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j) kcb[j] = bop.kc(bn0 + nbl + 64 * j);
-  typename AOp::Row rowa[8];
-  typename AOp::Raw ra[8];
-  typename BOp::Row rowb[4];
-  typename BOp::Raw rb[WN][4];
-  auto fetch = [&](int r0) {
-    const int bha = r0 / rows_N(aop), bhb = r0 / rows_N(bop);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = r0 + qa * 8 + i;
-      rowa[i] = aop.row(r < rend ? r : 0x7ffffff0, bha);
-      ra[i] = aop.raw(rowa[i], bm0 + ma);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = r0 + gb * 4 + i;
-      rowb[i] = bop.row(r < rend ? r : 0x7ffffff0, bhb);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) rb[j][i] = bop.raw(rowb[i], bn0 + nbl + 64 * j);
-    }
-  };
-  auto stash = [&](int buf) {
-    u32x4 w;
-    w.x = pack_bf16(aop.fin(rowa[0], kca, ra[0]), aop.fin(rowa[1], kca, ra[1]));
-    w.y = pack_bf16(aop.fin(rowa[2], kca, ra[2]), aop.fin(rowa[3], kca, ra[3]));
-    w.z = pack_bf16(aop.fin(rowa[4], kca, ra[4]), aop.fin(rowa[5], kca, ra[5]));
-    w.w = pack_bf16(aop.fin(rowa[6], kca, ra[6]), aop.fin(rowa[7], kca, ra[7]));
-    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + ma) * LP + qa * 8) = w;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      u32x2 v;
-      v.x = pack_bf16(bop.fin(rowb[0], kcb[j], rb[j][0]), bop.fin(rowb[1], kcb[j], rb[j][1]));
-      v.y = pack_bf16(bop.fin(rowb[2], kcb[j], rb[j][2]), bop.fin(rowb[3], kcb[j], rb[j][3]));
-      *reinterpret_cast<u32x2*>(Bs + ((size_t)buf * BNW + nbl + 64 * j) * LP + gb * 4) = v;
-    }
-  };
-  f32x16 acc[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const int nk = (rend - rbeg + BK - 1) / BK;
-  if (nk > 0) {
-    fetch(rbeg);
-    stash(0);
-  }
-  __syncthreads();
-  const int fk = (lane >> 5) * 8, fr = lane & 31;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) fetch(rbeg + (kt + 1) * BK);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((size_t)cur * BM + wm * 32 + fr) * LP + ks * 16 + fk);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((size_t)cur * BNW + wn * 32 * WN + j * 32 + fr) * LP + ks * 16 + fk);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-      }
-    }
-    if (more) stash(cur ^ 1);
-    __syncthreads();
-  }
-  float* dst = part + (size_t)blockIdx.y * M * Nc;
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int col = bn0 + wn * 32 * WN + j * 32 + (lane & 31);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = bm0 + wm * 32 + acc_row(reg, lane);
-      if (m < M && col < Nc) dst[(size_t)m * Nc + col] = acc[j][reg];
-    }
-  }
-}
+#include "decoder_bf16.h"
 
 }  // namespace dec
 
@@ -982,8 +782,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   t[c] = beta[c] - m * gamma[c] * rs;
 }
 
+// element loads of an activation stored as fp32 (exact flavour) or bf16 (bf16 flavour)
+__device__ __forceinline__ float ldact(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ldact(const bfraw* p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
+
 // out[r, 0:3] = f * (b4 + W4 . relu(s3*h3[r]+t3)); 32 lanes per row, float4 per lane (C3 <= 128), 2 rows per wave pass
-__global__ __launch_bounds__(256) void l4_fwd_kernel(const float* __restrict__ H3, int ld3, const float* __restrict__ s3,
+template <class HT>
+__global__ __launch_bounds__(256) void l4_fwd_kernel(const HT* __restrict__ H3, int ld3, const float* __restrict__ s3,
                                                      const float* __restrict__ t3, const float* __restrict__ W4,
                                                      const float* __restrict__ b4, float f, long R, int C3, float* __restrict__ out) {
   const int tid = threadIdx.x, sub = tid & 31;
@@ -992,7 +797,7 @@ __global__ __launch_bounds__(256) void l4_fwd_kernel(const float* __restrict__ H
   for (long r = r0; r < R; r += stride) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int c = sub; c < C3; c += 32) {
-      const float a = fmaxf(__fmaf_rn(s3[c], H3[(size_t)r * ld3 + c], t3[c]), 0.f);
+      const float a = fmaxf(__fmaf_rn(s3[c], ldact(H3, (size_t)r * ld3 + c), t3[c]), 0.f);
       a0 = __fmaf_rn(a, W4[c], a0);
       a1 = __fmaf_rn(a, W4[C3 + c], a1);
       a2 = __fmaf_rn(a, W4[2 * C3 + c], a2);
@@ -1011,7 +816,8 @@ __global__ __launch_bounds__(256) void l4_fwd_kernel(const float* __restrict__ H
 
 // Layer-4 backward over a chunk of rows: thread = channel c.  Partials: sums[blk][C3][2] (S1,S2 fp64),
 // gw[blk][3*C3 + 4] (gW4 rows then gb4).
-__global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G, const float* __restrict__ H3, int ld3,
+template <class HT>
+__global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G, const HT* __restrict__ H3, int ld3,
                                                      const float* __restrict__ s3, const float* __restrict__ t3,
                                                      const float* __restrict__ mean3, const float* __restrict__ rstd3,
                                                      const float* __restrict__ W4, float f, long R, int C3, int rows_per_blk,
@@ -1025,7 +831,7 @@ __global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G
   float g0a = 0.f, g1a = 0.f, g2a = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
   for (long r = rbeg; r < rend; ++r) {
     const float g0 = f * G[r * 3], g1 = f * G[r * 3 + 1], g2 = f * G[r * 3 + 2];
-    const float h = ok ? H3[(size_t)r * ld3 + c] : 0.f;
+    const float h = ok ? ldact(H3, (size_t)r * ld3 + c) : 0.f;
     const float y = __fmaf_rn(cs, h, ct);
     const float a = fmaxf(y, 0.f);
     const float gy = y > 0.f ? (g0 * w0 + g1 * w1 + g2 * w2) : 0.f;
@@ -1330,8 +1136,7 @@ struct Dims {
   long R;
 };
 inline int kpad(int K) { return (K + BK - 1) / BK * BK; }       // k extent of a bf16 weight image (zero padded)
-inline int wide_wn(int Nc) { return Nc > 320 ? 9 : (Nc > 128 ? 5 : 2); }  // 32-column MFMA tiles per wave of the bf16 rows kernel
-inline int tn_wn(int Nc) { return Nc > 128 ? 5 : 2; }                       // ... of the bf16 weight-gradient kernel
+inline int wide_wn(int Nc) { return Nc > 128 ? 5 : 2; }         // 32-column MFMA tiles per wave of the bf16 kernels (block = 64 * WN columns)
 Dims dims_of(const obman_pointgen_params* p) {
   Dims d;
   d.B = p->B; d.N = p->N; d.C1 = p->C1; d.C2 = p->C1 / 2; d.C3 = p->C1 / 4;
@@ -1352,8 +1157,9 @@ FwdWs fwd_ws(const Dims& d) {
   FwdWs w; long o = 0;
   auto take = [&](long n) { long at = o; o += (n + 15) / 16 * 16; return at; };
   w.Gx = take((long)d.N * d.ld1); w.Fx = take((long)d.B * d.ld1); w.mean1 = take(d.ld1); w.rstd1 = take(d.ld1);
-  w.H2 = take(d.R * d.ld2); w.mean2 = take(d.ld2); w.rstd2 = take(d.ld2); w.s2 = take(d.ld2); w.t2 = take(d.ld2);
-  w.H3 = take(d.R * d.ld3); w.mean3 = take(d.ld3); w.rstd3 = take(d.ld3); w.s3 = take(d.ld3); w.t3 = take(d.ld3);
+  const int act = d.bf16 ? 2 : 1;  // bf16 flavour: activations stored as bf16 (two per float slot)
+  w.H2 = take(d.R * d.ld2 / act); w.mean2 = take(d.ld2); w.rstd2 = take(d.ld2); w.s2 = take(d.ld2); w.t2 = take(d.ld2);
+  w.H3 = take(d.R * d.ld3 / act); w.mean3 = take(d.ld3); w.rstd3 = take(d.ld3); w.s3 = take(d.ld3); w.t3 = take(d.ld3);
   w.moments = take((long)d.rb * d.C2 * 2 * 2);  // doubles
   w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
   w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
@@ -1369,12 +1175,17 @@ int tn_chunk_rows(int M, int Nc, long R, int bn = BN) {
   want = (want + 7) / 8 * 8;                              // ... a multiple of 8: whole chunks are dealt to the 8 XCDs
   long rows = (R + want - 1) / want;
   if (rows < 128) rows = 128;
+  if (bn > BN) rows = (rows + BKT - 1) / BKT * BKT;      // whole 64-row k-tiles of the bf16 kernel
   return (int)rows;
 }
 // l1_reduce geometry: vertex sub-tiles per block such that tiles x sample-groups x channel-tiles ~ 1024 blocks
 struct L1Geo { int S, tiles, groups; };
 L1Geo l1_geo(const Dims& d) {
   L1Geo g;
+  if (d.bf16) {  // EpiL1B: one partial P per group of 16 vertices, one partial Q per group of 8 samples
+    g.S = 1; g.tiles = (d.N + 15) / 16; g.groups = (d.B + 7) / 8;
+    return g;
+  }
   g.groups = (d.B + L1_B - 1) / L1_B;
   const int sub = (d.N + L1_V - 1) / L1_V, ct = (d.C1 + 255) / 256;
   const int want = 1024 / (g.groups * ct) > 0 ? 1024 / (g.groups * ct) : 1;
@@ -1384,7 +1195,7 @@ L1Geo l1_geo(const Dims& d) {
   return g;
 }
 struct BwdWs {
-  long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, dF, dG, seg, segw, tn, wt2, wt3, total;
+  long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, Ppre, dF, dG, seg, segw, tn, wt2, wt3, total;
   int chunks;
 };
 BwdWs bwd_ws(const Dims& d) {
@@ -1392,7 +1203,8 @@ BwdWs bwd_ws(const Dims& d) {
   auto take = [&](long n) { long at = o; o += (n + 15) / 16 * 16; return at; };
   w.chunks = (int)((d.R + TN_CHUNK_ROWS - 1) / TN_CHUNK_ROWS);
   const int l4b = (int)((d.R + L4_ROWS - 1) / L4_ROWS);
-  w.GY2 = take(d.R * d.ld2); w.GY1 = take(d.R * d.ld1);
+  w.GY2 = take(d.bf16 ? d.R * d.ld2 / 2 : d.R * d.ld2);
+  w.GY1 = take(d.bf16 ? 0 : d.R * d.ld1);  // bf16 flavour: gy1 is never materialised (EpiL1B)
   w.sums = take((long)(d.rb > l4b ? d.rb : l4b) * d.C1 * 2 * 2);
   w.sred = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.C1 * 2 * 2 : 0);  // doubles
   w.k = take(3 * d.ld1);
@@ -1403,6 +1215,7 @@ BwdWs bwd_ws(const Dims& d) {
     const L1Geo g = l1_geo(d);
     w.Pp = take((long)g.tiles * d.B * d.ld1); w.Qp = take((long)g.groups * d.N * d.ld1);
   }
+  w.Ppre = take(d.bf16 && l1_geo(d).tiles > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.B * d.ld1 : 0);
   {  // large-template layer-1 finalize: per-segment partials
     const long nseg = d.N > L1_SPLIT_N ? (d.N + L1_SEG_ROWS - 1) / L1_SEG_ROWS : 0;
     w.seg = take(nseg * 2 * d.C1 * 2);  // doubles
@@ -1410,7 +1223,7 @@ BwdWs bwd_ws(const Dims& d) {
   }
   {  // split-K partials: the largest of the three weight-gradient products
     auto need = [&](int M, int Nc, long R) {
-      const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * tn_wn(Nc) : BN);
+      const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * wide_wn(Nc) : BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
     };
     long a = need(d.C3, d.C2, d.R), b = need(d.C2, d.C1, d.R), c = need(d.C1, d.C1 - 3, d.B);
@@ -1450,48 +1263,48 @@ int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* o
   return 0;
 }
 template <class AOp, class Epi, int WN>
-int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw);
-  static const int once = [] {
-    return (int)hipFuncSetAttribute((const void*)gemm_rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * (BM + 64 * WN) * LP * (int)sizeof(bfraw));
-  }();
-  if (once) return once;
-  dim3 grid((unsigned)((R + BM - 1) / BM), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
-  gemm_rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, kpad(K), K, Nc, e);
+int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+  const int Kp = kpad(K);
+  const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
+  static int granted = 0;  // largest dynamic-LDS size already enabled for this instantiation
+  if ((int)lds > granted) {
+    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted = (int)lds;
+  }
+  dim3 grid((unsigned)geo.blocks(), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
+  rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
 template <class AOp, class Epi>
-int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
-  switch (wide_wn(Nc)) {
-    case 9: return launch_rows_bf16_wn<AOp, Epi, 9>(a, Wb, K, Nc, R, e, st);  // N = 515: one 576-wide block instead of two 320-wide ones
-    case 5: return launch_rows_bf16_wn<AOp, Epi, 5>(a, Wb, K, Nc, R, e, st);
-    default: return launch_rows_bf16_wn<AOp, Epi, 2>(a, Wb, K, Nc, R, e, st);
-  }
+int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+  return wide_wn(Nc) == 5 ? launch_rows_bf16_wn<AOp, Epi, 5>(a, Wb, K, Nc, geo, e, st)
+                          : launch_rows_bf16_wn<AOp, Epi, 2>(a, Wb, K, Nc, geo, e, st);
 }
 template <class AOp, class BOp, int WN>
-int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, float* part, float* out, int ldo, int off, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw);
+int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
+                      hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + 64 * WN) * LPT * sizeof(bfraw);
   static const int once = [] {
-    return (int)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * (BM + 64 * WN) * LP * (int)sizeof(bfraw));
+    return (int)hipFuncSetAttribute((const void*)tn_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * (BM + 64 * WN) * LPT * (int)sizeof(bfraw));
   }();
   if (once) return once;
   const int chunk_rows = tn_chunk_rows(M, Nc, R, 64 * WN);
   const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
   dim3 grid((unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))), (unsigned)chunks);
-  gemm_tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, (int)R, chunk_rows, part);
+  tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, R, N, Bsz, chunk_rows, part);
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
 template <class AOp, class BOp>
-int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, float* part, float* out, int ldo, int off, hipStream_t st) {
-  // (9 column tiles per wave spill in this kernel: two generated operands are staged per thread)
-  return tn_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, part, out, ldo, off, st)
-                        : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, part, out, ldo, off, st);
+int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
+                   hipStream_t st) {
+  return wide_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st)
+                          : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st);
 }
 // -> pointer / row count the finalize kernels should read: the partials themselves, or their 64-segment pre-reduction
 template <class T>
@@ -1504,6 +1317,118 @@ int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) 
   rows = segs;
   return 0;
 }
+// ---- bf16 flavour: layers 2-4 of the forward (after prep_kernel) and the whole backward (decoder_bf16.h)
+int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, float* out, float* ws, hipStream_t st) {
+  const int tr = p->training;
+  double* moments = reinterpret_cast<double*>(ws + w.moments);
+  bfraw* H2 = reinterpret_cast<bfraw*>(ws + w.H2);
+  bfraw* H3 = reinterpret_cast<bfraw*>(ws + w.H3);
+  const RowGeo geo{(int)d.R, d.N, d.B, 0, 0};
+  int rc;
+  {  // h2 = W2 relu(bn1(h1)) + b2
+    BGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
+    EpiStoreB e{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
+    bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
+    if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st))) return rc;
+    if ((rc = launch_rows_bf16<BGridFeat, EpiStoreB>(a, wb, d.C1, d.C2, geo, e, st))) return rc;
+    const double* mom = moments;
+    int mrows = d.rb;
+    if (tr && (rc = pre_reduce<double>(mom, mrows, d.C2 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
+    bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(mom, mrows, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
+                                                               p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
+    OBMAN_LAUNCH_CHECK();
+  }
+  {  // h3 = W3 relu(bn2(h2)) + b3
+    BBnRelu a{H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
+    EpiStoreB e{H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
+    bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb3);
+    if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st))) return rc;
+    if ((rc = launch_rows_bf16<BBnRelu, EpiStoreB>(a, wb, d.C2, d.C3, geo, e, st))) return rc;
+    const double* mom = moments;
+    int mrows = d.rb;
+    if (tr && (rc = pre_reduce<double>(mom, mrows, d.C3 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
+    bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(mom, mrows, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
+                                                               p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
+    OBMAN_LAUNCH_CHECK();
+  }
+  l4_fwd_kernel<bfraw><<<2048, 256, 0, st>>>(H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// everything of the backward up to (and including) P[b,c] = sum_n gy1, Q[n,c] = sum_b gy1; the caller continues with layer 1
+int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, const BwdWs& v, const float* g_out, const float* ws,
+                  float* ws2, const obman_pointgen_grads* g, hipStream_t st) {
+  const int tr = p->training;
+  double* sums = reinterpret_cast<double*>(ws2 + v.sums);
+  float *k1 = ws2 + v.k, *k2 = k1 + d.ld1, *k3 = k2 + d.ld1;
+  const float f = p->out_factor;
+  const bfraw* H2 = reinterpret_cast<const bfraw*>(ws + w.H2);
+  const bfraw* H3 = reinterpret_cast<const bfraw*>(ws + w.H3);
+  bfraw* GY2 = reinterpret_cast<bfraw*>(ws2 + v.GY2);
+  const RowGeo lin{(int)d.R, d.N, d.B, 0, 0};
+  int rc;
+  // ---- layer 4 + BN-3 statistics
+  const int l4b = obman_cdiv(d.R, L4_ROWS);
+  l4_bwd_kernel<bfraw><<<l4b, 128, 0, st>>>(g_out, H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3, L4_ROWS,
+                                             sums, ws2 + v.l4p);
+  OBMAN_LAUNCH_CHECK();
+  {
+    const float* lp = ws2 + v.l4p;
+    int lrows = l4b;
+    if ((rc = pre_reduce<float>(lp, lrows, 3 * d.C3 + 4, ws2 + v.l4red, st))) return rc;
+    l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 4), 256, 0, st>>>(lp, lrows, d.C3, g->w4, g->b4);
+    OBMAN_LAUNCH_CHECK();
+  }
+  const double* sp = sums;
+  int srows = l4b;
+  if ((rc = pre_reduce<double>(sp, srows, d.C3 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sp, srows, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2], g->bn_b[2],
+                                                                 g->b3, k1, k2, k3);
+  OBMAN_LAUNCH_CHECK();
+  {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
+    TGradH3 ta{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
+    TBnRelu tb{H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
+    if ((rc = launch_tn_bf16<TGradH3, TBnRelu>(ta, tb, d.C3, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
+  }
+  {  // gy2 = (gh3 W3) * (y2 > 0) stored bf16, BN-2 sums.  B[k = out channel][n = in channel] = W3[k][n]: the transposed image
+    BGradH3 a{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
+    EpiMaskB e{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
+    bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt3);
+    if ((rc = launch_wcast(p->w3, d.C2, d.C2, d.C3, 1, wt, st))) return rc;
+    if ((rc = launch_rows_bf16<BGradH3, EpiMaskB>(a, wt, d.C3, d.C2, lin, e, st))) return rc;
+  }
+  sp = sums;
+  srows = d.rb;
+  if ((rc = pre_reduce<double>(sp, srows, d.C2 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
+  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
+                                                                 g->b2, k1, k2, k3);
+  OBMAN_LAUNCH_CHECK();
+  {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c]
+    TGradH ta{GY2, H2, k1, k2, k3, d.ld2, d.C2};
+    TGridFeat tb{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, d.C1};
+    if ((rc = launch_tn_bf16<TGradH, TGridFeat>(ta, tb, d.C2, d.C1, d.R, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
+  }
+  const L1Geo lg = l1_geo(d);
+  {  // dA(gy1) with the (8 samples x 16 vertices) row tiling: P / Q partials straight from the accumulators
+    BGradH a{GY2, H2, k1, k2, k3, d.ld2, d.C2};
+    EpiL1B e{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
+    const RowGeo tiled{(int)d.R, d.N, d.B, lg.tiles, 1};
+    bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt2);
+    if ((rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st))) return rc;
+    if ((rc = launch_rows_bf16<BGradH, EpiL1B>(a, wt, d.C2, d.C1, tiled, e, st))) return rc;
+  }
+  {  // P[b,c] = sum over the vertex groups, Q[n,c] = sum over the sample groups (fixed order)
+    const float* pp = ws2 + v.Pp;
+    int prow = lg.tiles;
+    if ((rc = pre_reduce<float>(pp, prow, d.B * d.ld1, ws2 + v.Ppre, st))) return rc;
+    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, lg.groups,
+                                                                                ws2 + v.P, ws2 + v.Q);
+    OBMAN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 bool params_ok(const obman_pointgen_params* p) {
   return p && p->B > 0 && p->N > 0 && p->C1 >= 8 && p->C1 / 4 <= 128 && p->grid && p->feat && p->w1 && p->w2 && p->w3 && p->w4;
 }
@@ -1532,19 +1457,13 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
                                                                ws + w.mean1, ws + w.rstd1);
     OBMAN_LAUNCH_CHECK();
   }
+  if (d.bf16) return forward_bf16(p, d, w, out, ws, st);
   double* moments = reinterpret_cast<double*>(ws + w.moments);
   {  // h2 = W2 relu(bn1(h1)) + b2
     AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1};
     EpiStoreImpl e;
     e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
-    int rc;
-    if (d.bf16) {
-      bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
-      rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st);
-      if (!rc) rc = launch_rows_bf16<AGridFeat, EpiStoreImpl>(a, wb, d.C1, d.C2, d.R, e, st);
-    } else {
-      rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
-    }
+    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
     if (rc) return rc;
     const double* mom = moments;
     int mrows = d.rb;
@@ -1557,14 +1476,7 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
     ABnRelu a{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, (int)d.R, d.C2};
     EpiStoreImpl e;
     e.C = ws + w.H3; e.bias = p->b3; e.moments = tr ? moments : nullptr; e.ldc = d.ld3; e.R = (int)d.R; e.Nc = d.C3;
-    int rc;
-    if (d.bf16) {
-      bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb3);
-      rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st);
-      if (!rc) rc = launch_rows_bf16<ABnRelu, EpiStoreImpl>(a, wb, d.C2, d.C3, d.R, e, st);
-    } else {
-      rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
-    }
+    int rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
     if (rc) return rc;
     const double* mom = moments;
     int mrows = d.rb;
@@ -1573,7 +1485,7 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
     OBMAN_LAUNCH_CHECK();
   }
-  l4_fwd_kernel<<<2048, 256, 0, st>>>(ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
+  l4_fwd_kernel<float><<<2048, 256, 0, st>>>(ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -1588,75 +1500,60 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
   const int tr = p->training;
   const int R = (int)d.R;
   ObmanProfScope prof(OBMAN_K_DECODER_BWD, st);
-  double* sums = reinterpret_cast<double*>(ws2 + v.sums);
-  float *k1 = ws2 + v.k, *k2 = k1 + d.ld1, *k3 = k2 + d.ld1;
-  const float f = p->out_factor;
-  // ---- layer 4 + BN-3 statistics
-  const int l4b = obman_cdiv(d.R, L4_ROWS);
-  l4_bwd_kernel<<<l4b, 128, 0, st>>>(g_out, ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3,
-                                      L4_ROWS, sums, ws2 + v.l4p);
-  OBMAN_LAUNCH_CHECK();
   int rc;
-  {
-    const float* lp = ws2 + v.l4p;
-    int lrows = l4b;
-    if ((rc = pre_reduce<float>(lp, lrows, 3 * d.C3 + 4, ws2 + v.l4red, st))) return rc;
-    l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 4), 256, 0, st>>>(lp, lrows, d.C3, g->w4, g->b4);
-  }
-  const double* sp = sums;
-  int srows = l4b;
-  if ((rc = pre_reduce<double>(sp, srows, d.C3 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sp, srows, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2], g->bn_b[2],
-                                                                 g->b3, k1, k2, k3);
-  OBMAN_LAUNCH_CHECK();
-  AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
-  {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
-    ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
-    rc = d.bf16 ? launch_tn_bf16<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, ws2 + v.tn, g->w3, d.C2, 0, st)
-                : launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st);
-    if (rc) return rc;
-  }
-  {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
-    EpiMaskStatsImpl e;
-    e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
-    e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
-    e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N;
-    if (d.bf16) {  // B[k = out channel][n = in channel] = W3[k][n]: the transposed image
-      bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt3);
-      rc = launch_wcast(p->w3, d.C2, d.C2, d.C3, 1, wt, st);
-      if (!rc) rc = launch_rows_bf16<AGradH3, EpiMaskStatsImpl>(gh3, wt, d.C3, d.C2, d.R, e, st);
-    } else {
-      rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st);
+  if (d.bf16) {
+    if ((rc = backward_bf16(p, d, w, v, g_out, ws, ws2, g, st))) return rc;
+  } else {
+    double* sums = reinterpret_cast<double*>(ws2 + v.sums);
+    float *k1 = ws2 + v.k, *k2 = k1 + d.ld1, *k3 = k2 + d.ld1;
+    const float f = p->out_factor;
+    // ---- layer 4 + BN-3 statistics
+    const int l4b = obman_cdiv(d.R, L4_ROWS);
+    l4_bwd_kernel<float><<<l4b, 128, 0, st>>>(g_out, ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3,
+                                               L4_ROWS, sums, ws2 + v.l4p);
+    OBMAN_LAUNCH_CHECK();
+    {
+      const float* lp = ws2 + v.l4p;
+      int lrows = l4b;
+      if ((rc = pre_reduce<float>(lp, lrows, 3 * d.C3 + 4, ws2 + v.l4red, st))) return rc;
+      l4_bwd_finalize_kernel<<<obman_cdiv(3 * d.C3 + 3, 4), 256, 0, st>>>(lp, lrows, d.C3, g->w4, g->b4);
+      OBMAN_LAUNCH_CHECK();
     }
-    if (rc) return rc;
-  }
-  sp = sums;
-  srows = d.rb;
-  if ((rc = pre_reduce<double>(sp, srows, d.C2 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
-  bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
-                                                                 g->b2, k1, k2, k3);
-  OBMAN_LAUNCH_CHECK();
-  AGradH gh2{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, R, d.C2};
-  AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1};
-  rc = d.bf16 ? launch_tn_bf16<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, ws2 + v.tn, g->w2, d.C1, 0, st)  // gW2[o,c]
-              : launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st);
-  if (rc) return rc;
-  {  // gy1 = (gh2 W2) * (y1 > 0)
-    EpiMaskStatsImpl e;
-    e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
-    e.H = e.s = e.t = e.mean = e.rstd = nullptr;
-    e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N;
-    if (d.bf16) {
-      bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt2);
-      rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st);
-      if (!rc) rc = launch_rows_bf16<AGradH, EpiMaskStatsImpl>(gh2, wt, d.C2, d.C1, d.R, e, st);
-    } else {
-      rc = launch_rows<AGradH, false, EpiMaskStatsImpl>(gh2, p->w2, d.C1, d.C2, d.C1, d.R, e, st);
+    const double* sp = sums;
+    int srows = l4b;
+    if ((rc = pre_reduce<double>(sp, srows, d.C3 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
+    bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sp, srows, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2],
+                                                                   g->bn_b[2], g->b3, k1, k2, k3);
+    OBMAN_LAUNCH_CHECK();
+    AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
+    {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
+      ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
+      if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
     }
-    if (rc) return rc;
-  }
-  // ---- layer 1 in factored form
-  {
+    {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
+      EpiMaskStatsImpl e;
+      e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
+      e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
+      e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N;
+      if ((rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st))) return rc;
+    }
+    sp = sums;
+    srows = d.rb;
+    if ((rc = pre_reduce<double>(sp, srows, d.C2 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
+    bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1],
+                                                                   g->bn_b[1], g->b2, k1, k2, k3);
+    OBMAN_LAUNCH_CHECK();
+    AGradH gh2{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, R, d.C2};
+    AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1};
+    if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;  // gW2[o,c]
+    {  // gy1 = (gh2 W2) * (y1 > 0)
+      EpiMaskStatsImpl e;
+      e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
+      e.H = e.s = e.t = e.mean = e.rstd = nullptr;
+      e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N;
+      if ((rc = launch_rows<AGradH, false, EpiMaskStatsImpl>(gh2, p->w2, d.C1, d.C2, d.C1, d.R, e, st))) return rc;
+    }
+    // ---- layer 1 in factored form: P[b,c] = sum_n gy1, Q[n,c] = sum_b gy1 from one read of gy1
     const L1Geo lg = l1_geo(d);
     l1_reduce_kernel<<<dim3(lg.tiles, lg.groups, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, lg.S, ws2 + v.Pp,
                                                                                          ws2 + v.Qp);

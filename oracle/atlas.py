@@ -15,14 +15,17 @@ from .chamfer import chamfer_loss
 def pointgen(params, x, training=True, out_factor=200.0, prefix="decoder.", momentum=0.1, eps=1e-5, mfma_round=None):
     """PointGenCon.forward (atlasutils.py:65-75): x [B,C,N] -> [B,3,N]; 3x(conv1d k=1, BN1d, ReLU), conv1d, x out_factor.
 
-    ``mfma_round`` (not in the reference): rounding applied to both operands of the layer-2 and layer-3 contractions, e.g.
-    ``lambda t: t.bfloat16().float()`` - the model of the build's bf16-MFMA flavour (fp32 accumulation, fp32 BatchNorm)."""
+    ``mfma_round`` (not in the reference): the model of the build's bf16-MFMA flavour, e.g. ``lambda t: t.bfloat16().float()``:
+    both operands of the layer-2 and layer-3 contractions are rounded, and so are the layer outputs h2 / h3 the build keeps
+    in bf16 (rounded BEFORE BatchNorm, whose statistics are those of the stored values); fp32 accumulation, fp32 BatchNorm."""
     h = x
     for k in (1, 2, 3):
         w = params["%sconv%d.weight" % (prefix, k)]
         if mfma_round is not None and k in (2, 3):
             h, w = mfma_round(h), mfma_round(w)
         h = F.conv1d(h, w, params["%sconv%d.bias" % (prefix, k)])
+        if mfma_round is not None and k in (2, 3):
+            h = mfma_round(h)
         h = F.batch_norm(
             h, params.get("%sbn%d.running_mean" % (prefix, k)), params.get("%sbn%d.running_var" % (prefix, k)),
             params["%sbn%d.weight" % (prefix, k)], params["%sbn%d.bias" % (prefix, k)],
