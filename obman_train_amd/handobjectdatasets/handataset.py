@@ -22,12 +22,62 @@ from . import handutils, imgtrans, vertexsample
 from .imagestage import DeviceImageStage, ImagePlan
 
 
-def one_query_in(candidates, pool):
-    return any(c in pool for c in candidates)
+class _Wants:
+    """Membership tests over the queries of one ``get_sample`` call."""
+
+    def __init__(self, queries):
+        self._q = set(queries)
+
+    def __call__(self, key):
+        return key in self._q
+
+    def any(self, *keys):
+        return any(k in self._q for k in keys)
 
 
-def no_query_in(candidates, pool):
-    return not one_query_in(candidates, pool)
+class _View:
+    """What was drawn for the image of one sample: mirror flag, crop centre / scale, in-plane rotation, and the affine maps
+    derived from them (``affine`` source -> crop pixels, ``post_rot`` = the part that acts on the intrinsics)."""
+
+    __slots__ = ("flip", "pixels", "width", "center", "scale", "rot", "affine", "post_rot")
+
+    def __init__(self):
+        self.flip, self.pixels, self.width = False, None, None
+        self.center = self.scale = None
+        self.rot, self.affine, self.post_rot = 0, None, None
+
+    def mirror_x(self, pts2d):
+        """x -> width - x on a copy (pixel coordinates of the un-mirrored source image)."""
+        if not self.flip:
+            return pts2d
+        pts2d = pts2d.copy()
+        pts2d[:, 0] = self.width - pts2d[:, 0]
+        return pts2d
+
+    def to_crop(self, pts2d):
+        return torch.from_numpy(np.array(handutils.transform_coords(pts2d, self.affine)))
+
+
+class _Rigid3D:
+    """The rigid part of the augmentation applied to every 3-D annotation: mirror about the camera's x axis (when the hand
+    side was switched) and the image's in-plane rotation about the optical axis (float32, like the reference's matrix)."""
+
+    def __init__(self, rot, flip):
+        c, s_ = np.cos(rot), np.sin(rot)
+        self.R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]).astype(np.float32)
+        self.flip = flip
+
+    def mirrored(self, pts):
+        if self.flip:  # in place, as the reference does on the arrays its accessors return
+            pts[:, 0] = -pts[:, 0]
+        return pts
+
+    def spun(self, pts):
+        return self.R.dot(pts.transpose(1, 0)).transpose()
+
+
+_HAND_ROOT_SOURCES = (TransQueries.joints3d, BaseQueries.joints3d, TransQueries.verts3d)
+_OBJECT_TARGETS = (TransQueries.objpoints3d, TransQueries.objverts3d)
 
 
 class HandDataset(torch.utils.data.Dataset):
@@ -61,159 +111,150 @@ class HandDataset(torch.utils.data.Dataset):
         return len(self.pose_dataset)
 
     # -------------------------------------------------------------------------------------------------- one sample
+    # get_sample is assembled from five steps; the order of the RNG draws is the reference's (handataset.py:104-372):
+    # centre jitter, scale jitter, rotation [_draw_view]; surface samples of a mesh object [_object_annotations]; blur radius,
+    # colour factors, op shuffle [_image_plan].
     def get_sample(self, idx, query=None):
-        query = self.queries if query is None else query
-        pose = self.pose_dataset
-        sample = {}
-        wants_image = BaseQueries.images in query or TransQueries.images in query
-        if wants_image:
-            center, scale = pose.get_center_scale(idx)
-
-        flip = False
-        if BaseQueries.sides in query:
-            hand_side = pose.get_sides(idx)
-            if self.sides in ("right", "left") and hand_side != self.sides:
-                flip, hand_side = True, self.sides  # mirror every hand onto the requested side
-            sample[BaseQueries.sides] = hand_side
-
-        if wants_image:
-            img = np.asarray(pose.get_image(idx))  # PIL image or array; the mirror flip itself happens on the GPU
-            src_w = img.shape[1]
-            if BaseQueries.images in query:
-                sample[BaseQueries.images] = img[:, ::-1] if flip else img
-        if flip:
-            center[0] = src_w - center[0]
-
-        if self.train and wants_image:
-            offsets = self.center_jittering * scale * np.random.uniform(low=-1, high=1, size=2)
-            center = center + offsets.astype(int)
-            jitter = self.scale_jittering * np.random.randn() + 1
-            scale = scale * np.clip(jitter, 1 - self.scale_jittering, 1 + self.scale_jittering)
-            rot = np.random.uniform(low=-self.max_rot, high=self.max_rot)
-        else:
-            rot = 0
-        if self.block_rot:
-            rot = self.max_rot
-        rot_mat = np.array([[np.cos(rot), -np.sin(rot), 0], [np.sin(rot), np.cos(rot), 0], [0, 0, 1]]).astype(np.float32)
-
-        if TransQueries.joints2d in query or TransQueries.images in query:
-            affinetrans, post_rot_trans = handutils.get_affine_transform(center, scale, [self.inp_res, self.inp_res], rot=rot)
-            if TransQueries.affinetrans in query:
-                sample[TransQueries.affinetrans] = torch.from_numpy(affinetrans)
-        if BaseQueries.joints2d in query or TransQueries.joints2d in query:
-            joints2d = pose.get_joints2d(idx)
-            if flip:
-                joints2d = joints2d.copy()
-                joints2d[:, 0] = src_w - joints2d[:, 0]
-            if BaseQueries.joints2d in query:
-                sample[BaseQueries.joints2d] = torch.from_numpy(joints2d)
-        if TransQueries.joints2d in query:
-            sample[TransQueries.joints2d] = torch.from_numpy(np.array(handutils.transform_coords(joints2d, affinetrans)))
-
-        if BaseQueries.camintrs in query or TransQueries.camintrs in query:
-            camintr = pose.get_camintr(idx)
-            if BaseQueries.camintrs in query:
-                sample[BaseQueries.camintrs] = camintr
-            if TransQueries.camintrs in query:
-                sample[TransQueries.camintrs] = post_rot_trans.dot(camintr)  # the rotation acts as an extrinsic
-
-        if BaseQueries.objpoints2d in query or TransQueries.objpoints2d in query:
-            objpoints2d = pose.get_objpoints2d(idx)
-            if flip:
-                objpoints2d = objpoints2d.copy()
-                objpoints2d[:, 0] = src_w - objpoints2d[:, 0]
-            if BaseQueries.objpoints2d in query:
-                sample[BaseQueries.objpoints2d] = torch.from_numpy(objpoints2d)
-            if TransQueries.objpoints2d in query:
-                sample[TransQueries.objpoints2d] = torch.from_numpy(np.array(handutils.transform_coords(objpoints2d, affinetrans)))
-
-        if BaseQueries.segms in query or TransQueries.segms in query:
+        want = _Wants(self.queries if query is None else query)
+        out = {}
+        view = self._draw_view(idx, want, out)
+        self._pixel_annotations(idx, want, view, out)
+        if want.any(BaseQueries.segms, TransQueries.segms):
             raise NotImplementedError("segmentation maps are not on the training path (traineval.py:77-88 never requests them)")
+        rigid = _Rigid3D(view.rot, view.flip)
+        root, object_only = self._hand_annotations(idx, want, rigid, out)
+        root = self._object_annotations(idx, want, rigid, root, object_only, out)
+        if want(TransQueries.center3d):
+            out[TransQueries.center3d] = root
+        if want(BaseQueries.manoidxs):
+            out[BaseQueries.manoidxs] = self.pose_dataset.get_manoidxs(idx)
+        if want(TransQueries.images):
+            out[TransQueries.images] = self._image_plan(view)
+        if want(BaseQueries.meta):
+            out[BaseQueries.meta] = self.pose_dataset.get_meta(idx)
+        return out
 
-        # ---- 3-D annotations: flip x, rotate with the image, centre on the root joint
-        center3d = None
-        obj_only = False
-        if one_query_in([BaseQueries.joints3d, TransQueries.joints3d, TransQueries.verts3d, TransQueries.objverts3d,
-                         TransQueries.objpoints3d], query):
-            center3d_queries = [TransQueries.joints3d, BaseQueries.joints3d, TransQueries.verts3d]
-            obj_only = ((TransQueries.objverts3d in query or TransQueries.objpoints3d in query)
-                        and no_query_in(center3d_queries, pose.all_queries)) or self.as_obj_only
-            if not obj_only and one_query_in([TransQueries.objpoints3d, TransQueries.objverts3d] + center3d_queries, query):
-                joints3d = pose.get_joints3d(idx)
-                if flip:
-                    joints3d[:, 0] = -joints3d[:, 0]
-                if BaseQueries.joints3d in query:
-                    sample[BaseQueries.joints3d] = joints3d
+    def _draw_view(self, idx, want, out):
+        """Hand side (and whether the sample is mirrored onto ``self.sides``), source pixels, the drawn crop and rotation."""
+        src, view = self.pose_dataset, _View()
+        with_image = want.any(BaseQueries.images, TransQueries.images)
+        if with_image:
+            view.center, view.scale = src.get_center_scale(idx)
+        if want(BaseQueries.sides):
+            side = src.get_sides(idx)
+            if self.sides in ("right", "left") and side != self.sides:
+                view.flip, side = True, self.sides
+            out[BaseQueries.sides] = side
+        if with_image:
+            view.pixels = np.asarray(src.get_image(idx))  # PIL image or array; the mirror flip itself happens on the GPU
+            view.width = view.pixels.shape[1]
+            if want(BaseQueries.images):
+                out[BaseQueries.images] = view.pixels[:, ::-1] if view.flip else view.pixels
+        if view.flip:
+            view.center[0] = view.width - view.center[0]  # no image requested: fails like the reference (nothing to mirror about)
+        if self.train and with_image:
+            shift = self.center_jittering * view.scale * np.random.uniform(low=-1, high=1, size=2)
+            view.center = view.center + shift.astype(int)
+            zoom = np.clip(self.scale_jittering * np.random.randn() + 1, 1 - self.scale_jittering, 1 + self.scale_jittering)
+            view.scale = view.scale * zoom
+            view.rot = np.random.uniform(low=-self.max_rot, high=self.max_rot)
+        if self.block_rot:
+            view.rot = self.max_rot
+        if want.any(TransQueries.joints2d, TransQueries.images):
+            view.affine, view.post_rot = handutils.get_affine_transform(view.center, view.scale, [self.inp_res, self.inp_res],
+                                                                        rot=view.rot)
+            if want(TransQueries.affinetrans):
+                out[TransQueries.affinetrans] = torch.from_numpy(view.affine)
+        return view
+
+    def _pixel_annotations(self, idx, want, view, out):
+        """2-D joints / object points in source and crop pixels, camera intrinsics before and after the rotation."""
+        src = self.pose_dataset
+        for base_key, crop_key, getter in ((BaseQueries.joints2d, TransQueries.joints2d, src.get_joints2d),
+                                           (BaseQueries.objpoints2d, TransQueries.objpoints2d,
+                                            getattr(src, "get_objpoints2d", None))):
+            if not want.any(base_key, crop_key):
+                continue
+            pts = view.mirror_x(getter(idx))
+            if want(base_key):
+                out[base_key] = torch.from_numpy(pts)
+            if want(crop_key):
+                out[crop_key] = view.to_crop(pts)
+        if want.any(BaseQueries.camintrs, TransQueries.camintrs):
+            intr = src.get_camintr(idx)
+            if want(BaseQueries.camintrs):
+                out[BaseQueries.camintrs] = intr
+            if want(TransQueries.camintrs):
+                out[TransQueries.camintrs] = view.post_rot.dot(intr)  # the rotation acts as an extrinsic
+
+    def _hand_annotations(self, idx, want, rigid, out):
+        """3-D joints and MANO vertices, mirrored / rotated with the image and expressed relative to the root joint.
+        -> (root [3] or None, object_only): ``object_only`` = the sample has no hand to take a root from."""
+        src = self.pose_dataset
+        root, object_only = None, False
+        if want.any(BaseQueries.joints3d, TransQueries.joints3d, TransQueries.verts3d, *_OBJECT_TARGETS):
+            handless = not any(q in src.all_queries for q in _HAND_ROOT_SOURCES)
+            object_only = (want.any(*_OBJECT_TARGETS) and handless) or self.as_obj_only
+            if not object_only and want.any(*(_OBJECT_TARGETS + _HAND_ROOT_SOURCES)):
+                joints = rigid.mirrored(src.get_joints3d(idx))
+                if want(BaseQueries.joints3d):
+                    out[BaseQueries.joints3d] = joints
                 if self.train:
-                    joints3d = rot_mat.dot(joints3d.transpose(1, 0)).transpose()
+                    joints = rigid.spun(joints)
                 if self.center_idx is not None:
-                    center3d = (joints3d[9] + joints3d[0]) / 2 if self.center_idx == -1 else joints3d[self.center_idx]
-                if TransQueries.joints3d in query:
-                    if self.center_idx is not None:
-                        joints3d = joints3d - center3d
-                    sample[TransQueries.joints3d] = torch.from_numpy(joints3d)
+                    root = (joints[9] + joints[0]) / 2 if self.center_idx == -1 else joints[self.center_idx]
+                if want(TransQueries.joints3d):
+                    out[TransQueries.joints3d] = torch.from_numpy(joints - root if self.center_idx is not None else joints)
+        if want(TransQueries.verts3d):
+            verts = rigid.spun(rigid.mirrored(src.get_verts3d(idx)))
+            out[TransQueries.verts3d] = verts - root if self.center_idx is not None else verts
+        return root, object_only
 
-        if TransQueries.verts3d in query:
-            verts = pose.get_verts3d(idx)
-            if flip:
-                verts[:, 0] = -verts[:, 0]
-            verts = rot_mat.dot(verts.transpose(1, 0)).transpose()
-            if self.center_idx is not None:
-                verts = verts - center3d
-            sample[TransQueries.verts3d] = verts
-
-        obj_verts3d = None
-        if TransQueries.objpoints3d in query and BaseQueries.objpoints3d in pose.all_queries:
-            points3d = pose.get_objpoints3d(idx, point_nb=self.point_nb)
-            if flip:
-                points3d[:, 0] = -points3d[:, 0]
-            obj_verts3d = rot_mat.dot(points3d.transpose(1, 0)).transpose()
-        elif (TransQueries.objpoints3d in query or BaseQueries.objverts3d in query or TransQueries.objverts3d in query) and (
-                BaseQueries.objverts3d in pose.all_queries):
-            obj_verts3d, obj_faces = pose.get_obj_verts_faces(idx)
-            if flip:
-                obj_verts3d[:, 0] = -obj_verts3d[:, 0]
-            if BaseQueries.objverts3d in query:
-                sample[BaseQueries.objverts3d] = obj_verts3d
-            if TransQueries.objverts3d in query:
-                mesh = rot_mat.dot(obj_verts3d.transpose(1, 0)).transpose()
-                sample[TransQueries.objverts3d] = mesh - center3d if self.center_idx is not None else mesh
-            if BaseQueries.objfaces in query:
-                sample[BaseQueries.objfaces] = obj_faces
-            obj_verts3d = vertexsample.points_from_mesh(obj_faces, obj_verts3d, vertex_nb=self.point_nb).astype(np.float32)
-            obj_verts3d = rot_mat.dot(obj_verts3d.transpose(1, 0)).transpose()
-        elif TransQueries.objpoints3d in query:
+    def _object_annotations(self, idx, want, rigid, root, object_only, out):
+        """Object point cloud (given, or sampled from the object's mesh) in the hand's frame; for an object-only sample the
+        cloud is centred on its bounding box and inscribed in the unit sphere.  -> the root used (returned for center3d)."""
+        src = self.pose_dataset
+        cloud = None
+        if want(TransQueries.objpoints3d) and BaseQueries.objpoints3d in src.all_queries:
+            cloud = rigid.spun(rigid.mirrored(src.get_objpoints3d(idx, point_nb=self.point_nb)))
+        elif want.any(TransQueries.objpoints3d, BaseQueries.objverts3d, TransQueries.objverts3d) and (
+                BaseQueries.objverts3d in src.all_queries):
+            mesh_verts, mesh_faces = src.get_obj_verts_faces(idx)
+            mesh_verts = rigid.mirrored(mesh_verts)
+            if want(BaseQueries.objverts3d):
+                out[BaseQueries.objverts3d] = mesh_verts
+            if want(TransQueries.objverts3d):
+                posed = rigid.spun(mesh_verts)
+                out[TransQueries.objverts3d] = posed - root if self.center_idx is not None else posed
+            if want(BaseQueries.objfaces):
+                out[BaseQueries.objfaces] = mesh_faces
+            surface = vertexsample.points_from_mesh(mesh_faces, mesh_verts, vertex_nb=self.point_nb).astype(np.float32)
+            cloud = rigid.spun(surface)
+        elif want(TransQueries.objpoints3d):
             raise ValueError("Requested TransQueries.objpoints3d for dataset without BaseQueries.objpoints3d and "
                              "BaseQueries.objverts3d")
-        if TransQueries.objpoints3d in query:
-            if obj_only:
-                center3d = (obj_verts3d.max(0) + obj_verts3d.min(0)) / 2
-            if self.center_idx is not None or obj_only:
-                obj_verts3d = obj_verts3d - center3d
-            if obj_verts3d.max() > 5000:
-                print("object points beyond 5 m in sample {}".format(getattr(pose, "image_names", [idx] * (idx + 1))[idx]))
-            if obj_only:
-                obj_verts3d = obj_verts3d / np.linalg.norm(obj_verts3d, 2, 1).max()  # inscribe in the unit sphere
-            sample[TransQueries.objpoints3d] = torch.from_numpy(obj_verts3d)
+        if want(TransQueries.objpoints3d):
+            if object_only:
+                root = (cloud.max(0) + cloud.min(0)) / 2
+            if self.center_idx is not None or object_only:
+                cloud = cloud - root
+            if cloud.max() > 5000:
+                names = getattr(src, "image_names", None)
+                print("object points beyond 5 m in sample {}".format(names[idx] if names is not None else idx))
+            if object_only:
+                cloud = cloud / np.linalg.norm(cloud, 2, 1).max()
+            out[TransQueries.objpoints3d] = torch.from_numpy(cloud)
+        return root
 
-        if TransQueries.center3d in query:
-            sample[TransQueries.center3d] = center3d
-        if BaseQueries.manoidxs in query:
-            sample[BaseQueries.manoidxs] = pose.get_manoidxs(idx)
-
-        # ---- the image: draw what PIL would have been asked to do, leave the pixels to the GPU
-        if TransQueries.images in query:
-            blur, color_ops = (-1, 0, 0), []
-            if self.train:
-                blur = imgtrans.box_blur_weights(random.random() * self.blur_radius)
-                color_ops = imgtrans.color_jitter_plan(brightness=self.brightness, saturation=self.saturation, hue=self.hue,
-                                                       contrast=self.contrast)
-            fixed = handutils.fixed_point_affine(affinetrans, [self.inp_res, self.inp_res])
-            sample[TransQueries.images] = ImagePlan(img, flip, fixed, blur=blur, ops=color_ops)
-
-        if BaseQueries.meta in query:
-            sample[BaseQueries.meta] = pose.get_meta(idx)
-        return sample
+    def _image_plan(self, view):
+        """What PIL would have been asked to do, recorded instead of done: the pixels are rendered on the GPU per batch."""
+        blur, color_ops = (-1, 0, 0), []
+        if self.train:
+            blur = imgtrans.box_blur_weights(random.random() * self.blur_radius)
+            color_ops = imgtrans.color_jitter_plan(brightness=self.brightness, saturation=self.saturation, hue=self.hue,
+                                                   contrast=self.contrast)
+        fixed = handutils.fixed_point_affine(view.affine, [self.inp_res, self.inp_res])
+        return ImagePlan(view.pixels, view.flip, fixed, blur=blur, ops=color_ops)
 
     def __getitem__(self, idx):
         try:
