@@ -89,7 +89,7 @@ struct RowGeo {
 struct BGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k])   (Gx, Fx: fp32 x-hat factors of layer 1)
   const float *Gx, *Fx, *gamma, *beta;
   int ld, K;
-  static constexpr int NC = 2, DEPTH = 3;
+  static constexpr int NC = 2, DEPTH = 4;
   struct Row { const float *g, *f; bool ok; };
   struct Raw { float4 g0, g1, f0, f1; };
   __device__ void stage(float* kcs, int Kp, int tid) const {
@@ -423,12 +423,17 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
   typename AOp::Raw qa[DA];
   u32x4 qb[DB][BCH];
   const int nk = Kp / BK;
+  // B chunk c of a tile: row n = c / 4, 8 k at (c % 4) * 8.  Every thread loads BCH chunks (the surplus ones of the last
+  // round re-read chunk 0 and are not written to LDS): no divergent load, so the compiler can count outstanding loads.
+  const bfraw* bsrc[BCH];
+#pragma unroll
+  for (int j = 0; j < BCH; ++j) {
+    const int c = tid + NTB * j, cc = c < 256 * WN ? c : 0, n = bn0 + (cc >> 2);
+    bsrc[j] = Wb + (size_t)(n < Nc ? n : Nc - 1) * Kp + (cc & 3) * 8;
+  }
   auto loadB = [&](u32x4* q, int k0) {
 #pragma unroll
-    for (int j = 0; j < BCH; ++j) {
-      const int c = tid + NTB * j, n = bn0 + (c >> 2);
-      if (c < 256 * WN) q[j] = *reinterpret_cast<const u32x4*>(Wb + (size_t)(n < Nc ? n : Nc - 1) * Kp + k0 + (c & 3) * 8);
-    }
+    for (int j = 0; j < BCH; ++j) q[j] = *reinterpret_cast<const u32x4*>(bsrc[j] + k0);
   };
   auto stash = [&](int buf, int kt, const typename AOp::Raw& ra, const u32x4* rb) {
     float v[8];
@@ -440,43 +445,68 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
       if (c < 256 * WN) *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + (c >> 2)) * LP + (c & 3) * 8) = rb[j];
     }
   };
-#pragma unroll
-  for (int d = 0; d < DA; ++d)
-    if (d < nk) aop.load(qa[d], row, d * BK + kq);
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-    if (d < nk) loadB(qb[d], d * BK);
+  const int fk = (lane >> 5) * 8, fr = lane & 31;
   f32x16 acc[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  auto mma = [&](int cur) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((size_t)cur * BM + wm * 32 + fr) * LP + ks * 16 + fk);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((size_t)cur * BNW + wn * 32 * WN + j * 32 + fr) * LP + ks * 16 + fk);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  };
+  // prologue: tiles 0 .. DA-1 (A) / 0 .. DB-1 (B) requested; tile 0 transformed into LDS buffer 0
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+    if (d < nk) loadB(qb[d], d * BK);
+#pragma unroll
+  for (int d = 0; d < DA; ++d)
+    if (d < nk) aop.load(qa[d], row, d * BK + kq);
   __syncthreads();  // constants staged
   stash(0, 0, qa[0], qb[0]);
-  if (DA < nk) aop.load(qa[0], row, DA * BK + kq);
   if (DB < nk) loadB(qb[0], DB * BK);
+  if (DA < nk) aop.load(qa[0], row, DA * BK + kq);
   __syncthreads();
-  const int fk = (lane >> 5) * 8, fr = lane & 31;
-  for (int kt0 = 0; kt0 < nk; kt0 += UN) {
+  // Queue slots are compile-time (tile t lives in slot t % DEPTH), so the loop is unrolled by UN = lcm(DA, DB).
+  // MAIN phase: whole groups of UN iterations in which every tile index touched is valid - no branch between a load and its
+  // use, hence the compiler waits with vmcnt(#younger loads) and DEPTH-1 tiles really stay in flight (with a conditional load
+  // anywhere in the loop it falls back to vmcnt(0): one exposed Infinity-Cache / HBM round trip per k-tile).  Within an
+  // iteration the B tile (weights, L2) is requested BEFORE the A tile: the counter is in-order, and the next iteration's wait
+  // for that B tile must not also drain the deep A request behind it.
+  const int main_end = nk - 1 - DA > 0 ? ((nk - 1 - DA) / UN) * UN : 0;
+  int kt0 = 0;
+  for (; kt0 < main_end; kt0 += UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int kt = kt0 + u, cur = u & 1;  // kt0 is even
+      const int sa = (u + 1) % DA, sb = (u + 1) % DB;
+      mma(cur);
+      stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
+      loadB(qb[sb], (kt + 1 + DB) * BK);
+      aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
+      __syncthreads();
+    }
+  }
+  // TAIL phase (at most UN + DA + 1 iterations; for the production shapes it requests nothing new): guarded
+  for (; kt0 < nk; kt0 += UN) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int kt = kt0 + u;
       if (kt < nk) {
         const int cur = kt & 1;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((size_t)cur * BM + wm * 32 + fr) * LP + ks * 16 + fk);
-#pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((size_t)cur * BNW + wn * 32 * WN + j * 32 + fr) * LP + ks * 16 + fk);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-          }
-        }
-        if (kt + 1 < nk) {  // tile kt+1 landed DEPTH-1 iterations ago: transform it, then reuse its slot for tile kt+1+DEPTH
-          const int sa = (u + 1) % DA, sb = (u + 1) % DB;
+        const int sa = (u + 1) % DA, sb = (u + 1) % DB;
+        mma(cur);
+        if (kt + 1 < nk) {
           stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
-          if (kt + 1 + DA < nk) aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
           if (kt + 1 + DB < nk) loadB(qb[sb], (kt + 1 + DB) * BK);
+          if (kt + 1 + DA < nk) aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
         }
         __syncthreads();
       }
