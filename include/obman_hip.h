@@ -124,7 +124,7 @@ int obman_contact_bwd(const float* hand, const float* obj, const int* idx21, con
 /* ---- K6: AtlasNet PointGenCon decoder (fp32 MFMA; optional bf16 MFMA) ---------------------------------------------------
  * Replaces atlasbranch.py:117-132 (grid/feature repeat + concat) + PointGenCon.forward (atlasutils.py:65-75):
  * 4 pointwise convs C1 -> C1 -> C1/2 -> C1/4 -> 3 with BatchNorm1d + ReLU after the first three, x out_factor.
- * C1 = 3 + feature size (515).  grid [N,3] is the shared sphere template, feat [B,C1-3]; weights are the conv
+ * C1 = 3 + feature size (515).  grid [N,3] is the shared sphere template (or [B,N,3], see grid_per_sample), feat [B,C1-3]; weights are the conv
  * weights [Cout,Cin] (kernel size 1 squeezed), BN gamma/beta/running stats per layer.  training != 0: batch
  * statistics (running stats updated in place with `momentum`); else running statistics.  out [B,N,3].
  * ws: obman_pointgen_ws_floats(p, 0) floats, written by fwd and read by bwd; ws2: ..._ws_floats(p, 1) scratch. */
@@ -133,6 +133,10 @@ typedef struct {
   float eps, momentum, out_factor;
   int mfma_bf16; /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32
                     accumulation and fp32 BatchNorm statistics (BASELINE configs[2] flavour) */
+  int grid_per_sample; /* 0: grid [N,3] shared by the batch (AtlasBranch.forward_inference, atlasbranch.py:110-150);
+                          1: grid [B,N,3], one point set per sample (AtlasBranch.forward's random sphere samples,
+                          atlasbranch.py:78-108); fp32 contraction only */
+  int reserved_;
   const float *grid, *feat;
   const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
   const float* bn_w[3];

@@ -9,7 +9,7 @@ import os
 from .build import LIB
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); 'p' pointer, 'i' int, 'l' long, 'f' float
 _SIGNATURES = {
@@ -53,6 +53,7 @@ _fp = ctypes.c_void_p
 class PointGenParams(ctypes.Structure):  # obman_pointgen_params
     _fields_ = [("B", _c_int), ("N", _c_int), ("C1", _c_int), ("training", _c_int),
                 ("eps", _c_float), ("momentum", _c_float), ("out_factor", _c_float), ("mfma_bf16", _c_int),
+                ("grid_per_sample", _c_int), ("reserved_", _c_int),
                 ("grid", _fp), ("feat", _fp),
                 ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("w4", _fp), ("b4", _fp),
                 ("bn_w", _fp * 3), ("bn_b", _fp * 3), ("bn_rm", _fp * 3), ("bn_rv", _fp * 3)]

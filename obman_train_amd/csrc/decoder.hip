@@ -42,6 +42,7 @@ __device__ __forceinline__ void split_row(int r, int N, int bhint, int& b, int& 
 struct AGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k]),  r = b*N + n  (Gx, Fx are x-hat factors)
   const float *Gx, *Fx, *gamma, *beta;
   int N, ld, R, K;
+  int ps;  // per-sample grid: Gx is [R,ld], indexed by the row instead of the template vertex
   struct Row { int g, f; bool ok; };
   struct KC { float ga, be; bool ok; };
   struct Raw { float a, b; };
@@ -49,7 +50,7 @@ struct AGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k]),
     const bool ok = r < R;
     int b, n;
     split_row(ok ? r : R - 1, N, ok ? bhint : (R - 1) / N, b, n);
-    return Row{n * ld, b * ld, ok};
+    return Row{(ps ? (ok ? r : R - 1) : n) * ld, b * ld, ok};
   }
   __device__ KC kc(int k) const { const bool ok = k < K; const int c = ok ? k : 0; return KC{gamma[c], beta[c], ok}; }
   __device__ Raw raw(const Row& w, int k) const { const int c = k < K ? k : 0; return Raw{Gx[w.g + c], Fx[w.f + c]}; }
@@ -167,6 +168,7 @@ struct EpiMaskStats {  // C = acc * (y > 0); per row-block column sums S1 = sum(
   const float *H, *s, *t, *mean, *rstd;   // mode 0 (ld = ldc)
   const float *Gx, *Fx, *gamma, *beta;    // mode 1 (ld = ldc)
   int N;
+  int ps;        // mode 1 with a per-sample grid: Gx indexed by the row
 };
 
 template <class A> __device__ __forceinline__ int rows_N(const A&) { return 1 << 30; }
@@ -335,56 +337,6 @@ struct EpiStoreImpl : EpiStore {
       }
     }
   }
-  // bf16 kernel: a wave owns 32 rows x WN column tiles (c0 + 32 j); four M-waves per block, summed in wave order.
-  // Row addresses are formed once per accumulator row and shared by the WN tiles.
-  template <int WN>
-  __device__ __forceinline__ void finish_wide(const f32x16 (&acc)[WN], int r0, int c0, int lane, int wm, int wn, char* smem) const {
-    const int cl = c0 + (lane & 31);
-    float bv[WN];
-    double s1[WN], s2[WN];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) { bv[j] = (bias && cl + 32 * j < Nc) ? bias[cl + 32 * j] : 0.f; s1[j] = 0.0; s2[j] = 0.0; }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = r0 + acc_row(reg, lane);
-      if (r < R) {
-        float* crow = C + (size_t)r * ldc + cl;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          if (cl + 32 * j < Nc) {
-            const float v = acc[j][reg] + bv[j];
-            crow[32 * j] = v;
-            s1[j] += (double)v;
-            s2[j] += (double)v * (double)v;
-          }
-        }
-      }
-    }
-    if (moments) {
-      double* red = reinterpret_cast<double*>(smem);  // [3 waves][2 wn][WN][32 lanes][2]
-#pragma unroll
-      for (int j = 0; j < WN; ++j) { s1[j] += __shfl_xor(s1[j], 32, 64); s2[j] += __shfl_xor(s2[j], 32, 64); }
-      __syncthreads();
-      if (wm > 0 && lane < 32) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) { double* q = red + (((((wm - 1) * 2 + wn) * WN + j) * 32) + lane) * 2; q[0] = s1[j]; q[1] = s2[j]; }
-      }
-      __syncthreads();
-      if (wm == 0 && lane < 32) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          if (cl + 32 * j < Nc) {
-            double a = s1[j], b = s2[j];
-#pragma unroll
-            for (int w = 0; w < 3; ++w) { const double* q = red + ((((w * 2 + wn) * WN + j) * 32) + lane) * 2; a += q[0]; b += q[1]; }
-            double* dst = moments + ((size_t)blockIdx.x * Nc + cl + 32 * j) * 2;
-            dst[0] = a;
-            dst[1] = b;
-          }
-        }
-      }
-    }
-  }
 };
 
 struct EpiMaskStatsImpl : EpiMaskStats {
@@ -412,7 +364,7 @@ struct EpiMaskStatsImpl : EpiMaskStats {
           y = __fmaf_rn(c_s, h, c_t);
           xh = (h - c_m) * c_r;
         } else {
-          xh = Gx[(size_t)nn * ldc + col] + Fx[(size_t)bb * ldc + col];
+          xh = Gx[(size_t)(ps ? r : nn) * ldc + col] + Fx[(size_t)bb * ldc + col];
           y = __fmaf_rn(c_s, xh, c_t);
         }
         const float v = y > 0.f ? a[reg] : 0.f;
@@ -448,76 +400,6 @@ struct EpiMaskStatsImpl : EpiMaskStats {
       double* dst = sums + ((size_t)rblk * Nc + col) * 2;
       dst[0] = s1 + red[(wn * 32 + lane) * 2];
       dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
-    }
-  }
-  // bf16 kernel: a wave owns 32 rows x WN column tiles; row addresses and the (sample, vertex) split are formed once per
-  // accumulator row and shared by the WN tiles; one barrier pair for all tiles; four M-waves summed in wave order.
-  template <int WN>
-  __device__ __forceinline__ void finish_wide(const f32x16 (&acc)[WN], int r0, int c0, int lane, int wm, int wn, char* smem) const {
-    const int cl = c0 + (lane & 31);
-    Cst cst[WN];
-    float s1[WN], s2[WN];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) { cst[j] = consts(cl + 32 * j, cl + 32 * j < Nc); s1[j] = 0.f; s2[j] = 0.f; }
-    const int rb = r0 + 4 * (lane >> 5);
-    int b = 0, n = 0;
-    if (mode != 0) { b = rb / N; n = rb - b * N; }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int off = (reg & 3) + 8 * (reg >> 2);
-      const int r = rb + off;
-      int bb = b, nn = n + off;
-      if (mode != 0) while (nn >= N) { nn -= N; ++bb; }
-      if (r < R) {
-        const size_t ro = (size_t)r * ldc + cl;
-        float* crow = C + ro;
-        const float* p0 = mode == 0 ? H + ro : Gx + (size_t)nn * ldc + cl;
-        const float* p1 = mode == 0 ? p0 : Fx + (size_t)bb * ldc + cl;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          if (cl + 32 * j < Nc) {
-            float xh, y;
-            if (mode == 0) {
-              const float h = p0[32 * j];
-              y = __fmaf_rn(cst[j].s, h, cst[j].t);
-              xh = (h - cst[j].m) * cst[j].r;
-            } else {
-              xh = p0[32 * j] + p1[32 * j];
-              y = __fmaf_rn(cst[j].s, xh, cst[j].t);
-            }
-            const float v = y > 0.f ? acc[j][reg] : 0.f;
-            crow[32 * j] = v;
-            s1[j] += v;
-            s2[j] = __fmaf_rn(v, xh, s2[j]);
-          }
-        }
-      }
-    }
-    double d1[WN], d2[WN];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      d1[j] = (double)s1[j]; d2[j] = (double)s2[j];
-      d1[j] += __shfl_xor(d1[j], 32, 64); d2[j] += __shfl_xor(d2[j], 32, 64);
-    }
-    double* red = reinterpret_cast<double*>(smem);  // [3 waves][2 wn][WN][32 lanes][2]
-    __syncthreads();
-    if (wm > 0 && lane < 32) {
-#pragma unroll
-      for (int j = 0; j < WN; ++j) { double* q = red + (((((wm - 1) * 2 + wn) * WN + j) * 32) + lane) * 2; q[0] = d1[j]; q[1] = d2[j]; }
-    }
-    __syncthreads();
-    if (wm == 0 && lane < 32) {
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        if (cl + 32 * j < Nc) {
-          double a = d1[j], bsum = d2[j];
-#pragma unroll
-          for (int w = 0; w < 3; ++w) { const double* q = red + ((((w * 2 + wn) * WN + j) * 32) + lane) * 2; a += q[0]; bsum += q[1]; }
-          double* dst = sums + ((size_t)blockIdx.x * Nc + cl + 32 * j) * 2;
-          dst[0] = a;
-          dst[1] = bsum;
-        }
-      }
     }
   }
 };
@@ -1167,15 +1049,24 @@ FwdWs fwd_ws(const Dims& d) {
   w.total = o;
   return w;
 }
-// rows per split-K chunk: enough chunks that tiles x chunks covers the chip ~4x, never below 128 rows
+// rows per split-K chunk.  fp32 kernel (256-thread blocks, 3 per CU): tiles x chunks covers the chip ~4x, chunk count a
+// multiple of 8 (whole chunks are dealt to the 8 XCDs), never below 128 rows.  bf16 kernel (512-thread blocks, ONE per CU,
+// 64-row k-tiles): tiles x chunks <= 512 = two full rounds of the 256 CUs - a grid of 528 blocks would run three.
 int tn_chunk_rows(int M, int Nc, long R, int bn = BN) {
   const long tiles = (long)((M + BM - 1) / BM) * ((Nc + bn - 1) / bn);
-  const long blocks = bn > BN ? 512 : 1024;               // wide (bf16) tiles: a block is 5x the work and writes 5x the partial
-  long want = (blocks + tiles - 1) / tiles;               // chunks wanted ...
-  want = (want + 7) / 8 * 8;                              // ... a multiple of 8: whole chunks are dealt to the 8 XCDs
-  long rows = (R + want - 1) / want;
-  if (rows < 128) rows = 128;
-  if (bn > BN) rows = (rows + BKT - 1) / BKT * BKT;      // whole 64-row k-tiles of the bf16 kernel
+  long rows;
+  if (bn > BN) {
+    long want = 512 / tiles;
+    if (want < 1) want = 1;
+    rows = (R + want - 1) / want;
+    rows = (rows + BKT - 1) / BKT * BKT;  // whole 64-row k-tiles
+    if (rows < 2 * BKT) rows = 2 * BKT;
+  } else {
+    long want = (1024 + tiles - 1) / tiles;
+    want = (want + 7) / 8 * 8;
+    rows = (R + want - 1) / want;
+    if (rows < 128) rows = 128;
+  }
   return (int)rows;
 }
 // l1_reduce geometry: vertex sub-tiles per block such that tiles x sample-groups x channel-tiles ~ 1024 blocks

@@ -55,7 +55,7 @@ def test_decoder_full_size(subdiv, flavour):
     else:
         want_bf, _, _ = _oracle(dec, feats, grid, True, mfma_round=lambda t: t.bfloat16().float())
         scale = want_bf.abs().max().item()
-        assert (got.detach().cpu() - want_bf.detach()).abs().max().item() <= 4e-3 * scale
+        assert (got.detach().cpu() - want_bf.detach()).abs().max().item() <= 1e-2 * scale
         tol = 8e-2
     worst = {"features": _rel_l2(f_g.grad, f_o.grad)}
     for name, prm in dec_g.named_parameters():
