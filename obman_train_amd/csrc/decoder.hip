@@ -607,6 +607,161 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1,
   }
 }
 
+constexpr int L1PS_ROWS = 128;  // rows per block of the per-sample-grid layer-1 backward
+
+// Layer 1 for a PER-SAMPLE grid (AtlasBranch.forward, atlasbranch.py:78-108: every sample gets its own points on the sphere).
+// h1[b,n,c] = G[b,n,c] + F[b,c] with G = W1[c,0:3].grid[b,n]: the two-factor form survives (Gx is just [R,ld] now, indexed
+// by the row), but the batch statistics are no longer additive - the per-sample means of G correlate with F:
+//   E[h] = mean_r G + mean_b F,   E[h^2] = (sum_r G^2 + 2 sum_b F_b sum_n G_bn + N sum_b F_b^2) / R.
+// One block = PREP_COLS channels; one wave per channel walks the rows sample by sample (fp64 sums, fixed order).
+__global__ __launch_bounds__(256) void prep_ps_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                                      const float* __restrict__ grid, const float* __restrict__ feat, int B, int N,
+                                                      int C1, int ld1, int training, float eps, float momentum,
+                                                      float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ Gx,
+                                                      float* __restrict__ Fx, float* __restrict__ mean1, float* __restrict__ rstd1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Cf = C1 - 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sW = reinterpret_cast<float*>(smem);          // [PREP_COLS][C1]
+  float* sF = sW + PREP_COLS * C1;                      // [PREP_COLS][B]
+  float* sStat = sF + PREP_COLS * B;                    // [PREP_COLS][4]: gm, fm, rstd
+  const int c0 = blockIdx.x * PREP_COLS;
+  const long R = (long)B * N;
+  for (int i = tid; i < PREP_COLS * C1; i += 256) {
+    const int c = c0 + i / C1;
+    sW[i] = c < C1 ? W1[(size_t)c * C1 + i % C1] : 0.f;
+  }
+  __syncthreads();
+  auto Gval = [&](int j, long r) {
+    return sW[j * C1] * grid[r * 3] + sW[j * C1 + 1] * grid[r * 3 + 1] + sW[j * C1 + 2] * grid[r * 3 + 2];
+  };
+  for (int b = wave; b < B; b += 4) {  // F[b,c] = b1[c] + W1[c,3:].feat[b]: one wave per sample
+    float acc[PREP_COLS];
+#pragma unroll
+    for (int j = 0; j < PREP_COLS; ++j) acc[j] = 0.f;
+    for (int k = lane; k < Cf; k += 64) {
+      const float f = feat[(size_t)b * Cf + k];
+#pragma unroll
+      for (int j = 0; j < PREP_COLS; ++j) acc[j] = __fmaf_rn(f, sW[j * C1 + 3 + k], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < PREP_COLS; ++j) {
+      const float r = obman_wave_sum(acc[j]);
+      if (lane == 0) sF[j * B + b] = r + ((c0 + j < C1) ? b1[c0 + j] : 0.f);
+    }
+  }
+  __syncthreads();
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  for (int j = wave; j < PREP_COLS; j += 4) {
+    const int c = c0 + j;
+    double sg = 0, sgg = 0, cross = 0, sf = 0, sff = 0;
+    for (int b = 0; b < B; ++b) {
+      double g1 = 0, g2 = 0;
+      for (int n = lane; n < N; n += 64) { const double v = Gval(j, (long)b * N + n); g1 += v; g2 += v * v; }
+      g1 = wsum(g1); g2 = wsum(g2);
+      const double f = sF[j * B + b];
+      sg += g1; sgg += g2; cross += f * g1; sf += f; sff += f * f;
+    }
+    if (lane == 0 && c < C1) {
+      float gm, fm, var;
+      if (training) {
+        const double mg = sg / (double)R, mf = sf / B;
+        const double mean = mg + mf;
+        double v = (sgg + 2.0 * cross + (double)N * sff) / (double)R - mean * mean;
+        if (v < 0) v = 0;
+        gm = (float)mg; fm = (float)mf; var = (float)v;
+        if (rmean) {
+          rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+          rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(v * ((double)R / (R > 1 ? R - 1 : 1)));
+        }
+      } else {
+        gm = rmean[c]; fm = 0.f; var = rvar[c];
+      }
+      const float rs = 1.f / sqrtf(var + eps);
+      sStat[j * 4] = gm; sStat[j * 4 + 1] = fm; sStat[j * 4 + 2] = rs;
+      mean1[c] = gm + fm;
+      rstd1[c] = rs;
+    }
+  }
+  __syncthreads();
+  for (long i = tid; i < (long)PREP_COLS * R; i += 256) {
+    const long r = i / PREP_COLS;
+    const int j = (int)(i % PREP_COLS);
+    if (c0 + j < C1) Gx[(size_t)r * ld1 + c0 + j] = (Gval(j, r) - sStat[j * 4]) * sStat[j * 4 + 2];
+  }
+  for (int i = tid; i < PREP_COLS * B; i += 256) {
+    const int b = i / PREP_COLS, j = i % PREP_COLS;
+    if (c0 + j < C1) Fx[(size_t)b * ld1 + c0 + j] = (sF[j * B + b] - sStat[j * 4 + 1]) * sStat[j * 4 + 2];
+  }
+}
+
+// Per-sample-grid layer-1 backward, pass over gy1 [R,ld1] and Gx [R,ld1]: thread = channel, block = L1PS_ROWS rows of one
+// sample.  gh1 = ca*gy1 + cb*xhat1 + cc (coefficients from l1ps_coef_kernel);  PdF[b][chunk][c] = sum_n gh1,
+// Pw[b][chunk][j][c] = sum_n gh1 * grid[b,n,j].
+__global__ __launch_bounds__(256) void l1ps_reduce_kernel(const float* __restrict__ GY1, const float* __restrict__ Gx,
+                                                          const float* __restrict__ Fx, const float* __restrict__ grid,
+                                                          const float* __restrict__ ca, const float* __restrict__ cb,
+                                                          const float* __restrict__ cc, int ld1, int N, int C1, int chunks,
+                                                          float* __restrict__ PdF, float* __restrict__ Pw) {
+  const int c = blockIdx.z * 256 + threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
+  if (c >= C1) return;
+  const int n0 = chunk * L1PS_ROWS, n1 = min(N, n0 + L1PS_ROWS);
+  const float a_ = ca[c], b_ = cb[c], c_ = cc[c], fx = Fx[(size_t)b * ld1 + c];
+  float d = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const size_t r = (size_t)b * N + n;
+    const float gh = __fmaf_rn(a_, GY1[r * ld1 + c], __fmaf_rn(b_, Gx[r * ld1 + c] + fx, c_));
+    d += gh;
+    w0 = __fmaf_rn(gh, grid[r * 3], w0); w1 = __fmaf_rn(gh, grid[r * 3 + 1], w1); w2 = __fmaf_rn(gh, grid[r * 3 + 2], w2);
+  }
+  const size_t slot = (size_t)b * chunks + chunk;
+  PdF[slot * ld1 + c] = d;
+  Pw[(slot * 3 + 0) * ld1 + c] = w0; Pw[(slot * 3 + 1) * ld1 + c] = w1; Pw[(slot * 3 + 2) * ld1 + c] = w2;
+}
+// sums [blocks][C1][2] (S1 = sum gy1, S2 = sum gy1*xhat1) -> g_gamma1 = S2, g_beta1 = S1 and the coefficients of
+// gh1 = k1*(gy1 - S1/R - xhat1*S2/R) = ca*gy1 + cb*xhat1 + cc  (eval: ca = k1, cb = cc = 0).  One wave per channel.
+__global__ __launch_bounds__(256) void l1ps_coef_kernel(const double* __restrict__ sums, int blocks, long R, int C, int training,
+                                                        const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                        float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                        float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = lane; b < blocks; b += 64) { s1 += sums[((size_t)b * C + c) * 2]; s2 += sums[((size_t)b * C + c) * 2 + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+  if (lane != 0) return;
+  g_gamma[c] = (float)s2;
+  g_beta[c] = (float)s1;
+  const float k1 = gamma[c] * rstd[c];
+  ca[c] = k1;
+  cb[c] = training ? (float)(-(double)k1 * s2 / (double)R) : 0.f;
+  cc[c] = training ? (float)(-(double)k1 * s1 / (double)R) : 0.f;
+}
+// dF[b,c] = sum_chunk PdF, g_b1[c] = sum_b dF[b,c], gW1[c, 0:3] = sum_{b,chunk} Pw   (fixed order).  Thread = channel.
+__global__ __launch_bounds__(256) void l1ps_finalize_kernel(const float* __restrict__ PdF, const float* __restrict__ Pw, int ld1, int B,
+                                                            int C1, int chunks, float* __restrict__ dF, float* __restrict__ g_b1,
+                                                            float* __restrict__ gW1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C1) return;
+  float gb = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float d = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+      const size_t slot = (size_t)b * chunks + k;
+      d += PdF[slot * ld1 + c];
+      w0 += Pw[(slot * 3 + 0) * ld1 + c]; w1 += Pw[(slot * 3 + 1) * ld1 + c]; w2 += Pw[(slot * 3 + 2) * ld1 + c];
+    }
+    dF[(size_t)b * ld1 + c] = d;
+    gb += d;
+  }
+  g_b1[c] = gb;
+  gW1[(size_t)c * C1] = w0; gW1[(size_t)c * C1 + 1] = w1; gW1[(size_t)c * C1 + 2] = w2;
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -1015,6 +1170,7 @@ using namespace dec;
 struct Dims {
   int B, N, C1, C2, C3, ld1, ld2, ld3, rb;  // rb = row blocks of the rows-GEMMs
   int bf16;                                 // contraction on the bf16 matrix pipe (operands rounded to bf16, fp32 accumulate)
+  int ps;                                   // per-sample grid [B,N,3] (AtlasBranch.forward): Gx is [R,ld1]
   long R;
 };
 inline int kpad(int K) { return (K + BK - 1) / BK * BK; }       // k extent of a bf16 weight image (zero padded)
@@ -1026,6 +1182,7 @@ Dims dims_of(const obman_pointgen_params* p) {
   d.R = (long)d.B * d.N;
   d.rb = (int)((d.R + BM - 1) / BM);
   d.bf16 = p->mfma_bf16 ? 1 : 0;
+  d.ps = p->grid_per_sample ? 1 : 0;
   return d;
 }
 constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 blocks at 64 x 642 points)
@@ -1038,7 +1195,7 @@ struct FwdWs {
 FwdWs fwd_ws(const Dims& d) {
   FwdWs w; long o = 0;
   auto take = [&](long n) { long at = o; o += (n + 15) / 16 * 16; return at; };
-  w.Gx = take((long)d.N * d.ld1); w.Fx = take((long)d.B * d.ld1); w.mean1 = take(d.ld1); w.rstd1 = take(d.ld1);
+  w.Gx = take((d.ps ? d.R : (long)d.N) * d.ld1); w.Fx = take((long)d.B * d.ld1); w.mean1 = take(d.ld1); w.rstd1 = take(d.ld1);
   const int act = d.bf16 ? 2 : 1;  // bf16 flavour: activations stored as bf16 (two per float slot)
   w.H2 = take(d.R * d.ld2 / act); w.mean2 = take(d.ld2); w.rstd2 = take(d.ld2); w.s2 = take(d.ld2); w.t2 = take(d.ld2);
   w.H3 = take(d.R * d.ld3 / act); w.mean3 = take(d.ld3); w.rstd3 = take(d.ld3); w.s3 = take(d.ld3); w.t3 = take(d.ld3);
@@ -1102,7 +1259,10 @@ BwdWs bwd_ws(const Dims& d) {
   w.l4p = take((long)l4b * (3 * d.C3 + 4));
   w.l4red = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * (3 * d.C3 + 4) : 0);
   w.P = take((long)d.B * d.ld1); w.Q = take((long)d.N * d.ld1); w.dF = take((long)d.B * d.ld1); w.dG = take((long)d.N * d.ld1);
-  {
+  if (d.ps) {  // per-sample grid: partial dF / gW1[:, 0:3] per (sample, chunk of L1PS_ROWS rows)
+    const long ch = (d.N + L1PS_ROWS - 1) / L1PS_ROWS;
+    w.Pp = take((long)d.B * ch * d.ld1); w.Qp = take((long)d.B * ch * 3 * d.ld1);
+  } else {
     const L1Geo g = l1_geo(d);
     w.Pp = take((long)g.tiles * d.B * d.ld1); w.Qp = take((long)g.groups * d.N * d.ld1);
   }
@@ -1321,7 +1481,8 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
 }
 
 bool params_ok(const obman_pointgen_params* p) {
-  return p && p->B > 0 && p->N > 0 && p->C1 >= 8 && p->C1 / 4 <= 128 && p->grid && p->feat && p->w1 && p->w2 && p->w3 && p->w4;
+  return p && p->B > 0 && p->N > 0 && p->C1 >= 8 && p->C1 / 4 <= 128 && p->grid && p->feat && p->w1 && p->w2 && p->w3 && p->w4 &&
+         !(p->grid_per_sample && p->mfma_bf16);  // the random-sphere path is exact fp32 only
 }
 
 }  // namespace
@@ -1343,15 +1504,20 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
   ObmanProfScope prof(OBMAN_K_DECODER_FWD, st);
   {
     const size_t sm = sizeof(float) * ((size_t)PREP_COLS * (d.C1 + d.B) + PREP_COLS * 4);
-    prep_kernel<<<obman_cdiv(d.C1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
-                                                               p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
-                                                               ws + w.mean1, ws + w.rstd1);
+    if (d.ps)
+      prep_ps_kernel<<<obman_cdiv(d.C1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
+                                                                    p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
+                                                                    ws + w.mean1, ws + w.rstd1);
+    else
+      prep_kernel<<<obman_cdiv(d.C1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
+                                                                 p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
+                                                                 ws + w.mean1, ws + w.rstd1);
     OBMAN_LAUNCH_CHECK();
   }
   if (d.bf16) return forward_bf16(p, d, w, out, ws, st);
   double* moments = reinterpret_cast<double*>(ws + w.moments);
   {  // h2 = W2 relu(bn1(h1)) + b2
-    AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1};
+    AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1, d.ps};
     EpiStoreImpl e;
     e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
     int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
@@ -1425,7 +1591,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
       e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
-      e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N;
+      e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N; e.ps = 0;
       if ((rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st))) return rc;
     }
     sp = sums;
@@ -1435,15 +1601,29 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
                                                                    g->bn_b[1], g->b2, k1, k2, k3);
     OBMAN_LAUNCH_CHECK();
     AGradH gh2{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, R, d.C2};
-    AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1};
+    AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1, d.ps};
     if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;  // gW2[o,c]
     {  // gy1 = (gh2 W2) * (y1 > 0)
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
       e.H = e.s = e.t = e.mean = e.rstd = nullptr;
-      e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N;
+      e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N; e.ps = d.ps;
       if ((rc = launch_rows<AGradH, false, EpiMaskStatsImpl>(gh2, p->w2, d.C1, d.C2, d.C1, d.R, e, st))) return rc;
     }
+    if (d.ps) {  // per-sample grid: BN-1 backward coefficients from the epilogue's sums, then one pass over gy1 and Gx
+      sp = sums;
+      srows = d.rb;
+      if ((rc = pre_reduce<double>(sp, srows, d.C1 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
+      l1ps_coef_kernel<<<obman_cdiv(d.C1, 4), 256, 0, st>>>(sp, srows, d.R, d.C1, tr, p->bn_w[0], ws + w.rstd1, g->bn_w[0], g->bn_b[0], k1, k2,
+                                                             k3);
+      OBMAN_LAUNCH_CHECK();
+      const int ch = obman_cdiv(d.N, L1PS_ROWS);
+      l1ps_reduce_kernel<<<dim3(ch, d.B, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, ws + w.Gx, ws + w.Fx, p->grid, k1, k2, k3, d.ld1,
+                                                                                 d.N, d.C1, ch, ws2 + v.Pp, ws2 + v.Qp);
+      OBMAN_LAUNCH_CHECK();
+      l1ps_finalize_kernel<<<obman_cdiv(d.C1, 256), 256, 0, st>>>(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.C1, ch, ws2 + v.dF, g->b1, g->w1);
+      OBMAN_LAUNCH_CHECK();
+    } else {
     // ---- layer 1 in factored form: P[b,c] = sum_n gy1, Q[n,c] = sum_b gy1 from one read of gy1
     const L1Geo lg = l1_geo(d);
     l1_reduce_kernel<<<dim3(lg.tiles, lg.groups, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, lg.S, ws2 + v.Pp,
@@ -1452,8 +1632,11 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, lg.tiles, lg.groups,
                                                                                 ws2 + v.P, ws2 + v.Q);
     OBMAN_LAUNCH_CHECK();
+    }
   }
-  if (d.N > L1_SPLIT_N) {
+  if (d.ps) {
+    // dF, g_b1, gW1[:, 0:3], g_gamma1, g_beta1 are done (l1ps_* kernels above)
+  } else if (d.N > L1_SPLIT_N) {
     const int nseg = obman_cdiv(d.N, L1_SEG_ROWS);
     double* seg = reinterpret_cast<double*>(ws2 + v.seg);
     const dim3 grid(obman_cdiv(d.C1, 64), nseg);

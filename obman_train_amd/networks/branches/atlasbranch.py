@@ -68,14 +68,16 @@ class AtlasBranch(nn.Module):
             res["objscale"] = scale
         return res
 
-    def forward(self, img_features):
-        """Random points on the unit sphere (atlasbranch.py:78-108); non-deterministic by construction."""
+    def forward(self, img_features, rand_grid=None):
+        """Random points on the unit sphere (atlasbranch.py:78-108), one set per sample, through the fused decoder
+        (``obman_pointgen_fwd/bwd`` with ``grid_per_sample``): the [B,3+C,points_nb] concat is not built here either.
+        ``rand_grid`` (test hook): the normal draws [B,3,points_nb] the reference would make, to compare like with like."""
         trans = self.decode_trans(img_features) if self.predict_trans else None
         B = img_features.shape[0]
-        grid = torch.randn((B, self.points_nb, 3), device=img_features.device, dtype=img_features.dtype)
-        grid = grid / grid.norm(dim=2, keepdim=True)
-        x = torch.cat((grid.transpose(2, 1), img_features.unsqueeze(2).expand(-1, -1, self.points_nb)), 1)
-        verts = self.decoder(x).transpose(2, 1)
+        if rand_grid is None:
+            rand_grid = torch.randn((B, 3, self.points_nb), device=img_features.device, dtype=img_features.dtype)
+        rand_grid = rand_grid / torch.sqrt(torch.sum(rand_grid ** 2, dim=1, keepdim=True))
+        verts = self.decoder.decode(img_features, rand_grid.transpose(2, 1).contiguous())
         return self._assemble(verts, trans, None, with_faces=False)
 
     def forward_inference(self, img_features, separate_encoder_features=None):

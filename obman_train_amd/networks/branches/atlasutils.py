@@ -54,6 +54,6 @@ class PointGenCon(nn.Module):
         return self._tail(torch_f.relu(self.bn1(self.conv1(x))))
 
     def decode(self, features, grid):
-        """features [B,C-3], grid [N,3] (shared template) -> points [B,N,3] (already transposed):
-        one call into the fused fp32-MFMA decoder (``csrc/decoder.hip``), forward and backward."""
+        """features [B,C-3], grid [N,3] (shared template) or [B,N,3] (one point set per sample) -> points [B,N,3] (already
+        transposed): one call into the fused fp32-MFMA decoder (``csrc/decoder.hip``), forward and backward."""
         return ops.pointgen_decode(self, features, grid)

@@ -283,7 +283,8 @@ def _pointgen_params(feat, grid, tensors, running, cfg):
     p = _lib.PointGenParams()
     p.B, p.N, p.C1, p.training = feat.shape[0], grid.shape[-2], tensors[0].shape[0], int(training)
     p.eps, p.momentum, p.out_factor = float(eps), float(momentum), float(out_factor)
-    p.mfma_bf16 = int(bool(mfma_bf16))
+    p.grid_per_sample = int(grid.dim() == 3)
+    p.mfma_bf16 = int(bool(mfma_bf16) and grid.dim() == 2)  # the per-sample-grid path is exact fp32 only
     p.grid, p.feat = grid.data_ptr(), feat.data_ptr()
     for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4"), tensors[:8]):
         setattr(p, name, t.data_ptr())
@@ -302,9 +303,10 @@ class _PointGen(torch.autograd.Function):
     def forward(ctx, feat, grid, w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3, running, cfg):
         feat, grid = _dev(feat, "features"), _dev(grid, "grid")
         tensors = [_dev(t, "decoder parameter") for t in (w1, b1, w2, b2, w3, b3, w4, b4, g1, be1, g2, be2, g3, be3)]
-        B, N, C1 = feat.shape[0], grid.shape[0], w1.shape[0]
-        if feat.shape[1] != C1 - 3 or grid.shape[1] != 3:
-            raise ValueError("features must be [B,%d] and grid [N,3]" % (C1 - 3))
+        B, N, C1 = feat.shape[0], grid.shape[-2], w1.shape[0]
+        if feat.dim() != 2 or feat.shape[1] != C1 - 3 or grid.shape[-1] != 3 or grid.dim() not in (2, 3) or (
+                grid.dim() == 3 and grid.shape[0] != B):
+            raise ValueError("features must be [B,%d] and grid [N,3] (shared template) or [B,N,3] (one point set per sample)" % (C1 - 3))
         p = _pointgen_params(feat, grid, tensors, running, cfg)
         lib = _lib.lib()
         n_ws = lib.obman_pointgen_ws_floats(_ct.addressof(p), 0)
@@ -344,6 +346,8 @@ class _PointGen(torch.autograd.Function):
 
 def pointgen_decode(decoder, features, grid, mfma_dtype=None):
     """decoder: PointGenCon-like module (conv1..4, bn1..3, out_factor); features [B,C], grid [N,3] -> [B,N,3].
+    ``grid`` may also be [B,N,3] - one point set per sample, as ``AtlasBranch.forward`` draws them (atlasbranch.py:78-108);
+    that path always contracts in exact fp32.
 
     mfma_dtype (default: the module's ``mfma_dtype`` attribute, else "f32"): "f32" = exact fp32 MFMA contraction;
     "bf16" = GEMM operands rounded to bf16 on the fly (fp32 master weights, fp32 accumulation, fp32 BatchNorm

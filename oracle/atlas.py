@@ -66,6 +66,17 @@ def forward_inference(params, features, template_verts, faces, predict_trans=Fal
     return res
 
 
+def forward_random(params, features, rand_grid, predict_trans=False, training=True, out_factor=200.0):
+    """AtlasBranch.forward (atlasbranch.py:78-108) with the normal draws given: rand_grid [B,3,P] (un-normalised)."""
+    trans = _mlp2(params, "decode_trans.", features) if predict_trans else None
+    grid = rand_grid / torch.sqrt(torch.sum(rand_grid ** 2, dim=1, keepdim=True))
+    x = torch.cat((grid, features.unsqueeze(2).repeat(1, 1, grid.size(2))), 1)
+    verts = pointgen(params, x, training=training, out_factor=out_factor).transpose(2, 1)
+    if predict_trans:
+        return {"objpoints3d": verts + trans.unsqueeze(1), "objtrans": trans, "objpointscentered3d": verts}
+    return {"objpoints3d": verts}
+
+
 def edge_loss(verts, faces):
     """atlasbranch.py:153-167: mean |squared edge length - per-sample mean squared edge length|."""
     f = torch.as_tensor(faces).long()

@@ -95,9 +95,10 @@ def pointgen_decode(decoder, features, grid):
     """Reference formulation: materialise the [B,3+C,N] concat and run PointGenCon (oracle/atlas.py)."""
     from oracle import atlas as oatlas
 
-    B, N = features.shape[0], grid.shape[0]
+    B, N = features.shape[0], grid.shape[-2]
     params = {"decoder." + k: v for k, v in list(decoder.named_parameters()) + list(decoder.named_buffers())}
-    x = torch.cat((grid.t().unsqueeze(0).expand(B, -1, -1), features.unsqueeze(2).expand(-1, -1, N)), 1)
+    g3 = grid.transpose(2, 1) if grid.dim() == 3 else grid.t().unsqueeze(0).expand(B, -1, -1)
+    x = torch.cat((g3, features.unsqueeze(2).expand(-1, -1, N)), 1)
     out = oatlas.pointgen(params, x, training=decoder.training, out_factor=decoder.out_factor,
                           momentum=decoder.bn1.momentum, eps=decoder.bn1.eps).transpose(2, 1)
     if decoder.training:
