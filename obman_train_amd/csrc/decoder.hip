@@ -597,13 +597,15 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1,
     }
   }
   __syncthreads();
+  // columns C1 .. ld1-1 (the pitch padding, covered by the extra blocks of the grid) are written as zeros: the bf16 flavour's
+  // operand generators read whole 8-wide chunks and rely on finite padding
   for (int i = tid; i < PREP_COLS * N; i += 256) {
     const int n = i / PREP_COLS, j = i % PREP_COLS;  // consecutive lanes -> consecutive channels (32-byte segments)
-    if (c0 + j < C1) Gx[(size_t)n * ld1 + c0 + j] = (Gval(j, n) - sStat[j * 4]) * sStat[j * 4 + 2];
+    if (c0 + j < ld1) Gx[(size_t)n * ld1 + c0 + j] = c0 + j < C1 ? (Gval(j, n) - sStat[j * 4]) * sStat[j * 4 + 2] : 0.f;
   }
   for (int i = tid; i < PREP_COLS * B; i += 256) {
     const int b = i / PREP_COLS, j = i % PREP_COLS;
-    if (c0 + j < C1) Fx[(size_t)b * ld1 + c0 + j] = (sF[j * B + b] - sStat[j * 4 + 1]) * sStat[j * 4 + 2];
+    if (c0 + j < ld1) Fx[(size_t)b * ld1 + c0 + j] = c0 + j < C1 ? (sF[j * B + b] - sStat[j * 4 + 1]) * sStat[j * 4 + 2] : 0.f;
   }
 }
 
@@ -1313,20 +1315,28 @@ int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* o
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
-template <class AOp, class Epi, int WN>
-int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+template <class AOp, class Epi, int WN, bool STAGGER>
+int launch_rows_bf16_impl(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
   const int Kp = kpad(K);
   const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
   static int granted = 0;  // largest dynamic-LDS size already enabled for this instantiation
   if ((int)lds > granted) {
-    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN, STAGGER>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return (int)err;
     granted = (int)lds;
   }
   dim3 grid((unsigned)geo.blocks(), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
-  rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
+  rows_bf16_kernel<AOp, Epi, WN, STAGGER><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+template <class AOp, class Epi, int WN>
+int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+  // OBMAN_BF16_STAGGER=1: the two waves of a SIMD run the MFMA / transform phases of an iteration in opposite order (A/B knob)
+  static const int stagger = [] { const char* v = getenv("OBMAN_BF16_STAGGER"); return v ? atoi(v) : 0; }();
+  return stagger ? launch_rows_bf16_impl<AOp, Epi, WN, true>(a, Wb, K, Nc, geo, e, st)
+                 : launch_rows_bf16_impl<AOp, Epi, WN, false>(a, Wb, K, Nc, geo, e, st);
 }
 template <class AOp, class Epi>
 int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
@@ -1509,7 +1519,7 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
                                                                     p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
                                                                     ws + w.mean1, ws + w.rstd1);
     else
-      prep_kernel<<<obman_cdiv(d.C1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
+      prep_kernel<<<obman_cdiv(d.ld1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
                                                                  p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
                                                                  ws + w.mean1, ws + w.rstd1);
     OBMAN_LAUNCH_CHECK();

@@ -72,11 +72,12 @@ struct RowGeo {
       if (!ok) { b = 0; n = 0; }
       r = (long)b * N + n;
     } else {
-      const long rr = (long)blk * BM + i;
+      const int rr = blk * BM + i;  // R < 2^31 (obman_pointgen_* reject larger row counts)
       ok = rr < R;
-      r = ok ? rr : 0;
-      b = (int)(r / N);
-      n = (int)(r - (long)b * N);
+      const int rc = ok ? rr : 0;
+      r = rc;
+      b = rc / N;
+      n = rc - b * N;
     }
   }
   __host__ int blocks() const { return tiled ? NG * ((B + 7) / 8) : (int)(((long)R + BM - 1) / BM); }
@@ -85,7 +86,9 @@ struct RowGeo {
 // ------------------------------------------------------------------------------------------------ A operands (rows GEMM)
 // A thread of the rows kernel owns ONE row and one 8-wide k chunk per tile (16-byte accesses).  load() only issues loads;
 // fin() turns a landed chunk into 8 operand values using the per-channel constants staged in LDS (kcs = [NC][Kp]).  Columns
-// >= K and invalid rows yield exact zeros (select, not multiply: padding columns may hold anything).
+// >= K come out as exact zeros because their constants are staged as zeros and every padding column of a source array holds a
+// finite value (the producers write zeros there: EpiStoreB / EpiMaskB up to the pitch, prep_kernel for Gx / Fx); rows beyond
+// the end are zeroed once per chunk by the caller (Row::ok), not per element.
 struct BGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k])   (Gx, Fx: fp32 x-hat factors of layer 1)
   const float *Gx, *Fx, *gamma, *beta;
   int ld, K;
@@ -109,7 +112,7 @@ struct BGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k]) 
     const float ga[8] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w};
     const float be[8] = {be0.x, be0.y, be0.z, be0.w, be1.x, be1.y, be1.z, be1.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (w.ok && k + j < K) ? fmaxf(__fmaf_rn(ga[j], x[j], be[j]), 0.f) : 0.f;
+    for (int j = 0; j < 8; ++j) o[j] = fmaxf(__fmaf_rn(ga[j], x[j], be[j]), 0.f);
   }
 };
 struct BBnRelu {  // a[r,k] = relu(s[k] * H[r,k] + t[k]),  H stored bf16
@@ -128,7 +131,7 @@ struct BBnRelu {  // a[r,k] = relu(s[k] * H[r,k] + t[k]),  H stored bf16
     float h[8];
     unpack8(q.h, h);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (w.ok && k + j < K) ? fmaxf(__fmaf_rn(kcs[k + j], h[j], kcs[Kp + k + j]), 0.f) : 0.f;
+    for (int j = 0; j < 8; ++j) o[j] = fmaxf(__fmaf_rn(kcs[k + j], h[j], kcs[Kp + k + j]), 0.f);
   }
 };
 // d(loss)/d(h) of a BatchNorm'd layer in the affine form gh = ka*gy + kb*h + kc (see bn_bwd_finalize_kernel), gy and h bf16
@@ -157,7 +160,7 @@ struct BGradH {
     unpack8(q.h, h);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      o[j] = (w.ok && k + j < K) ? __fmaf_rn(kcs[k + j], gy[j], __fmaf_rn(kcs[Kp + k + j], h[j], kcs[2 * Kp + k + j])) : 0.f;
+      o[j] = __fmaf_rn(kcs[k + j], gy[j], __fmaf_rn(kcs[Kp + k + j], h[j], kcs[2 * Kp + k + j]));
   }
 };
 struct BGradH3 {  // gy3[r,o] = f * (g[r,:] . W4[:,o]) * (y3 > 0) regenerated from the 3-channel output gradient, then gh3
@@ -169,26 +172,30 @@ struct BGradH3 {  // gy3[r,o] = f * (g[r,:] . W4[:,o]) * (y3 > 0) regenerated fr
   static constexpr int NC = 8, DEPTH = 4;
   struct Row { const bfraw* p; float g0, g1, g2; bool ok; };
   struct Raw { u32x4 h; };
+  // constants interleaved per channel, two 16-byte reads per element: {s, t, kb, kc} {ka*w0, ka*w1, ka*w2, -}
+  //   gh3 = (s*h + t > 0 ? g . (ka*w) : 0) + kb*h + kc
   __device__ void stage(float* kcs, int Kp, int tid) const {
     for (int i = tid; i < Kp; i += NTB) {
       const bool ok = i < K;
-      kcs[i] = ok ? s[i] : 0.f; kcs[Kp + i] = ok ? t[i] : 0.f; kcs[2 * Kp + i] = ok ? ka[i] : 0.f; kcs[3 * Kp + i] = ok ? kb[i] : 0.f;
-      kcs[4 * Kp + i] = ok ? kc[i] : 0.f; kcs[5 * Kp + i] = ok ? W4[i] : 0.f; kcs[6 * Kp + i] = ok ? W4[K + i] : 0.f;
-      kcs[7 * Kp + i] = ok ? W4[2 * K + i] : 0.f;
+      const float a = ok ? ka[i] : 0.f;
+      float* q = kcs + (size_t)i * 8;
+      q[0] = ok ? s[i] : 0.f; q[1] = ok ? t[i] : 0.f; q[2] = ok ? kb[i] : 0.f; q[3] = ok ? kc[i] : 0.f;
+      q[4] = ok ? a * W4[i] : 0.f; q[5] = ok ? a * W4[K + i] : 0.f; q[6] = ok ? a * W4[2 * K + i] : 0.f; q[7] = 0.f;
     }
   }
   __device__ Row row(long r, int, int, bool ok) const {
     return Row{H + (size_t)r * ld, f * G[r * 3], f * G[r * 3 + 1], f * G[r * 3 + 2], ok};
   }
   __device__ void load(Raw& q, const Row& w, int k) const { q.h = *reinterpret_cast<const u32x4*>(w.p + (k <= ld - 8 ? k : ld - 8)); }
-  __device__ void fin(const Row& w, const float* kcs, int Kp, int k, const Raw& q, float* o) const {
+  __device__ void fin(const Row& w, const float* kcs, int, int k, const Raw& q, float* o) const {
     float h[8];
     unpack8(q.h, h);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = k + j;
-      const float gy = __fmaf_rn(kcs[c], h[j], kcs[Kp + c]) > 0.f ? (w.g0 * kcs[5 * Kp + c] + w.g1 * kcs[6 * Kp + c] + w.g2 * kcs[7 * Kp + c]) : 0.f;
-      o[j] = (w.ok && c < K) ? __fmaf_rn(kcs[2 * Kp + c], gy, __fmaf_rn(kcs[3 * Kp + c], h[j], kcs[4 * Kp + c])) : 0.f;
+      const float4 c0 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8);
+      const float4 c1 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8 + 4);
+      const float gy = __fmaf_rn(c0.x, h[j], c0.y) > 0.f ? (w.g0 * c1.x + w.g1 * c1.y + w.g2 * c1.z) : 0.f;
+      o[j] = gy + __fmaf_rn(c0.z, h[j], c0.w);
     }
   }
 };
@@ -251,9 +258,9 @@ struct EpiStoreB {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, s
     const int cl = c.bn0 + c.wn * 32 * WN + (c.lane & 31);
     const bool odd = c.lane & 1;
     float bv[WN];
-    double s1[WN], s2[WN];
+    float s1[WN], s2[WN];  // 16 values per lane in fp32, fp64 across lanes / waves / blocks
 #pragma unroll
-    for (int j = 0; j < WN; ++j) { bv[j] = (bias && cl + 32 * j < Nc) ? bias[cl + 32 * j] : 0.f; s1[j] = 0.0; s2[j] = 0.0; }
+    for (int j = 0; j < WN; ++j) { bv[j] = (bias && cl + 32 * j < Nc) ? bias[cl + 32 * j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int i0 = c.wm * 32 + acc_row(2 * p, c.lane);
@@ -267,13 +274,18 @@ struct EpiStoreB {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, s
         const bool cok = cl + 32 * j < Nc;
         const unsigned pk = pack_bf16(cok ? acc[j][2 * p] + bv[j] : 0.f, cok ? acc[j][2 * p + 1] + bv[j] : 0.f);
         const float v0 = ok0 ? bf_lo(pk) : 0.f, v1 = ok1 ? bf_hi(pk) : 0.f;
-        s1[j] += (double)(v0 + v1);
-        s2[j] += (double)__fmaf_rn(v0, v0, v1 * v1);
+        s1[j] += v0 + v1;
+        s2[j] = __fmaf_rn(v0, v0, __fmaf_rn(v1, v1, s2[j]));
         const unsigned w = pair_exchange(pk, odd);
         if (okw && (cl & ~1) + 32 * j < ldc) *reinterpret_cast<unsigned*>(dst + 32 * j) = w;
       }
     }
-    if (moments) reduce_cols<WN>(s1, s2, c, Nc, moments, smem);
+    if (moments) {
+      double d1[WN], d2[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) { d1[j] = (double)s1[j]; d2[j] = (double)s2[j]; }
+      reduce_cols<WN>(d1, d2, c, Nc, moments, smem);
+    }
   }
 };
 
@@ -401,7 +413,7 @@ struct EpiL1B {
 
 // ------------------------------------------------------------------------------------------------ rows GEMM
 // C[rows x Nc] = Aop[rows x K] * Wb^T, Wb = bf16 [Nc][Kp] image.  grid (row blocks, column blocks of 64*WN).
-template <class AOp, class Epi, int WN>
+template <class AOp, class Epi, int WN, bool STAGGER>
 __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, RowGeo geo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BNW = 64 * WN;
@@ -438,7 +450,9 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
   auto stash = [&](int buf, int kt, const typename AOp::Raw& ra, const u32x4* rb) {
     float v[8];
     aop.fin(row, kcs, Kp, kt * BK + kq, ra, v);
-    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + arow) * LP + kq) = pack8(v);
+    u32x4 pk = pack8(v);
+    if (!row.ok) pk = u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + arow) * LP + kq) = pk;
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
       const int c = tid + NTB * j;
@@ -480,6 +494,7 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
   // anywhere in the loop it falls back to vmcnt(0): one exposed Infinity-Cache / HBM round trip per k-tile).  Within an
   // iteration the B tile (weights, L2) is requested BEFORE the A tile: the counter is in-order, and the next iteration's wait
   // for that B tile must not also drain the deep A request behind it.
+  const bool late = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
   const int main_end = nk - 1 - DA > 0 ? ((nk - 1 - DA) / UN) * UN : 0;
   int kt0 = 0;
   for (; kt0 < main_end; kt0 += UN) {
@@ -487,10 +502,23 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
     for (int u = 0; u < UN; ++u) {
       const int kt = kt0 + u, cur = u & 1;  // kt0 is even
       const int sa = (u + 1) % DA, sb = (u + 1) % DB;
-      mma(cur);
-      stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
-      loadB(qb[sb], (kt + 1 + DB) * BK);
-      aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
+      // The two waves that share a SIMD (w and w + 4) run the iteration's two phases in OPPOSITE order: while one has its
+      // MFMAs in the matrix pipe the other transforms the next tile on the VALU.  Both orders are legal (the phases touch
+      // different LDS buffers); with the same order in every wave the barrier keeps all eight in lockstep and the two pipes
+      // take turns idling.
+      if (late) {
+        stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
+        loadB(qb[sb], (kt + 1 + DB) * BK);
+        aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
+        __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of the MFMA phase below the transform (register pressure)
+        mma(cur);
+      } else {
+        mma(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
+        loadB(qb[sb], (kt + 1 + DB) * BK);
+        aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
+      }
       __syncthreads();
     }
   }
@@ -502,12 +530,13 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
       if (kt < nk) {
         const int cur = kt & 1;
         const int sa = (u + 1) % DA, sb = (u + 1) % DB;
-        mma(cur);
+        if (!late) mma(cur);
         if (kt + 1 < nk) {
           stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
           if (kt + 1 + DB < nk) loadB(qb[sb], (kt + 1 + DB) * BK);
           if (kt + 1 + DA < nk) aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
         }
+        if (late) mma(cur);
         __syncthreads();
       }
     }
@@ -540,9 +569,8 @@ struct TBnRelu {  // relu(s*H+t), H bf16
   __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool ok = i < w.nvalid;
-      o0[i] = (ok && c < K) ? fmaxf(__fmaf_rn(k.s0, bf_lo(q.h[i]), k.t0), 0.f) : 0.f;
-      o1[i] = (ok && c + 1 < K) ? fmaxf(__fmaf_rn(k.s1, bf_hi(q.h[i]), k.t1), 0.f) : 0.f;
+      o0[i] = fmaxf(__fmaf_rn(k.s0, bf_lo(q.h[i]), k.t0), 0.f);
+      o1[i] = fmaxf(__fmaf_rn(k.s1, bf_hi(q.h[i]), k.t1), 0.f);
     }
   }
 };
@@ -568,9 +596,8 @@ struct TGradH {  // ka*gy + kb*h + kc, gy and h bf16
   __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool ok = i < w.nvalid;
-      o0[i] = (ok && c < K) ? __fmaf_rn(k.a0, bf_lo(q.gy[i]), __fmaf_rn(k.b0, bf_lo(q.h[i]), k.c0)) : 0.f;
-      o1[i] = (ok && c + 1 < K) ? __fmaf_rn(k.a1, bf_hi(q.gy[i]), __fmaf_rn(k.b1, bf_hi(q.h[i]), k.c1)) : 0.f;
+      o0[i] = __fmaf_rn(k.a0, bf_lo(q.gy[i]), __fmaf_rn(k.b0, bf_lo(q.h[i]), k.c0));
+      o1[i] = __fmaf_rn(k.a1, bf_hi(q.gy[i]), __fmaf_rn(k.b1, bf_hi(q.h[i]), k.c1));
     }
   }
 };
@@ -605,13 +632,12 @@ struct TGradH3 {  // gh3 regenerated from the 3-channel output gradient (see BGr
   __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool ok = i < w.nvalid;
       const float h0 = bf_lo(q.h[i]), h1 = bf_hi(q.h[i]);
       const float g0 = f * q.g[i][0], g1 = f * q.g[i][1], g2 = f * q.g[i][2];
       const float gy0 = __fmaf_rn(k.s[0], h0, k.t[0]) > 0.f ? (g0 * k.w0[0] + g1 * k.w1[0] + g2 * k.w2[0]) : 0.f;
       const float gy1 = __fmaf_rn(k.s[1], h1, k.t[1]) > 0.f ? (g0 * k.w0[1] + g1 * k.w1[1] + g2 * k.w2[1]) : 0.f;
-      o0[i] = (ok && c < K) ? __fmaf_rn(k.a[0], gy0, __fmaf_rn(k.b[0], h0, k.c[0])) : 0.f;
-      o1[i] = (ok && c + 1 < K) ? __fmaf_rn(k.a[1], gy1, __fmaf_rn(k.b[1], h1, k.c[1])) : 0.f;
+      o0[i] = __fmaf_rn(k.a[0], gy0, __fmaf_rn(k.b[0], h0, k.c[0]));
+      o1[i] = __fmaf_rn(k.a[1], gy1, __fmaf_rn(k.b[1], h1, k.c[1]));
     }
   }
 };
@@ -635,11 +661,10 @@ struct TGridFeat {  // a1 = relu(gamma*(Gx[n]+Fx[b])+beta) from the fp32 factors
   __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool ok = i < w.nvalid;
       const bool next = w.n + i >= N;  // wrapped into the next sample
       const float fx = next ? q.fb.x : q.fa.x, fy = next ? q.fb.y : q.fa.y;
-      o0[i] = (ok && c < K) ? fmaxf(__fmaf_rn(k.g0, q.gx[i].x + fx, k.b0), 0.f) : 0.f;
-      o1[i] = (ok && c + 1 < K) ? fmaxf(__fmaf_rn(k.g1, q.gx[i].y + fy, k.b1), 0.f) : 0.f;
+      o0[i] = fmaxf(__fmaf_rn(k.g0, q.gx[i].x + fx, k.b0), 0.f);
+      o1[i] = fmaxf(__fmaf_rn(k.g1, q.gx[i].y + fy, k.b1), 0.f);
     }
   }
 };
@@ -672,37 +697,67 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
   }
   typename AOp::Raw ra;
   typename BOp::Raw rb[BT];
-  TRows wa, wb[BT];
-  auto rows_of = [&](long r0) {
+  // Row cursor of a task: first row of its 8-row group in the current k-tile, and that row's (sample, vertex).  Advanced by one
+  // k-tile (64 rows) per iteration with a wrap at N - no division in the loop.
+  struct Cursor { long pos; int b, n; };
+  auto cursor_at = [&](long r0) {
+    Cursor c;
+    c.pos = r0;
+    const long rc = r0 < R ? r0 : 0;
+    c.b = (int)(rc / N);
+    c.n = (int)(rc - (long)c.b * N);
+    return c;
+  };
+  auto advance = [&](Cursor& c) {
+    c.pos += BKT;
+    c.n += BKT;
+    while (c.n >= N) { c.n -= N; ++c.b; }
+  };
+  auto rows_at = [&](const Cursor& c) {
     TRows w;
-    const long left = rend - r0;
+    const long left = rend - c.pos;
     w.nvalid = left >= 8 ? 8 : (left > 0 ? (int)left : 0);
-    w.r0 = w.nvalid ? r0 : 0;
-    w.b = (int)(w.r0 / N);
-    w.n = (int)(w.r0 - (long)w.b * N);
+    w.r0 = w.nvalid ? c.pos : rbeg;  // a group wholly beyond the chunk re-reads valid rows and is masked to zero
+    w.b = w.nvalid ? c.b : 0;
+    w.n = w.nvalid ? c.n : 0;
     return w;
   };
-  auto fetch = [&](long rt) {
-    wa = rows_of(rt + ga * 8);
-    aop.load(ra, wa, ca, Bsz);
+  // rows i >= nvalid of a packed 8-row strip -> zero (words hold row pairs)
+  auto mask_rows = [](u32x4 v, int nvalid) {
+    const unsigned m0 = (nvalid > 0 ? 0xffffu : 0u) | (nvalid > 1 ? 0xffff0000u : 0u);
+    const unsigned m1 = (nvalid > 2 ? 0xffffu : 0u) | (nvalid > 3 ? 0xffff0000u : 0u);
+    const unsigned m2 = (nvalid > 4 ? 0xffffu : 0u) | (nvalid > 5 ? 0xffff0000u : 0u);
+    const unsigned m3 = (nvalid > 6 ? 0xffffu : 0u) | (nvalid > 7 ? 0xffff0000u : 0u);
+    v.x &= m0; v.y &= m1; v.z &= m2; v.w &= m3;
+    return v;
+  };
+  Cursor cura = cursor_at(rbeg + ga * 8), curb[BT];
+#pragma unroll
+  for (int j = 0; j < BT; ++j) curb[j] = cursor_at(rbeg + gb[j] * 8);
+  TRows wa, wb[BT];
+  auto fetch = [&]() {  // loads of the tile the cursors point at; then the cursors move on
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
-      wb[j] = rows_of(rt + gb[j] * 8);
+      wb[j] = rows_at(curb[j]);
       if (tb_ok[j]) bop.load(rb[j], wb[j], cb[j], Bsz);
+      advance(curb[j]);
     }
+    wa = rows_at(cura);
+    aop.load(ra, wa, ca, Bsz);
+    advance(cura);
   };
   auto stash = [&](int buf) {
     float o0[8], o1[8];
     aop.fin(ra, kca, wa, ca, o0, o1);
-    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + 2 * lane) * LPT + ga * 8) = pack8(o0);
-    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + 2 * lane + 1) * LPT + ga * 8) = pack8(o1);
+    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + 2 * lane) * LPT + ga * 8) = mask_rows(pack8(o0), wa.nvalid);
+    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + 2 * lane + 1) * LPT + ga * 8) = mask_rows(pack8(o1), wa.nvalid);
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
       if (tb_ok[j]) {
         bop.fin(rb[j], kcb[j], wb[j], cb[j], o0, o1);
         const int ch = cb[j] - bn0;
-        *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + ch) * LPT + gb[j] * 8) = pack8(o0);
-        *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + ch + 1) * LPT + gb[j] * 8) = pack8(o1);
+        *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + ch) * LPT + gb[j] * 8) = mask_rows(pack8(o0), wb[j].nvalid);
+        *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + ch + 1) * LPT + gb[j] * 8) = mask_rows(pack8(o1), wb[j].nvalid);
       }
     }
   };
@@ -713,7 +768,7 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int nk = (int)((rend - rbeg + BKT - 1) / BKT);
   if (nk > 0) {
-    fetch(rbeg);
+    fetch();
     stash(0);
   }
   __syncthreads();
@@ -722,7 +777,7 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
-    if (more) fetch(rbeg + (long)(kt + 1) * BKT);
+    if (more) fetch();
     if (wave_live) {
 #pragma unroll
       for (int ks = 0; ks < BKT / 16; ++ks) {
