@@ -821,25 +821,41 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   t[c] = beta[c] - m * gamma[c] * rs;
 }
 
-// element loads of an activation stored as fp32 (exact flavour) or bf16 (bf16 flavour)
-__device__ __forceinline__ float ldact(const float* p, size_t i) { return p[i]; }
-__device__ __forceinline__ float ldact(const bfraw* p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
-
-// out[r, 0:3] = f * (b4 + W4 . relu(s3*h3[r]+t3)); 32 lanes per row, float4 per lane (C3 <= 128), 2 rows per wave pass
+// out[r, 0:3] = f * (b4 + W4 . relu(s3*h3[r]+t3)); 32 lanes per row, 2 rows per wave pass.  Lane sub owns the four CONSECUTIVE
+// channels 4 sub .. 4 sub + 3 (C3 <= 128): one 16-byte (fp32) or 8-byte (bf16) load per row.
+__device__ __forceinline__ void ld4act(const float* p, float* o) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ld4act(const bfraw* p, float* o) {
+  const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+  o[0] = bf_lo(v.x); o[1] = bf_hi(v.x); o[2] = bf_lo(v.y); o[3] = bf_hi(v.y);
+}
 template <class HT>
 __global__ __launch_bounds__(256) void l4_fwd_kernel(const HT* __restrict__ H3, int ld3, const float* __restrict__ s3,
                                                      const float* __restrict__ t3, const float* __restrict__ W4,
                                                      const float* __restrict__ b4, float f, long R, int C3, float* __restrict__ out) {
-  const int tid = threadIdx.x, sub = tid & 31;
+  const int tid = threadIdx.x, sub = tid & 31, c0 = sub * 4;
   const long r0 = ((long)blockIdx.x * 256 + tid) >> 5;
   const long stride = ((long)gridDim.x * 256) >> 5;
+  float cs[4], ct[4], w0[4], w1[4], w2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = c0 + j < C3;
+    const int c = ok ? c0 + j : 0;
+    cs[j] = ok ? s3[c] : 0.f; ct[j] = ok ? t3[c] : 0.f;
+    w0[j] = ok ? W4[c] : 0.f; w1[j] = ok ? W4[C3 + c] : 0.f; w2[j] = ok ? W4[2 * C3 + c] : 0.f;
+  }
+  const int cl = c0 + 4 <= ld3 ? c0 : 0;  // ld3 is a multiple of 16: a lane's four channels are inside the pitch or wholly masked
   for (long r = r0; r < R; r += stride) {
+    float h[4];
+    ld4act(H3 + (size_t)r * ld3 + cl, h);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int c = sub; c < C3; c += 32) {
-      const float a = fmaxf(__fmaf_rn(s3[c], ldact(H3, (size_t)r * ld3 + c), t3[c]), 0.f);
-      a0 = __fmaf_rn(a, W4[c], a0);
-      a1 = __fmaf_rn(a, W4[C3 + c], a1);
-      a2 = __fmaf_rn(a, W4[2 * C3 + c], a2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // channels beyond C3 (pitch padding of the fp32 flavour is not initialised): select, do not multiply
+      const float a = c0 + j < C3 ? fmaxf(__fmaf_rn(cs[j], h[j], ct[j]), 0.f) : 0.f;
+      a0 = __fmaf_rn(a, w0[j], a0); a1 = __fmaf_rn(a, w1[j], a1); a2 = __fmaf_rn(a, w2[j], a2);
     }
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) {
@@ -853,38 +869,69 @@ __global__ __launch_bounds__(256) void l4_fwd_kernel(const HT* __restrict__ H3, 
   }
 }
 
-// Layer-4 backward over a chunk of rows: thread = channel c.  Partials: sums[blk][C3][2] (S1,S2 fp64),
+// Layer-4 backward over a chunk of rows.  Block = 128 threads = 64 channel PAIRS x 2 row halves (4-byte loads of bf16 pairs,
+// 8-byte of fp32); the two halves are combined through LDS in fixed order.  Partials: sums[blk][C3][2] (S1,S2 fp64),
 // gw[blk][3*C3 + 4] (gW4 rows then gb4).
+__device__ __forceinline__ void ld2act(const float* p, float& a, float& b) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
+__device__ __forceinline__ void ld2act(const bfraw* p, float& a, float& b) { const unsigned v = *reinterpret_cast<const unsigned*>(p); a = bf_lo(v); b = bf_hi(v); }
 template <class HT>
 __global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G, const HT* __restrict__ H3, int ld3,
                                                      const float* __restrict__ s3, const float* __restrict__ t3,
                                                      const float* __restrict__ mean3, const float* __restrict__ rstd3,
                                                      const float* __restrict__ W4, float f, long R, int C3, int rows_per_blk,
                                                      double* __restrict__ sums, float* __restrict__ gw) {
-  const int c = threadIdx.x;
+  const int pair = threadIdx.x & 63, half = threadIdx.x >> 6, c = pair * 2;
   const long rbeg = (long)blockIdx.x * rows_per_blk, rend = min(R, rbeg + rows_per_blk);
-  const bool ok = c < C3;
-  const float cs = ok ? s3[c] : 0.f, ct = ok ? t3[c] : 0.f, cm = ok ? mean3[c] : 0.f, cr = ok ? rstd3[c] : 0.f;
-  const float w0 = ok ? W4[c] : 0.f, w1 = ok ? W4[C3 + c] : 0.f, w2 = ok ? W4[2 * C3 + c] : 0.f;
-  double S1 = 0, S2 = 0;
-  float g0a = 0.f, g1a = 0.f, g2a = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  for (long r = rbeg; r < rend; ++r) {
-    const float g0 = f * G[r * 3], g1 = f * G[r * 3 + 1], g2 = f * G[r * 3 + 2];
-    const float h = ok ? ldact(H3, (size_t)r * ld3 + c) : 0.f;
-    const float y = __fmaf_rn(cs, h, ct);
-    const float a = fmaxf(y, 0.f);
-    const float gy = y > 0.f ? (g0 * w0 + g1 * w1 + g2 * w2) : 0.f;
-    S1 += (double)gy;
-    S2 += (double)gy * (double)((h - cm) * cr);
-    g0a = __fmaf_rn(g0, a, g0a); g1a = __fmaf_rn(g1, a, g1a); g2a = __fmaf_rn(g2, a, g2a);
-    b0 += g0; b1 += g1; b2 += g2;
+  float cs[2], ct[2], cm[2], cr[2], w0[2], w1[2], w2[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const bool ok = c + e < C3;
+    const int cc = ok ? c + e : 0;
+    cs[e] = ok ? s3[cc] : 0.f; ct[e] = ok ? t3[cc] : 0.f; cm[e] = ok ? mean3[cc] : 0.f; cr[e] = ok ? rstd3[cc] : 0.f;
+    w0[e] = ok ? W4[cc] : 0.f; w1[e] = ok ? W4[C3 + cc] : 0.f; w2[e] = ok ? W4[2 * C3 + cc] : 0.f;
   }
-  if (ok) {
-    sums[((size_t)blockIdx.x * C3 + c) * 2] = S1;
-    sums[((size_t)blockIdx.x * C3 + c) * 2 + 1] = S2;
+  const int cl = c + 2 <= ld3 ? c : 0;
+  double S1[2] = {0, 0}, S2[2] = {0, 0};
+  float ga[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb[3] = {0.f, 0.f, 0.f};
+  for (long r = rbeg + half; r < rend; r += 2) {
+    const float g0 = f * G[r * 3], g1 = f * G[r * 3 + 1], g2 = f * G[r * 3 + 2];
+    float h[2];
+    ld2act(H3 + (size_t)r * ld3 + cl, h[0], h[1]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float y = __fmaf_rn(cs[e], h[e], ct[e]);
+      const float a = fmaxf(y, 0.f);
+      const float gy = y > 0.f ? (g0 * w0[e] + g1 * w1[e] + g2 * w2[e]) : 0.f;
+      S1[e] += (double)gy;
+      S2[e] += (double)gy * (double)((h[e] - cm[e]) * cr[e]);
+      ga[e][0] = __fmaf_rn(g0, a, ga[e][0]); ga[e][1] = __fmaf_rn(g1, a, ga[e][1]); ga[e][2] = __fmaf_rn(g2, a, ga[e][2]);
+    }
+    gb[0] += g0; gb[1] += g1; gb[2] += g2;
+  }
+  __shared__ double sd[64][4];
+  __shared__ float sf[64][9];
+  if (half == 1) {
+    sd[pair][0] = S1[0]; sd[pair][1] = S2[0]; sd[pair][2] = S1[1]; sd[pair][3] = S2[1];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sf[pair][e * 3 + k] = ga[e][k];
+    sf[pair][6] = gb[0]; sf[pair][7] = gb[1]; sf[pair][8] = gb[2];
+  }
+  __syncthreads();
+  if (half == 0) {
     float* dst = gw + (size_t)blockIdx.x * (3 * C3 + 4);
-    dst[c] = g0a; dst[C3 + c] = g1a; dst[2 * C3 + c] = g2a;
-    if (c == 0) { dst[3 * C3] = b0; dst[3 * C3 + 1] = b1; dst[3 * C3 + 2] = b2; }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (c + e < C3) {
+        sums[((size_t)blockIdx.x * C3 + c + e) * 2] = S1[e] + sd[pair][2 * e];
+        sums[((size_t)blockIdx.x * C3 + c + e) * 2 + 1] = S2[e] + sd[pair][2 * e + 1];
+        dst[c + e] = ga[e][0] + sf[pair][e * 3];
+        dst[C3 + c + e] = ga[e][1] + sf[pair][e * 3 + 1];
+        dst[2 * C3 + c + e] = ga[e][2] + sf[pair][e * 3 + 2];
+      }
+    }
+    if (pair == 0) { dst[3 * C3] = gb[0] + sf[0][6]; dst[3 * C3 + 1] = gb[1] + sf[0][7]; dst[3 * C3 + 2] = gb[2] + sf[0][8]; }
   }
 }
 
@@ -1315,28 +1362,20 @@ int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* o
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
-template <class AOp, class Epi, int WN, bool STAGGER>
-int launch_rows_bf16_impl(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+template <class AOp, class Epi, int WN>
+int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
   const int Kp = kpad(K);
   const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
   static int granted = 0;  // largest dynamic-LDS size already enabled for this instantiation
   if ((int)lds > granted) {
-    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN, STAGGER>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return (int)err;
     granted = (int)lds;
   }
   dim3 grid((unsigned)geo.blocks(), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
-  rows_bf16_kernel<AOp, Epi, WN, STAGGER><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
+  rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
   OBMAN_LAUNCH_CHECK();
   return 0;
-}
-template <class AOp, class Epi, int WN>
-int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
-  // OBMAN_BF16_STAGGER=1: the two waves of a SIMD run the MFMA / transform phases of an iteration in opposite order (A/B knob)
-  static const int stagger = [] { const char* v = getenv("OBMAN_BF16_STAGGER"); return v ? atoi(v) : 0; }();
-  return stagger ? launch_rows_bf16_impl<AOp, Epi, WN, true>(a, Wb, K, Nc, geo, e, st)
-                 : launch_rows_bf16_impl<AOp, Epi, WN, false>(a, Wb, K, Nc, geo, e, st);
 }
 template <class AOp, class Epi>
 int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {

@@ -413,7 +413,7 @@ struct EpiL1B {
 
 // ------------------------------------------------------------------------------------------------ rows GEMM
 // C[rows x Nc] = Aop[rows x K] * Wb^T, Wb = bf16 [Nc][Kp] image.  grid (row blocks, column blocks of 64*WN).
-template <class AOp, class Epi, int WN, bool STAGGER>
+template <class AOp, class Epi, int WN>
 __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, RowGeo geo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BNW = 64 * WN;
@@ -494,7 +494,6 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
   // anywhere in the loop it falls back to vmcnt(0): one exposed Infinity-Cache / HBM round trip per k-tile).  Within an
   // iteration the B tile (weights, L2) is requested BEFORE the A tile: the counter is in-order, and the next iteration's wait
   // for that B tile must not also drain the deep A request behind it.
-  const bool late = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
   const int main_end = nk - 1 - DA > 0 ? ((nk - 1 - DA) / UN) * UN : 0;
   int kt0 = 0;
   for (; kt0 < main_end; kt0 += UN) {
@@ -502,23 +501,10 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
     for (int u = 0; u < UN; ++u) {
       const int kt = kt0 + u, cur = u & 1;  // kt0 is even
       const int sa = (u + 1) % DA, sb = (u + 1) % DB;
-      // The two waves that share a SIMD (w and w + 4) run the iteration's two phases in OPPOSITE order: while one has its
-      // MFMAs in the matrix pipe the other transforms the next tile on the VALU.  Both orders are legal (the phases touch
-      // different LDS buffers); with the same order in every wave the barrier keeps all eight in lockstep and the two pipes
-      // take turns idling.
-      if (late) {
-        stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
-        loadB(qb[sb], (kt + 1 + DB) * BK);
-        aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
-        __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of the MFMA phase below the transform (register pressure)
-        mma(cur);
-      } else {
-        mma(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
-        loadB(qb[sb], (kt + 1 + DB) * BK);
-        aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
-      }
+      mma(cur);
+      stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
+      loadB(qb[sb], (kt + 1 + DB) * BK);
+      aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
       __syncthreads();
     }
   }
@@ -530,13 +516,12 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
       if (kt < nk) {
         const int cur = kt & 1;
         const int sa = (u + 1) % DA, sb = (u + 1) % DB;
-        if (!late) mma(cur);
+        mma(cur);
         if (kt + 1 < nk) {
           stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
           if (kt + 1 + DB < nk) loadB(qb[sb], (kt + 1 + DB) * BK);
           if (kt + 1 + DA < nk) aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
         }
-        if (late) mma(cur);
         __syncthreads();
       }
     }
