@@ -273,32 +273,50 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
 
   f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
   const int nk = (K + BK - 1) / BK;
+  // A wave whose 32 output columns all lie beyond Nc (the 257th / 515th column leaves 1 / 3 live columns in the last 64-wide
+  // block) issues no MFMA and reads no fragment: it only helps staging.  The matrix pipe it would have burnt goes to the
+  // other blocks of the CU.
+  const bool live = bn0 + wn * 32 < Nc;
+  const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
   fetch(0);
   stash(0, 0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt + 1 < nk; ++kt) {  // every tile but the last: the next tile's transform rides behind the MFMAs
     const int cur = kt & 1;
-    if (kt + 1 < nk && !(variant & 1)) fetch((kt + 1) * BK);
-    const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
+    if (!(variant & 1)) fetch((kt + 1) * BK);
     // The next tile's operand transform + LDS writes are spread over MFMA steps 4..11 (one eighth each): the loads were
     // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
     // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
-    const bool more = kt + 1 < nk && !(variant & 1);
-    // fragments are double-buffered in registers: step i+1's LDS reads are issued before step i's MFMAs
-    float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
+    const bool more = !(variant & 1);
+    if (live) {
+      // fragments are double-buffered in registers: step i+1's LDS reads are issued before step i's MFMAs
+      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
-    for (int step = 0; step < BK / 2; ++step) {
-      const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
-      const float nb = T.Bs[cur][kn + kh][bcol];
-      const float na0 = T.As[cur][kn + kh][arow];
-      const float na1 = T.As[cur][kn + kh][arow + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
-      if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
-      fb = nb; fa0 = na0; fa1 = na1;
+      for (int step = 0; step < BK / 2; ++step) {
+        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+        const float nb = T.Bs[cur][kn + kh][bcol];
+        const float na0 = T.As[cur][kn + kh][arow];
+        const float na1 = T.As[cur][kn + kh][arow + 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+        if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
+        fb = nb; fa0 = na0; fa1 = na1;
+      }
+    } else if (more) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, (kt + 1) * BK, q);
     }
     if (!(variant & 2)) __syncthreads();
   }
+  if (live) {  // last tile: only the k-steps that hold real columns (K = 515 -> 2 of 16, K = 257 -> 1 of 16)
+    const int cur = (nk - 1) & 1, steps = (K - (nk - 1) * BK + 1) / 2;
+    for (int step = 0; step < steps; ++step) {
+      const float fb = T.Bs[cur][2 * step + kh][bcol], fa0 = T.As[cur][2 * step + kh][arow], fa1 = T.As[cur][2 * step + kh][arow + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+    }
+  }
+  __syncthreads();
   if (variant & 4) { if (acc0[0] + acc1[3] == 123.456f) epi.C[0] = 1.f; return; }
   epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, bo.group, smem);
 }
@@ -468,22 +486,31 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     stash(0);
   }
   __syncthreads();
+  // Waves whose output rows (M = 257 leaves ONE live row in the third 128-row tile) or columns (Nc = 515: three live columns in
+  // the ninth 64-wide tile) are all beyond the matrix issue no MFMA for them.
+  const bool ncol = bn0 + wn * 32 < Nc;
+  const bool live0 = ncol && bm0 + wm * 64 < M, live1 = ncol && bm0 + wm * 64 + 32 < M;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) fetch(rbeg + (kt + 1) * BK);
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
     const bool more = kt + 1 < nk;
-    float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
+    if (live0) {
+      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
-    for (int step = 0; step < BK / 2; ++step) {  // register double-buffered fragments; next tile's transform spread over steps 4..11
-      const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
-      const float nb = T.Bs[cur][kn + kh][bcol];
-      const float na0 = T.As[cur][kn + kh][arow];
-      const float na1 = T.As[cur][kn + kh][arow + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
-      if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
-      fb = nb; fa0 = na0; fa1 = na1;
+      for (int step = 0; step < BK / 2; ++step) {  // register double-buffered fragments; next tile's transform spread over steps 4..11
+        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+        const float nb = T.Bs[cur][kn + kh][bcol];
+        const float na0 = T.As[cur][kn + kh][arow];
+        const float na1 = T.As[cur][kn + kh][arow + 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+        if (live1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+        if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
+        fb = nb; fa0 = na0; fa1 = na1;
+      }
+    } else if (more) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, q);
     }
     __syncthreads();
   }
