@@ -283,30 +283,34 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
   __syncthreads();
   for (int kt = 0; kt + 1 < nk; ++kt) {  // every tile but the last: the next tile's transform rides behind the MFMAs
     const int cur = kt & 1;
-    if (!(variant & 1)) fetch((kt + 1) * BK);
+    fetch((kt + 1) * BK);
     // The next tile's operand transform + LDS writes are spread over MFMA steps 4..11 (one eighth each): the loads were
     // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
     // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
-    const bool more = !(variant & 1);
+    // (No run-time condition inside the 16 steps: one scheduling region, fragment reads can move ahead of the MFMAs.)
     if (live) {
-      // fragments are double-buffered in registers: step i+1's LDS reads are issued before step i's MFMAs
-      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
+      // fragments run TWO steps ahead in registers (three rotating sets): the reads of step i+2 are issued before step i's
+      // MFMAs, so an MFMA pair never waits for an LDS round trip that started only one pair (128 cycles) earlier - nor for
+      // the transform's LDS writes queued behind it (the LDS counter is in-order)
+      float fr[3][3];
+      fr[0][0] = T.Bs[cur][kh][bcol]; fr[0][1] = T.As[cur][kh][arow]; fr[0][2] = T.As[cur][kh][arow + 32];
+      fr[1][0] = T.Bs[cur][2 + kh][bcol]; fr[1][1] = T.As[cur][2 + kh][arow]; fr[1][2] = T.As[cur][2 + kh][arow + 32];
 #pragma unroll
       for (int step = 0; step < BK / 2; ++step) {
-        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
-        const float nb = T.Bs[cur][kn + kh][bcol];
-        const float na0 = T.As[cur][kn + kh][arow];
-        const float na1 = T.As[cur][kn + kh][arow + 32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
-        if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
-        fb = nb; fa0 = na0; fa1 = na1;
+        const int kn = (step + 2 < BK / 2 ? step + 2 : BK / 2 - 1) * 2, s0 = step % 3, s2 = (step + 2) % 3;
+        fr[s2][0] = T.Bs[cur][kn + kh][bcol];
+        fr[s2][1] = T.As[cur][kn + kh][arow];
+        fr[s2][2] = T.As[cur][kn + kh][arow + 32];
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them to the point of use)
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][1], fr[s0][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][2], fr[s0][0], acc1, 0, 0, 0);
+        if (step >= 4 && step < 12) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
       }
-    } else if (more) {
+    } else {
 #pragma unroll
       for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, (kt + 1) * BK, q);
     }
-    if (!(variant & 2)) __syncthreads();
+    __syncthreads();
   }
   if (live) {  // last tile: only the k-steps that hold real columns (K = 515 -> 2 of 16, K = 257 -> 1 of 16)
     const int cur = (nk - 1) & 1, steps = (K - (nk - 1) * BK + 1) / 2;
@@ -317,7 +321,6 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
     }
   }
   __syncthreads();
-  if (variant & 4) { if (acc0[0] + acc1[3] == 123.456f) epi.C[0] = 1.f; return; }
   epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, bo.group, smem);
 }
 
@@ -496,17 +499,19 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
     const bool more = kt + 1 < nk;
     if (live0) {
-      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
+      float fr[3][3];  // fragments two steps ahead (see gemm_rows_kernel); next tile's transform spread over steps 4..11
+      fr[0][0] = T.Bs[cur][kh][bcol]; fr[0][1] = T.As[cur][kh][arow]; fr[0][2] = T.As[cur][kh][arow + 32];
+      fr[1][0] = T.Bs[cur][2 + kh][bcol]; fr[1][1] = T.As[cur][2 + kh][arow]; fr[1][2] = T.As[cur][2 + kh][arow + 32];
 #pragma unroll
-      for (int step = 0; step < BK / 2; ++step) {  // register double-buffered fragments; next tile's transform spread over steps 4..11
-        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
-        const float nb = T.Bs[cur][kn + kh][bcol];
-        const float na0 = T.As[cur][kn + kh][arow];
-        const float na1 = T.As[cur][kn + kh][arow + 32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
-        if (live1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+      for (int step = 0; step < BK / 2; ++step) {
+        const int kn = (step + 2 < BK / 2 ? step + 2 : BK / 2 - 1) * 2, s0 = step % 3, s2 = (step + 2) % 3;
+        fr[s2][0] = T.Bs[cur][kn + kh][bcol];
+        fr[s2][1] = T.As[cur][kn + kh][arow];
+        fr[s2][2] = T.As[cur][kn + kh][arow + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][1], fr[s0][0], acc0, 0, 0, 0);
+        if (live1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][2], fr[s0][0], acc1, 0, 0, 0);
         if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
-        fb = nb; fa0 = na0; fa1 = na1;
       }
     } else if (more) {
 #pragma unroll
