@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c3p1 | c3")
+    ap.add_argument("--config", default="c2", help="c2 (headline, configs[1]) | c3 (configs[2]) | c5 (configs[4]) | c3p1")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16 = autocast the ResNet encoder (configs[2] flavour; NOT the headline fp32 config)")
@@ -331,6 +331,8 @@ def describe_workload(args, cfg, n_pred, n_gt):
         tag = "configs[1]"
     elif args.config == "c3" and args.batch == 64 and args.image_size == 256:
         tag = "configs[2]" if not fp32 else "configs[2] model in fp32 (the config is specified in bf16)"
+    elif args.config == "c5" and args.image_size == 256:
+        tag = "configs[4] model (25 x 2562-point patches; the FHB input stream is reported separately as input_stream)"
     else:
         tag = "non-BASELINE variant '%s'" % args.config
     prec = "fp32" if fp32 else "%s encoder / %s decoder contractions, fp32 heads, losses, optimizer" % (

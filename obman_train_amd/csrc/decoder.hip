@@ -289,21 +289,18 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
     // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
     // (No run-time condition inside the 16 steps: one scheduling region, fragment reads can move ahead of the MFMAs.)
     if (live) {
-      // fragments run TWO steps ahead in registers (three rotating sets): the reads of step i+2 are issued before step i's
-      // MFMAs, so an MFMA pair never waits for an LDS round trip that started only one pair (128 cycles) earlier - nor for
-      // the transform's LDS writes queued behind it (the LDS counter is in-order)
-      float fr[3][3];
-      fr[0][0] = T.Bs[cur][kh][bcol]; fr[0][1] = T.As[cur][kh][arow]; fr[0][2] = T.As[cur][kh][arow + 32];
-      fr[1][0] = T.Bs[cur][2 + kh][bcol]; fr[1][1] = T.As[cur][2 + kh][arow]; fr[1][2] = T.As[cur][2 + kh][arow + 32];
+      // fragments are double-buffered in registers: step i+1's LDS reads are issued before step i's MFMAs.  (Running them two
+      // steps ahead behind a sched_barrier changed the waits from lgkmcnt(0) to lgkmcnt(4..8) but not the time: r02 notes.)
+      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
       for (int step = 0; step < BK / 2; ++step) {
-        const int kn = (step + 2 < BK / 2 ? step + 2 : BK / 2 - 1) * 2, s0 = step % 3, s2 = (step + 2) % 3;
-        fr[s2][0] = T.Bs[cur][kn + kh][bcol];
-        fr[s2][1] = T.As[cur][kn + kh][arow];
-        fr[s2][2] = T.As[cur][kn + kh][arow + 32];
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them to the point of use)
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][1], fr[s0][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][2], fr[s0][0], acc1, 0, 0, 0);
+        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+        const float nb = T.Bs[cur][kn + kh][bcol];
+        const float na0 = T.As[cur][kn + kh][arow];
+        const float na1 = T.As[cur][kn + kh][arow + 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+        fb = nb; fa0 = na0; fa1 = na1;
         if (step >= 4 && step < 12) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
       }
     } else {
@@ -499,18 +496,16 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
     const bool more = kt + 1 < nk;
     if (live0) {
-      float fr[3][3];  // fragments two steps ahead (see gemm_rows_kernel); next tile's transform spread over steps 4..11
-      fr[0][0] = T.Bs[cur][kh][bcol]; fr[0][1] = T.As[cur][kh][arow]; fr[0][2] = T.As[cur][kh][arow + 32];
-      fr[1][0] = T.Bs[cur][2 + kh][bcol]; fr[1][1] = T.As[cur][2 + kh][arow]; fr[1][2] = T.As[cur][2 + kh][arow + 32];
+      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
-      for (int step = 0; step < BK / 2; ++step) {
-        const int kn = (step + 2 < BK / 2 ? step + 2 : BK / 2 - 1) * 2, s0 = step % 3, s2 = (step + 2) % 3;
-        fr[s2][0] = T.Bs[cur][kn + kh][bcol];
-        fr[s2][1] = T.As[cur][kn + kh][arow];
-        fr[s2][2] = T.As[cur][kn + kh][arow + 32];
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][1], fr[s0][0], acc0, 0, 0, 0);
-        if (live1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s0][2], fr[s0][0], acc1, 0, 0, 0);
+      for (int step = 0; step < BK / 2; ++step) {  // register double-buffered fragments; next tile's transform spread over steps 4..11
+        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+        const float nb = T.Bs[cur][kn + kh][bcol];
+        const float na0 = T.As[cur][kn + kh][arow];
+        const float na1 = T.As[cur][kn + kh][arow + 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+        if (live1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+        fb = nb; fa0 = na0; fa1 = na1;
         if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
       }
     } else if (more) {
@@ -1394,20 +1389,27 @@ int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* o
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
-template <class AOp, class Epi, int WN>
-int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+template <class AOp, class Epi, int WN, int SCHED>
+int launch_rows_bf16_impl(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
   const int Kp = kpad(K);
   const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
   static int granted = 0;  // largest dynamic-LDS size already enabled for this instantiation
   if ((int)lds > granted) {
-    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN, SCHED>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return (int)err;
     granted = (int)lds;
   }
   dim3 grid((unsigned)geo.blocks(), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
-  rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
+  rows_bf16_kernel<AOp, Epi, WN, SCHED><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+template <class AOp, class Epi, int WN>
+int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+  static const int sched = [] { const char* v = getenv("OBMAN_BF16_SCHED"); return v ? atoi(v) : 0; }();  // A/B knob
+  return sched ? launch_rows_bf16_impl<AOp, Epi, WN, 1>(a, Wb, K, Nc, geo, e, st)
+               : launch_rows_bf16_impl<AOp, Epi, WN, 0>(a, Wb, K, Nc, geo, e, st);
 }
 template <class AOp, class Epi>
 int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {

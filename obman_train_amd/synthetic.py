@@ -25,6 +25,8 @@ CONFIGS["c3"] = dict(
     contact_lambda=1.0, collision_lambda=1.0, atlas_patches=25,
 )
 CONFIGS["c3p1"] = dict(CONFIGS["c3"], atlas_patches=1)  # contact config on the reference's single sphere
+# configs[4]: high-resolution object decoder, 25 patches x 2562 points (icosphere subdivision 4), same losses as configs[2]
+CONFIGS["c5"] = dict(CONFIGS["c3"], atlas_ico_divisions=4)
 
 
 def make_batch(batch, device, seed=0, n_obj=600, image_size=256, dtype=torch.float32):
