@@ -1295,8 +1295,10 @@ int tn_chunk_rows(int M, int Nc, long R, int bn = BN) {
     rows = (rows + BKT - 1) / BKT * BKT;  // whole 64-row k-tiles
     if (rows < 2 * BKT) rows = 2 * BKT;
   } else {
-    long want = (1024 + tiles - 1) / tiles;
-    want = (want + 7) / 8 * 8;
+    // 768 block slots (256 CUs x 3 blocks of 49.7 KB LDS): aim at just under TWO full rounds - 27 tiles x 40 chunks = 1080
+    // blocks ran a full round plus a 41 % one
+    long want = (2 * 768 / tiles) / 8 * 8;
+    if (want < 8) want = 8;
     rows = (R + want - 1) / want;
     if (rows < 128) rows = 128;
   }
@@ -1389,27 +1391,20 @@ int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* o
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
-template <class AOp, class Epi, int WN, int SCHED>
-int launch_rows_bf16_impl(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
+template <class AOp, class Epi, int WN>
+int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
   const int Kp = kpad(K);
   const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
   static int granted = 0;  // largest dynamic-LDS size already enabled for this instantiation
   if ((int)lds > granted) {
-    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN, SCHED>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return (int)err;
     granted = (int)lds;
   }
   dim3 grid((unsigned)geo.blocks(), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
-  rows_bf16_kernel<AOp, Epi, WN, SCHED><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
+  rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
   OBMAN_LAUNCH_CHECK();
   return 0;
-}
-template <class AOp, class Epi, int WN>
-int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
-  static const int sched = [] { const char* v = getenv("OBMAN_BF16_SCHED"); return v ? atoi(v) : 0; }();  // A/B knob
-  return sched ? launch_rows_bf16_impl<AOp, Epi, WN, 1>(a, Wb, K, Nc, geo, e, st)
-               : launch_rows_bf16_impl<AOp, Epi, WN, 0>(a, Wb, K, Nc, geo, e, st);
 }
 template <class AOp, class Epi>
 int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {

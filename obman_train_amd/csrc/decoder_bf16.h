@@ -413,7 +413,7 @@ struct EpiL1B {
 
 // ------------------------------------------------------------------------------------------------ rows GEMM
 // C[rows x Nc] = Aop[rows x K] * Wb^T, Wb = bf16 [Nc][Kp] image.  grid (row blocks, column blocks of 64*WN).
-template <class AOp, class Epi, int WN, int SCHED>
+template <class AOp, class Epi, int WN>
 __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, RowGeo geo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BNW = 64 * WN;
@@ -494,6 +494,8 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
   // anywhere in the loop it falls back to vmcnt(0): one exposed Infinity-Cache / HBM round trip per k-tile).  Within an
   // iteration the B tile (weights, L2) is requested BEFORE the A tile: the counter is in-order, and the next iteration's wait
   // for that B tile must not also drain the deep A request behind it.
+  // (Tried and dropped, profiles/r02_kernels.md: running the MFMA and transform phases in opposite order in the two waves of a
+  // SIMD - spills; interleaving them inside a wave with sched_group_barrier - no change in time.)
   const int main_end = nk - 1 - DA > 0 ? ((nk - 1 - DA) / UN) * UN : 0;
   int kt0 = 0;
   for (; kt0 < main_end; kt0 += UN) {
@@ -505,20 +507,6 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
       stash(cur ^ 1, kt + 1, qa[sa], qb[sb]);
       loadB(qb[sb], (kt + 1 + DB) * BK);
       aop.load(qa[sa], row, (kt + 1 + DA) * BK + kq);
-      if (SCHED) {
-        // One wave cannot overlap its own phases unless they are interleaved in program order: an MFMA is asynchronous once
-        // issued, so with "MFMA, a few transform instructions, MFMA, ..." the VALU works in the shadow of the matrix pipe
-        // instead of after it.  Order requested from the scheduler: the k-step's fragment reads, then (1 MFMA + 6 VALU) x WN.
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1 + WN, 0);  // DS reads: A fragment + WN B fragments
-#pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // VALU of the next tile's transform
-          }
-        }
-      }
       __syncthreads();
     }
   }
