@@ -157,8 +157,9 @@ struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o
 struct EpiStore {  // C[r, n] = acc + bias[n]; optional fp64 column moments (sum, sum of squares) per row-block
   float* C;
   const float* bias;
-  double* moments;  // [row_blocks][Nc][2] or null
+  double* moments;  // [row_blocks][mstride][2] or null
   int ldc, R, Nc;
+  int mstride;      // channels per row block in `moments` (>= Nc: the edge kernel fills the columns beyond the tile grid)
 };
 struct EpiMaskStats {  // C = acc * (y > 0); per row-block column sums S1 = sum(C), S2 = sum(C * xhat)
   float* C;
@@ -169,6 +170,7 @@ struct EpiMaskStats {  // C = acc * (y > 0); per row-block column sums S1 = sum(
   const float *Gx, *Fx, *gamma, *beta;    // mode 1 (ld = ldc)
   int N;
   int ps;        // mode 1 with a per-sample grid: Gx indexed by the row
+  int sstride;   // channels per row block in `sums` (>= Nc)
 };
 
 template <class A> __device__ __forceinline__ int rows_N(const A&) { return 1 << 30; }
@@ -349,7 +351,7 @@ struct EpiStoreImpl : EpiStore {
       if (wm == 1 && lane < 32) { red[(wn * 32 + lane) * 2] = s1; red[(wn * 32 + lane) * 2 + 1] = s2; }
       __syncthreads();
       if (wm == 0 && lane < 32 && col < Nc) {
-        double* dst = moments + ((size_t)rblk * Nc + col) * 2;
+        double* dst = moments + ((size_t)rblk * mstride + col) * 2;
         dst[0] = s1 + red[(wn * 32 + lane) * 2];
         dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
       }
@@ -415,7 +417,7 @@ struct EpiMaskStatsImpl : EpiMaskStats {
     if (wm == 1 && lane < 32) { red[(wn * 32 + lane) * 2] = s1; red[(wn * 32 + lane) * 2 + 1] = s2; }
     __syncthreads();
     if (wm == 0 && lane < 32 && cok) {
-      double* dst = sums + ((size_t)rblk * Nc + col) * 2;
+      double* dst = sums + ((size_t)rblk * sstride + col) * 2;
       dst[0] = s1 + red[(wn * 32 + lane) * 2];
       dst[1] = s2 + red[(wn * 32 + lane) * 2 + 1];
     }
@@ -523,6 +525,130 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
       const int m = bm0 + wm * 64 + t * 32 + acc_row(reg, lane);
       if (m < M && col < Nc) dst[(size_t)m * Nc + col] = t == 0 ? acc0[reg] : acc1[reg];
     }
+}
+
+// ------------------------------------------------------------------------------------------------ edge channels
+// 257 = 4 x 64 + 1 and 515 = 8 x 64 + 3: on the 64-wide tile grid the last channel(s) of a layer cost a whole extra column
+// block (one row block in five of the rows GEMMs, nine output tiles in twenty-seven of dW2) whose MFMAs multiply zeros, and
+// they push the block count just past a full round of the chip's block slots (1 605 blocks on 768 slots = three rounds, the
+// third 9 % full).  The tile kernels therefore cover the 256- / 512-aligned part only and these two VALU kernels add the
+// remaining channels: a skinny product is bandwidth / latency work, not matrix-pipe work.
+
+// Extra OUTPUT COLUMNS of a rows GEMM: C[r, col0 + j] = sum_k Aop[r,k] W[col0+j, k], j < NX.  One wave per row (lanes over k),
+// block = the same 128 rows as a tile-kernel row block, so its column partials land in the same [row block] slot.
+struct ColEpi {
+  float* C;
+  int ldc;
+  int mode;            // 0: C = acc + bias, partials (sum, sum sq)   1: C = acc * (s*H+t > 0), partials (sum C, sum C*xhat)
+  const float* bias;   // mode 0
+  const float *H, *s, *t, *mean, *rstd;  // mode 1
+  double* part;        // [row blocks][pstride][2] or null
+  int pstride;
+};
+template <class AOp, int NX, int KI>
+__global__ __launch_bounds__(256) void gemm_cols_kernel(AOp aop, const float* __restrict__ Bw, int ldb, int b_nk, int K, int col0, ColEpi e) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float w[KI][NX];
+  typename AOp::KC kc[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = lane + 64 * i, kk = k < K ? k : 0;
+    kc[i] = aop.kc(k);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) w[i][j] = k < K ? (b_nk ? Bw[(size_t)(col0 + j) * ldb + kk] : Bw[(size_t)kk * ldb + col0 + j]) : 0.f;
+  }
+  float cs[NX], ct[NX], cm[NX], cr[NX], bv[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    bv[j] = (e.mode == 0 && e.bias) ? e.bias[col0 + j] : 0.f;
+    cs[j] = e.mode == 1 ? e.s[col0 + j] : 0.f; ct[j] = e.mode == 1 ? e.t[col0 + j] : 0.f;
+    cm[j] = e.mode == 1 ? e.mean[col0 + j] : 0.f; cr[j] = e.mode == 1 ? e.rstd[col0 + j] : 0.f;
+  }
+  const int r0 = blockIdx.x * BM;
+  double p1[NX], p2[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) { p1[j] = 0.0; p2[j] = 0.0; }
+  for (int rr = wave; rr < BM; rr += 4) {
+    const int r = r0 + rr;
+    if (r >= aop.R) break;
+    const typename AOp::Row row = aop.row(r, r / rows_N(aop));
+    float acc[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const float x = aop.fin(row, kc[i], aop.raw(row, lane + 64 * i));  // 0 beyond K (kc.ok)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) acc[j] = __fmaf_rn(x, w[i][j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      float v = obman_wave_sum(acc[j]);
+      float q;
+      if (e.mode == 0) {
+        v += bv[j];
+        q = v;
+      } else {
+        const float h = e.H[(size_t)r * e.ldc + col0 + j];
+        v = __fmaf_rn(cs[j], h, ct[j]) > 0.f ? v : 0.f;
+        q = (h - cm[j]) * cr[j];
+      }
+      if (lane == 0) e.C[(size_t)r * e.ldc + col0 + j] = v;
+      p1[j] += (double)v;
+      p2[j] += (double)v * (double)q;
+    }
+  }
+  if (!e.part) return;
+  __shared__ double red[4][NX][2];
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { red[wave][j][0] = p1[j]; red[wave][j][1] = p2[j]; }
+  }
+  __syncthreads();
+  if (tid < NX * 2) {
+    const int j = tid >> 1, q = tid & 1;
+    e.part[((size_t)blockIdx.x * e.pstride + col0 + j) * 2 + q] = (red[0][j][q] + red[1][j][q]) + (red[2][j][q] + red[3][j][q]);
+  }
+}
+
+// One extra ROW or COLUMN of a weight-gradient product: part[chunk][j] = sum_{r in chunk} X[r, x0] * Y[r, j], j < NY (thread = j,
+// eight independent rows in flight per thread); reduce_edge_kernel sums the chunks in order and scatters with a stride.
+template <class XOp, class YOp>
+__global__ __launch_bounds__(256) void gemm_tn_edge_kernel(XOp xop, YOp yop, int x0, int NY, int R, int rows_per_chunk, float* __restrict__ part) {
+  const int j = blockIdx.x * 256 + threadIdx.x, jc = j < NY ? j : 0;
+  const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
+  const typename XOp::KC kx = xop.kc(x0);
+  const typename YOp::KC ky = yop.kc(j < NY ? j : (1 << 30));  // ok = false beyond NY: contributes zeros
+  const int hx = rbeg / rows_N(xop), hy = rbeg / rows_N(yop);
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int r = rbeg; r < rend; r += 8) {
+    typename XOp::Row rx[8];
+    typename YOp::Row ry[8];
+    typename XOp::Raw ax[8];
+    typename YOp::Raw ay[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int rr = r + u < rend ? r + u : 0x7ffffff0;  // row() turns rows >= R into "not ok" (zeros)
+      rx[u] = xop.row(rr, hx);
+      ry[u] = yop.row(rr, hy);
+      ax[u] = xop.raw(rx[u], x0);
+      ay[u] = yop.raw(ry[u], jc);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc0 = __fmaf_rn(xop.fin(rx[u], kx, ax[u]), yop.fin(ry[u], ky, ay[u]), acc0);
+      acc1 = __fmaf_rn(xop.fin(rx[u + 1], kx, ax[u + 1]), yop.fin(ry[u + 1], ky, ay[u + 1]), acc1);
+    }
+  }
+  if (j < NY) part[(size_t)blockIdx.y * NY + j] = acc0 + acc1;
+}
+// out[j * ostride] = sum_c part[c][j]   (fixed chunk order)
+__global__ __launch_bounds__(256) void reduce_edge_kernel(const float* __restrict__ part, int chunks, int NY, int ostride, float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= NY) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * NY + j];
+  out[(size_t)j * ostride] = s;
 }
 
 // out[i] = scale * sum_c part[c][i]  (fixed chunk order)
@@ -1263,6 +1389,7 @@ Dims dims_of(const obman_pointgen_params* p) {
 }
 constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 blocks at 64 x 642 points)
 constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gradient GEMMs
+constexpr int EDGE_CHUNK_ROWS = 128;  // rows per block of the edge-channel weight-gradient kernel
 
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
@@ -1321,7 +1448,7 @@ L1Geo l1_geo(const Dims& d) {
   return g;
 }
 struct BwdWs {
-  long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, Ppre, dF, dG, seg, segw, tn, wt2, wt3, total;
+  long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, Ppre, dF, dG, seg, segw, tn, tnx, wt2, wt3, total;
   int chunks;
 };
 BwdWs bwd_ws(const Dims& d) {
@@ -1360,6 +1487,7 @@ BwdWs bwd_ws(const Dims& d) {
     if (c > a) a = c;
     w.tn = take(a);
   }
+  w.tnx = take(d.bf16 ? 0 : ((d.R + EDGE_CHUNK_ROWS - 1) / EDGE_CHUNK_ROWS) * (long)d.C1);  // edge-channel partials of the weight gradients
   w.wt2 = take(d.bf16 ? ((long)d.C1 * kpad(d.C2) + 1) / 2 : 0);  // bf16 [C1][kpad(C2)] image of W2^T (dA GEMM of layer 2)
   w.wt3 = take(d.bf16 ? ((long)d.C2 * kpad(d.C3) + 1) / 2 : 0);
   w.total = o;
@@ -1382,6 +1510,38 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part, xcd_aware());
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+// ---- edge channels (see gemm_cols_kernel / gemm_tn_edge_kernel): a layer width of 64 q + 1 or 64 q + 3 is split into the tile grid's
+// 64 q columns and 1 / 3 edge channels; anything else stays on the tile grid
+inline int edge_of(int n) { const int r = n % BN; return (n > BN && (r == 1 || r == 3)) ? r : 0; }
+inline int edge_ki(int K) { const int k = (K + 63) / 64; return k <= 1 ? 1 : k <= 2 ? 2 : k <= 3 ? 3 : k <= 5 ? 5 : k <= 9 ? 9 : 0; }
+template <class AOp, int NX>
+int launch_cols_nx(const AOp& a, const float* W, int ldb, int b_nk, int K, int col0, long R, const ColEpi& e, hipStream_t st) {
+  const unsigned rb = (unsigned)((R + BM - 1) / BM);
+  switch (edge_ki(K)) {
+    case 1: gemm_cols_kernel<AOp, NX, 1><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
+    case 2: gemm_cols_kernel<AOp, NX, 2><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
+    case 3: gemm_cols_kernel<AOp, NX, 3><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
+    case 5: gemm_cols_kernel<AOp, NX, 5><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
+    case 9: gemm_cols_kernel<AOp, NX, 9><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
+    default: return -5;
+  }
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+template <class AOp>
+int launch_cols(const AOp& a, const float* W, int ldb, int b_nk, int K, int col0, int nx, long R, const ColEpi& e, hipStream_t st) {
+  return nx == 1 ? launch_cols_nx<AOp, 1>(a, W, ldb, b_nk, K, col0, R, e, st) : launch_cols_nx<AOp, 3>(a, W, ldb, b_nk, K, col0, R, e, st);
+}
+// out[j * ostride] = sum_r X[r, x0] Y[r, j], j < NY
+template <class XOp, class YOp>
+int launch_tn_edge(const XOp& x, const YOp& y, int x0, int NY, long R, float* part, float* out, int ostride, hipStream_t st) {
+  const int chunks = (int)((R + EDGE_CHUNK_ROWS - 1) / EDGE_CHUNK_ROWS);
+  gemm_tn_edge_kernel<XOp, YOp><<<dim3(obman_cdiv(NY, 256), chunks), 256, 0, st>>>(x, y, x0, NY, (int)R, EDGE_CHUNK_ROWS, part);
+  OBMAN_LAUNCH_CHECK();
+  reduce_edge_kernel<<<obman_cdiv(NY, 256), 256, 0, st>>>(part, chunks, NY, ostride, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -1596,10 +1756,16 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
   double* moments = reinterpret_cast<double*>(ws + w.moments);
   {  // h2 = W2 relu(bn1(h1)) + b2
     AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1, d.ps};
+    const int ex = edge_ki(d.C1) ? edge_of(d.C2) : 0;  // 257 = 256 + 1: the last channel goes to the edge kernel
     EpiStoreImpl e;
-    e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
-    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
+    e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2 - ex;
+    e.mstride = d.C2;
+    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2 - ex, d.R, e, st);
     if (rc) return rc;
+    if (ex) {
+      const ColEpi ce{ws + w.H2, d.ld2, 0, p->b2, nullptr, nullptr, nullptr, nullptr, nullptr, tr ? moments : nullptr, d.C2};
+      if ((rc = launch_cols<AGridFeat>(a, p->w2, d.C1, 1, d.C1, d.C2 - ex, ex, d.R, ce, st))) return rc;
+    }
     const double* mom = moments;
     int mrows = d.rb;
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C2 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
@@ -1611,6 +1777,7 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
     ABnRelu a{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, (int)d.R, d.C2};
     EpiStoreImpl e;
     e.C = ws + w.H3; e.bias = p->b3; e.moments = tr ? moments : nullptr; e.ldc = d.ld3; e.R = (int)d.R; e.Nc = d.C3;
+    e.mstride = d.C3;
     int rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
     if (rc) return rc;
     const double* mom = moments;
@@ -1663,14 +1830,23 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
     {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
       ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
-      if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
+      const int ex = edge_of(d.C2);  // the 257th input channel: one extra column of gW3
+      if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2 - ex, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
+      for (int j = 0; j < ex; ++j)
+        if ((rc = launch_tn_edge<ABnRelu, AGradH3>(a2, gh3, d.C2 - ex + j, d.C3, d.R, ws2 + v.tnx, g->w3 + d.C2 - ex + j, d.C2, st))) return rc;
     }
     {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
       e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
-      e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N; e.ps = 0;
-      if ((rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st))) return rc;
+      e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N; e.ps = 0; e.sstride = d.C2;
+      const int ex = edge_ki(d.C3) ? edge_of(d.C2) : 0;
+      e.Nc = d.C2 - ex;
+      if ((rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2 - ex, d.R, e, st))) return rc;
+      if (ex) {
+        const ColEpi ce{ws2 + v.GY2, d.ld2, 1, nullptr, ws + w.H2, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, sums, d.C2};
+        if ((rc = launch_cols<AGradH3>(gh3, p->w3, d.C2, 0, d.C3, d.C2 - ex, ex, d.R, ce, st))) return rc;
+      }
     }
     sp = sums;
     srows = d.rb;
@@ -1680,12 +1856,20 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     OBMAN_LAUNCH_CHECK();
     AGradH gh2{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, R, d.C2};
     AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1, d.ps};
-    if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;  // gW2[o,c]
+    {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c]: 256 x 512 on the tile grid, the 257th row and the last three columns on the edge kernel
+      const int em = edge_of(d.C2), en = edge_of(d.C1);
+      if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2 - em, d.C1 - en, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
+      for (int i = 0; i < em; ++i)  // rows C2-em .. C2-1, every column
+        if ((rc = launch_tn_edge<AGradH, AGridFeat>(gh2, a1, d.C2 - em + i, d.C1, d.R, ws2 + v.tnx, g->w2 + (size_t)(d.C2 - em + i) * d.C1, 1, st)))
+          return rc;
+      for (int j = 0; j < en; ++j)  // columns C1-en .. C1-1 of the tile-grid rows
+        if ((rc = launch_tn_edge<AGridFeat, AGradH>(a1, gh2, d.C1 - en + j, d.C2 - em, d.R, ws2 + v.tnx, g->w2 + d.C1 - en + j, d.C1, st))) return rc;
+    }
     {  // gy1 = (gh2 W2) * (y1 > 0)
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
       e.H = e.s = e.t = e.mean = e.rstd = nullptr;
-      e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N; e.ps = d.ps;
+      e.Gx = ws + w.Gx; e.Fx = ws + w.Fx; e.gamma = p->bn_w[0]; e.beta = p->bn_b[0]; e.N = d.N; e.ps = d.ps; e.sstride = d.C1;
       if ((rc = launch_rows<AGradH, false, EpiMaskStatsImpl>(gh2, p->w2, d.C1, d.C2, d.C1, d.R, e, st))) return rc;
     }
     if (d.ps) {  // per-sample grid: BN-1 backward coefficients from the epilogue's sums, then one pass over gy1 and Gx
