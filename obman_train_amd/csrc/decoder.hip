@@ -1391,6 +1391,10 @@ constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 bl
 constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gradient GEMMs
 constexpr int EDGE_CHUNK_ROWS = 128;  // rows per block of the edge-channel weight-gradient kernel
 
+// ---- edge channels (see gemm_cols_kernel / gemm_tn_edge_kernel): a layer width of 64 q + 1 or 64 q + 3 is split into the tile grid's
+// 64 q columns and 1 / 3 edge channels; anything else stays on the tile grid
+inline int edge_of(int n) { const int r = n % BN; return (n > BN && (r == 1 || r == 3)) ? r : 0; }
+inline int edge_ki(int K) { const int k = (K + 63) / 64; return k <= 1 ? 1 : k <= 2 ? 2 : k <= 3 ? 3 : k <= 5 ? 5 : k <= 9 ? 9 : 0; }
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
   long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
@@ -1482,7 +1486,10 @@ BwdWs bwd_ws(const Dims& d) {
       const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * wide_wn(Nc) : BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
     };
-    long a = need(d.C3, d.C2, d.R), b = need(d.C2, d.C1, d.R), c = need(d.C1, d.C1 - 3, d.B);
+    // fp32 flavour: the tile kernels see the 64-aligned parts only (edge channels go to gemm_tn_edge_kernel) - the chunk
+    // count depends on the tile count, so the sizes must be those of the launches
+    const int e2 = d.bf16 ? 0 : edge_of(d.C2), e1 = d.bf16 ? 0 : edge_of(d.C1);
+    long a = need(d.C3, d.C2 - e2, d.R), b = need(d.C2 - e2, d.C1 - e1, d.R), c = need(d.C1, d.C1 - 3, d.B);
     if (b > a) a = b;
     if (c > a) a = c;
     w.tn = take(a);
@@ -1513,10 +1520,6 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
-// ---- edge channels (see gemm_cols_kernel / gemm_tn_edge_kernel): a layer width of 64 q + 1 or 64 q + 3 is split into the tile grid's
-// 64 q columns and 1 / 3 edge channels; anything else stays on the tile grid
-inline int edge_of(int n) { const int r = n % BN; return (n > BN && (r == 1 || r == 3)) ? r : 0; }
-inline int edge_ki(int K) { const int k = (K + 63) / 64; return k <= 1 ? 1 : k <= 2 ? 2 : k <= 3 ? 3 : k <= 5 ? 5 : k <= 9 ? 9 : 0; }
 template <class AOp, int NX>
 int launch_cols_nx(const AOp& a, const float* W, int ldb, int b_nk, int K, int col0, long R, const ColEpi& e, hipStream_t st) {
   const unsigned rb = (unsigned)((R + BM - 1) / BM);
