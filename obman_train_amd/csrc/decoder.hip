@@ -528,127 +528,63 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
 }
 
 // ------------------------------------------------------------------------------------------------ edge channels
-// 257 = 4 x 64 + 1 and 515 = 8 x 64 + 3: on the 64-wide tile grid the last channel(s) of a layer cost a whole extra column
-// block (one row block in five of the rows GEMMs, nine output tiles in twenty-seven of dW2) whose MFMAs multiply zeros, and
-// they push the block count just past a full round of the chip's block slots (1 605 blocks on 768 slots = three rounds, the
-// third 9 % full).  The tile kernels therefore cover the 256- / 512-aligned part only and these two VALU kernels add the
-// remaining channels: a skinny product is bandwidth / latency work, not matrix-pipe work.
-
-// Extra OUTPUT COLUMNS of a rows GEMM: C[r, col0 + j] = sum_k Aop[r,k] W[col0+j, k], j < NX.  One wave per row (lanes over k),
-// block = the same 128 rows as a tile-kernel row block, so its column partials land in the same [row block] slot.
-struct ColEpi {
-  float* C;
-  int ldc;
-  int mode;            // 0: C = acc + bias, partials (sum, sum sq)   1: C = acc * (s*H+t > 0), partials (sum C, sum C*xhat)
-  const float* bias;   // mode 0
-  const float *H, *s, *t, *mean, *rstd;  // mode 1
-  double* part;        // [row blocks][pstride][2] or null
-  int pstride;
-};
-template <class AOp, int NX, int KI>
-__global__ __launch_bounds__(256) void gemm_cols_kernel(AOp aop, const float* __restrict__ Bw, int ldb, int b_nk, int K, int col0, ColEpi e) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float w[KI][NX];
-  typename AOp::KC kc[KI];
-#pragma unroll
-  for (int i = 0; i < KI; ++i) {
-    const int k = lane + 64 * i, kk = k < K ? k : 0;
-    kc[i] = aop.kc(k);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) w[i][j] = k < K ? (b_nk ? Bw[(size_t)(col0 + j) * ldb + kk] : Bw[(size_t)kk * ldb + col0 + j]) : 0.f;
-  }
-  float cs[NX], ct[NX], cm[NX], cr[NX], bv[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    bv[j] = (e.mode == 0 && e.bias) ? e.bias[col0 + j] : 0.f;
-    cs[j] = e.mode == 1 ? e.s[col0 + j] : 0.f; ct[j] = e.mode == 1 ? e.t[col0 + j] : 0.f;
-    cm[j] = e.mode == 1 ? e.mean[col0 + j] : 0.f; cr[j] = e.mode == 1 ? e.rstd[col0 + j] : 0.f;
-  }
-  const int r0 = blockIdx.x * BM;
-  double p1[NX], p2[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) { p1[j] = 0.0; p2[j] = 0.0; }
-  for (int rr = wave; rr < BM; rr += 4) {
-    const int r = r0 + rr;
-    if (r >= aop.R) break;
-    const typename AOp::Row row = aop.row(r, r / rows_N(aop));
-    float acc[NX];
-#pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const float x = aop.fin(row, kc[i], aop.raw(row, lane + 64 * i));  // 0 beyond K (kc.ok)
-#pragma unroll
-      for (int j = 0; j < NX; ++j) acc[j] = __fmaf_rn(x, w[i][j], acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      float v = obman_wave_sum(acc[j]);
-      float q;
-      if (e.mode == 0) {
-        v += bv[j];
-        q = v;
-      } else {
-        const float h = e.H[(size_t)r * e.ldc + col0 + j];
-        v = __fmaf_rn(cs[j], h, ct[j]) > 0.f ? v : 0.f;
-        q = (h - cm[j]) * cr[j];
-      }
-      if (lane == 0) e.C[(size_t)r * e.ldc + col0 + j] = v;
-      p1[j] += (double)v;
-      p2[j] += (double)v * (double)q;
-    }
-  }
-  if (!e.part) return;
-  __shared__ double red[4][NX][2];
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { red[wave][j][0] = p1[j]; red[wave][j][1] = p2[j]; }
-  }
-  __syncthreads();
-  if (tid < NX * 2) {
-    const int j = tid >> 1, q = tid & 1;
-    e.part[((size_t)blockIdx.x * e.pstride + col0 + j) * 2 + q] = (red[0][j][q] + red[1][j][q]) + (red[2][j][q] + red[3][j][q]);
-  }
-}
-
-// One extra ROW or COLUMN of a weight-gradient product: part[chunk][j] = sum_{r in chunk} X[r, x0] * Y[r, j], j < NY (thread = j,
-// eight independent rows in flight per thread); reduce_edge_kernel sums the chunks in order and scatters with a stride.
+// 257 = 4 x 64 + 1 and 515 = 8 x 64 + 3.  On the 64-wide tile grid gW2 [257 x 515] needs 3 x 9 = 27 output tiles of which 11
+// hold one row or three columns; the tile kernel therefore covers [256 x 512] (16 tiles: 244 -> 146 us at configs[1]) and this
+// VALU kernel adds the 257th row and the last three columns - skinny products are bandwidth / latency work, not matrix-pipe
+// work.  (The same split for the rows GEMMs h2 / gy2 and for gW3 was measured and dropped: there the extra pass over the
+// regenerated operand costs what the saved column block did - profiles/r02_kernels.md.)
+//
+// part[chunk][j] = sum_{r in chunk} X[r, x0] * Y[r, j], j < NY.  Block = 32 consecutive j x 8 row slices (row r of slice s:
+// rbeg + s + 8 i), four independent rows in flight per thread; the slices are combined through LDS in slice order.
+constexpr int EDGE_J = 32, EDGE_S = 8;
 template <class XOp, class YOp>
 __global__ __launch_bounds__(256) void gemm_tn_edge_kernel(XOp xop, YOp yop, int x0, int NY, int R, int rows_per_chunk, float* __restrict__ part) {
-  const int j = blockIdx.x * 256 + threadIdx.x, jc = j < NY ? j : 0;
+  const int jl = threadIdx.x & (EDGE_J - 1), sl = threadIdx.x / EDGE_J;
+  const int j = blockIdx.x * EDGE_J + jl, jc = j < NY ? j : 0;
   const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
   const typename XOp::KC kx = xop.kc(x0);
   const typename YOp::KC ky = yop.kc(j < NY ? j : (1 << 30));  // ok = false beyond NY: contributes zeros
   const int hx = rbeg / rows_N(xop), hy = rbeg / rows_N(yop);
   float acc0 = 0.f, acc1 = 0.f;
-  for (int r = rbeg; r < rend; r += 8) {
-    typename XOp::Row rx[8];
-    typename YOp::Row ry[8];
-    typename XOp::Raw ax[8];
-    typename YOp::Raw ay[8];
+  for (int r = rbeg + sl; r < rend; r += 4 * EDGE_S) {
+    typename XOp::Row rx[4];
+    typename YOp::Row ry[4];
+    typename XOp::Raw ax[4];
+    typename YOp::Raw ay[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int rr = r + u < rend ? r + u : 0x7ffffff0;  // row() turns rows >= R into "not ok" (zeros)
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + u * EDGE_S < rend ? r + u * EDGE_S : 0x7ffffff0;  // row() turns rows >= R into "not ok" (zeros)
       rx[u] = xop.row(rr, hx);
       ry[u] = yop.row(rr, hy);
       ax[u] = xop.raw(rx[u], x0);
       ay[u] = yop.raw(ry[u], jc);
     }
-#pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      acc0 = __fmaf_rn(xop.fin(rx[u], kx, ax[u]), yop.fin(ry[u], ky, ay[u]), acc0);
-      acc1 = __fmaf_rn(xop.fin(rx[u + 1], kx, ax[u + 1]), yop.fin(ry[u + 1], ky, ay[u + 1]), acc1);
-    }
+    acc0 = __fmaf_rn(xop.fin(rx[0], kx, ax[0]), yop.fin(ry[0], ky, ay[0]), acc0);
+    acc1 = __fmaf_rn(xop.fin(rx[1], kx, ax[1]), yop.fin(ry[1], ky, ay[1]), acc1);
+    acc0 = __fmaf_rn(xop.fin(rx[2], kx, ax[2]), yop.fin(ry[2], ky, ay[2]), acc0);
+    acc1 = __fmaf_rn(xop.fin(rx[3], kx, ax[3]), yop.fin(ry[3], ky, ay[3]), acc1);
   }
-  if (j < NY) part[(size_t)blockIdx.y * NY + j] = acc0 + acc1;
+  __shared__ float red[EDGE_S][EDGE_J];
+  red[sl][jl] = acc0 + acc1;
+  __syncthreads();
+  if (sl == 0 && j < NY) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < EDGE_S; ++k) s += red[k][jl];
+    part[(size_t)blockIdx.y * NY + j] = s;
+  }
 }
-// out[j * ostride] = sum_c part[c][j]   (fixed chunk order)
+// out[j * ostride] = sum_c part[c][j]   (chunk order; four partial sums per thread keep four loads in flight)
 __global__ __launch_bounds__(256) void reduce_edge_kernel(const float* __restrict__ part, int chunks, int NY, int ostride, float* __restrict__ out) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= NY) return;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * NY + j];
-  out[(size_t)j * ostride] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 3 < chunks; c += 4) {
+    s0 += part[(size_t)c * NY + j]; s1 += part[(size_t)(c + 1) * NY + j]; s2 += part[(size_t)(c + 2) * NY + j]; s3 += part[(size_t)(c + 3) * NY + j];
+  }
+  for (; c < chunks; ++c) s0 += part[(size_t)c * NY + j];
+  out[(size_t)j * ostride] = (s0 + s1) + (s2 + s3);
 }
 
 // out[i] = scale * sum_c part[c][i]  (fixed chunk order)
@@ -1389,12 +1325,11 @@ Dims dims_of(const obman_pointgen_params* p) {
 }
 constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 blocks at 64 x 642 points)
 constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gradient GEMMs
-constexpr int EDGE_CHUNK_ROWS = 128;  // rows per block of the edge-channel weight-gradient kernel
+constexpr int EDGE_CHUNK_ROWS = 1024;  // rows per block of the edge-channel weight-gradient kernel
 
 // ---- edge channels (see gemm_cols_kernel / gemm_tn_edge_kernel): a layer width of 64 q + 1 or 64 q + 3 is split into the tile grid's
 // 64 q columns and 1 / 3 edge channels; anything else stays on the tile grid
 inline int edge_of(int n) { const int r = n % BN; return (n > BN && (r == 1 || r == 3)) ? r : 0; }
-inline int edge_ki(int K) { const int k = (K + 63) / 64; return k <= 1 ? 1 : k <= 2 ? 2 : k <= 3 ? 3 : k <= 5 ? 5 : k <= 9 ? 9 : 0; }
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
   long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
@@ -1489,7 +1424,7 @@ BwdWs bwd_ws(const Dims& d) {
     // fp32 flavour: the tile kernels see the 64-aligned parts only (edge channels go to gemm_tn_edge_kernel) - the chunk
     // count depends on the tile count, so the sizes must be those of the launches
     const int e2 = d.bf16 ? 0 : edge_of(d.C2), e1 = d.bf16 ? 0 : edge_of(d.C1);
-    long a = need(d.C3, d.C2 - e2, d.R), b = need(d.C2 - e2, d.C1 - e1, d.R), c = need(d.C1, d.C1 - 3, d.B);
+    long a = need(d.C3, d.C2, d.R), b = need(d.C2 - e2, d.C1 - e1, d.R), c = need(d.C1, d.C1 - 3, d.B);
     if (b > a) a = b;
     if (c > a) a = c;
     w.tn = take(a);
@@ -1520,29 +1455,11 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
-template <class AOp, int NX>
-int launch_cols_nx(const AOp& a, const float* W, int ldb, int b_nk, int K, int col0, long R, const ColEpi& e, hipStream_t st) {
-  const unsigned rb = (unsigned)((R + BM - 1) / BM);
-  switch (edge_ki(K)) {
-    case 1: gemm_cols_kernel<AOp, NX, 1><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
-    case 2: gemm_cols_kernel<AOp, NX, 2><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
-    case 3: gemm_cols_kernel<AOp, NX, 3><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
-    case 5: gemm_cols_kernel<AOp, NX, 5><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
-    case 9: gemm_cols_kernel<AOp, NX, 9><<<rb, 256, 0, st>>>(a, W, ldb, b_nk, K, col0, e); break;
-    default: return -5;
-  }
-  OBMAN_LAUNCH_CHECK();
-  return 0;
-}
-template <class AOp>
-int launch_cols(const AOp& a, const float* W, int ldb, int b_nk, int K, int col0, int nx, long R, const ColEpi& e, hipStream_t st) {
-  return nx == 1 ? launch_cols_nx<AOp, 1>(a, W, ldb, b_nk, K, col0, R, e, st) : launch_cols_nx<AOp, 3>(a, W, ldb, b_nk, K, col0, R, e, st);
-}
 // out[j * ostride] = sum_r X[r, x0] Y[r, j], j < NY
 template <class XOp, class YOp>
 int launch_tn_edge(const XOp& x, const YOp& y, int x0, int NY, long R, float* part, float* out, int ostride, hipStream_t st) {
   const int chunks = (int)((R + EDGE_CHUNK_ROWS - 1) / EDGE_CHUNK_ROWS);
-  gemm_tn_edge_kernel<XOp, YOp><<<dim3(obman_cdiv(NY, 256), chunks), 256, 0, st>>>(x, y, x0, NY, (int)R, EDGE_CHUNK_ROWS, part);
+  gemm_tn_edge_kernel<XOp, YOp><<<dim3(obman_cdiv(NY, EDGE_J), chunks), 256, 0, st>>>(x, y, x0, NY, (int)R, EDGE_CHUNK_ROWS, part);
   OBMAN_LAUNCH_CHECK();
   reduce_edge_kernel<<<obman_cdiv(NY, 256), 256, 0, st>>>(part, chunks, NY, ostride, out);
   OBMAN_LAUNCH_CHECK();
@@ -1759,16 +1676,11 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
   double* moments = reinterpret_cast<double*>(ws + w.moments);
   {  // h2 = W2 relu(bn1(h1)) + b2
     AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1, d.ps};
-    const int ex = edge_ki(d.C1) ? edge_of(d.C2) : 0;  // 257 = 256 + 1: the last channel goes to the edge kernel
     EpiStoreImpl e;
-    e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2 - ex;
+    e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
     e.mstride = d.C2;
-    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2 - ex, d.R, e, st);
+    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
     if (rc) return rc;
-    if (ex) {
-      const ColEpi ce{ws + w.H2, d.ld2, 0, p->b2, nullptr, nullptr, nullptr, nullptr, nullptr, tr ? moments : nullptr, d.C2};
-      if ((rc = launch_cols<AGridFeat>(a, p->w2, d.C1, 1, d.C1, d.C2 - ex, ex, d.R, ce, st))) return rc;
-    }
     const double* mom = moments;
     int mrows = d.rb;
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C2 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
@@ -1833,23 +1745,14 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
     {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
       ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
-      const int ex = edge_of(d.C2);  // the 257th input channel: one extra column of gW3
-      if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2 - ex, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
-      for (int j = 0; j < ex; ++j)
-        if ((rc = launch_tn_edge<ABnRelu, AGradH3>(a2, gh3, d.C2 - ex + j, d.C3, d.R, ws2 + v.tnx, g->w3 + d.C2 - ex + j, d.C2, st))) return rc;
+      if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
     }
     {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
       e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
       e.Gx = e.Fx = e.gamma = e.beta = nullptr; e.N = d.N; e.ps = 0; e.sstride = d.C2;
-      const int ex = edge_ki(d.C3) ? edge_of(d.C2) : 0;
-      e.Nc = d.C2 - ex;
-      if ((rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2 - ex, d.R, e, st))) return rc;
-      if (ex) {
-        const ColEpi ce{ws2 + v.GY2, d.ld2, 1, nullptr, ws + w.H2, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, sums, d.C2};
-        if ((rc = launch_cols<AGradH3>(gh3, p->w3, d.C2, 0, d.C3, d.C2 - ex, ex, d.R, ce, st))) return rc;
-      }
+      if ((rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st))) return rc;
     }
     sp = sums;
     srows = d.rb;
