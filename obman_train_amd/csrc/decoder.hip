@@ -159,7 +159,7 @@ struct EpiStore {  // C[r, n] = acc + bias[n]; optional fp64 column moments (sum
   const float* bias;
   double* moments;  // [row_blocks][mstride][2] or null
   int ldc, R, Nc;
-  int mstride;      // channels per row block in `moments` (>= Nc: the edge kernel fills the columns beyond the tile grid)
+  int mstride;      // channels per row block in `moments` (>= Nc)
 };
 struct EpiMaskStats {  // C = acc * (y > 0); per row-block column sums S1 = sum(C), S2 = sum(C * xhat)
   float* C;
@@ -525,66 +525,6 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
       const int m = bm0 + wm * 64 + t * 32 + acc_row(reg, lane);
       if (m < M && col < Nc) dst[(size_t)m * Nc + col] = t == 0 ? acc0[reg] : acc1[reg];
     }
-}
-
-// ------------------------------------------------------------------------------------------------ edge channels
-// 257 = 4 x 64 + 1 and 515 = 8 x 64 + 3.  On the 64-wide tile grid gW2 [257 x 515] needs 3 x 9 = 27 output tiles of which 11
-// hold one row or three columns; the tile kernel therefore covers [256 x 512] (16 tiles: 244 -> 146 us at configs[1]) and this
-// VALU kernel adds the 257th row and the last three columns - skinny products are bandwidth / latency work, not matrix-pipe
-// work.  (The same split for the rows GEMMs h2 / gy2 and for gW3 was measured and dropped: there the extra pass over the
-// regenerated operand costs what the saved column block did - profiles/r02_kernels.md.)
-//
-// part[chunk][j] = sum_{r in chunk} X[r, x0] * Y[r, j], j < NY.  Block = 32 consecutive j x 8 row slices (row r of slice s:
-// rbeg + s + 8 i), four independent rows in flight per thread; the slices are combined through LDS in slice order.
-constexpr int EDGE_J = 32, EDGE_S = 8;
-template <class XOp, class YOp>
-__global__ __launch_bounds__(256) void gemm_tn_edge_kernel(XOp xop, YOp yop, int x0, int NY, int R, int rows_per_chunk, float* __restrict__ part) {
-  const int jl = threadIdx.x & (EDGE_J - 1), sl = threadIdx.x / EDGE_J;
-  const int j = blockIdx.x * EDGE_J + jl, jc = j < NY ? j : 0;
-  const int rbeg = blockIdx.y * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
-  const typename XOp::KC kx = xop.kc(x0);
-  const typename YOp::KC ky = yop.kc(j < NY ? j : (1 << 30));  // ok = false beyond NY: contributes zeros
-  const int hx = rbeg / rows_N(xop), hy = rbeg / rows_N(yop);
-  float acc0 = 0.f, acc1 = 0.f;
-  for (int r = rbeg + sl; r < rend; r += 4 * EDGE_S) {
-    typename XOp::Row rx[4];
-    typename YOp::Row ry[4];
-    typename XOp::Raw ax[4];
-    typename YOp::Raw ay[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rr = r + u * EDGE_S < rend ? r + u * EDGE_S : 0x7ffffff0;  // row() turns rows >= R into "not ok" (zeros)
-      rx[u] = xop.row(rr, hx);
-      ry[u] = yop.row(rr, hy);
-      ax[u] = xop.raw(rx[u], x0);
-      ay[u] = yop.raw(ry[u], jc);
-    }
-    acc0 = __fmaf_rn(xop.fin(rx[0], kx, ax[0]), yop.fin(ry[0], ky, ay[0]), acc0);
-    acc1 = __fmaf_rn(xop.fin(rx[1], kx, ax[1]), yop.fin(ry[1], ky, ay[1]), acc1);
-    acc0 = __fmaf_rn(xop.fin(rx[2], kx, ax[2]), yop.fin(ry[2], ky, ay[2]), acc0);
-    acc1 = __fmaf_rn(xop.fin(rx[3], kx, ax[3]), yop.fin(ry[3], ky, ay[3]), acc1);
-  }
-  __shared__ float red[EDGE_S][EDGE_J];
-  red[sl][jl] = acc0 + acc1;
-  __syncthreads();
-  if (sl == 0 && j < NY) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < EDGE_S; ++k) s += red[k][jl];
-    part[(size_t)blockIdx.y * NY + j] = s;
-  }
-}
-// out[j * ostride] = sum_c part[c][j]   (chunk order; four partial sums per thread keep four loads in flight)
-__global__ __launch_bounds__(256) void reduce_edge_kernel(const float* __restrict__ part, int chunks, int NY, int ostride, float* __restrict__ out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= NY) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int c = 0;
-  for (; c + 3 < chunks; c += 4) {
-    s0 += part[(size_t)c * NY + j]; s1 += part[(size_t)(c + 1) * NY + j]; s2 += part[(size_t)(c + 2) * NY + j]; s3 += part[(size_t)(c + 3) * NY + j];
-  }
-  for (; c < chunks; ++c) s0 += part[(size_t)c * NY + j];
-  out[(size_t)j * ostride] = (s0 + s1) + (s2 + s3);
 }
 
 // out[i] = scale * sum_c part[c][i]  (fixed chunk order)
@@ -1325,11 +1265,7 @@ Dims dims_of(const obman_pointgen_params* p) {
 }
 constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 blocks at 64 x 642 points)
 constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gradient GEMMs
-constexpr int EDGE_CHUNK_ROWS = 1024;  // rows per block of the edge-channel weight-gradient kernel
 
-// ---- edge channels (see gemm_cols_kernel / gemm_tn_edge_kernel): a layer width of 64 q + 1 or 64 q + 3 is split into the tile grid's
-// 64 q columns and 1 / 3 edge channels; anything else stays on the tile grid
-inline int edge_of(int n) { const int r = n % BN; return (n > BN && (r == 1 || r == 3)) ? r : 0; }
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
   long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
@@ -1387,7 +1323,7 @@ L1Geo l1_geo(const Dims& d) {
   return g;
 }
 struct BwdWs {
-  long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, Ppre, dF, dG, seg, segw, tn, tnx, wt2, wt3, total;
+  long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, Ppre, dF, dG, seg, segw, tn, wt2, wt3, total;
   int chunks;
 };
 BwdWs bwd_ws(const Dims& d) {
@@ -1421,15 +1357,11 @@ BwdWs bwd_ws(const Dims& d) {
       const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * wide_wn(Nc) : BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
     };
-    // fp32 flavour: the tile kernels see the 64-aligned parts only (edge channels go to gemm_tn_edge_kernel) - the chunk
-    // count depends on the tile count, so the sizes must be those of the launches
-    const int e2 = d.bf16 ? 0 : edge_of(d.C2), e1 = d.bf16 ? 0 : edge_of(d.C1);
-    long a = need(d.C3, d.C2, d.R), b = need(d.C2 - e2, d.C1 - e1, d.R), c = need(d.C1, d.C1 - 3, d.B);
+    long a = need(d.C3, d.C2, d.R), b = need(d.C2, d.C1, d.R), c = need(d.C1, d.C1 - 3, d.B);
     if (b > a) a = b;
     if (c > a) a = c;
     w.tn = take(a);
   }
-  w.tnx = take(d.bf16 ? 0 : ((d.R + EDGE_CHUNK_ROWS - 1) / EDGE_CHUNK_ROWS) * (long)d.C1);  // edge-channel partials of the weight gradients
   w.wt2 = take(d.bf16 ? ((long)d.C1 * kpad(d.C2) + 1) / 2 : 0);  // bf16 [C1][kpad(C2)] image of W2^T (dA GEMM of layer 2)
   w.wt3 = take(d.bf16 ? ((long)d.C2 * kpad(d.C3) + 1) / 2 : 0);
   w.total = o;
@@ -1452,16 +1384,6 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part, xcd_aware());
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
-  OBMAN_LAUNCH_CHECK();
-  return 0;
-}
-// out[j * ostride] = sum_r X[r, x0] Y[r, j], j < NY
-template <class XOp, class YOp>
-int launch_tn_edge(const XOp& x, const YOp& y, int x0, int NY, long R, float* part, float* out, int ostride, hipStream_t st) {
-  const int chunks = (int)((R + EDGE_CHUNK_ROWS - 1) / EDGE_CHUNK_ROWS);
-  gemm_tn_edge_kernel<XOp, YOp><<<dim3(obman_cdiv(NY, EDGE_J), chunks), 256, 0, st>>>(x, y, x0, NY, (int)R, EDGE_CHUNK_ROWS, part);
-  OBMAN_LAUNCH_CHECK();
-  reduce_edge_kernel<<<obman_cdiv(NY, 256), 256, 0, st>>>(part, chunks, NY, ostride, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -1762,15 +1684,10 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     OBMAN_LAUNCH_CHECK();
     AGradH gh2{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, R, d.C2};
     AGridFeat a1{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, R, d.C1, d.ps};
-    {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c]: 256 x 512 on the tile grid, the 257th row and the last three columns on the edge kernel
-      const int em = edge_of(d.C2), en = edge_of(d.C1);
-      if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2 - em, d.C1 - en, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
-      for (int i = 0; i < em; ++i)  // rows C2-em .. C2-1, every column
-        if ((rc = launch_tn_edge<AGradH, AGridFeat>(gh2, a1, d.C2 - em + i, d.C1, d.R, ws2 + v.tnx, g->w2 + (size_t)(d.C2 - em + i) * d.C1, 1, st)))
-          return rc;
-      for (int j = 0; j < en; ++j)  // columns C1-en .. C1-1 of the tile-grid rows
-        if ((rc = launch_tn_edge<AGridFeat, AGradH>(a1, gh2, d.C1 - en + j, d.C2 - em, d.R, ws2 + v.tnx, g->w2 + d.C1 - en + j, d.C1, st))) return rc;
-    }
+    // gW2[o,c] = sum_r gh2[r,o] a1[r,c].  (Tried in r02 and dropped: [256 x 512] on the tile grid + the 257th row and the last
+    // three columns on VALU edge kernels - the tile kernel went 244 -> 146 us, the extra passes over the regenerated operands
+    // cost 180 us; profiles/r02_kernels.md.)
+    if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
     {  // gy1 = (gh2 W2) * (y1 > 0)
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
