@@ -47,6 +47,9 @@ def parse():
                     help="upper bound on the untimed, REPORTED precondition steps run before --warmup (MIOpen find, lazy "
                          "module loads, allocator growth, clock ramp); 0 disables the phase")
     ap.add_argument("--trace", default=None, help="write per-step host/GPU times of every phase to this JSON file")
+    ap.add_argument("--deterministic-convs", action="store_true",
+                    help="experiment: torch.backends.cudnn.deterministic = True (MIOpen solutions without atomics: no output "
+                         "zeroing launches for split-K weight gradients, run-to-run identical bits)")
     return ap.parse_args()
 
 
@@ -366,6 +369,8 @@ def main():
     import warnings
     warnings.simplefilter("ignore")
     torch.backends.cudnn.benchmark = True
+    if args.deterministic_convs:
+        torch.backends.cudnn.deterministic = True
 
     from obman_train_amd import _lib
     from obman_train_amd.dp import GradientBuckets, broadcast_parameters
@@ -506,7 +511,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": describe_workload(args, cfg, n_pred, n_gt),
                        "name": args.config, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
-                       "parallelism": "dp%d" % world, "final_loss": loss_val},
+                       "parallelism": "dp%d" % world, "final_loss": loss_val,
+                       "deterministic_convs": bool(args.deterministic_convs)},
             "roofline": roof,
             "decoder_roofline": decoder,
         }

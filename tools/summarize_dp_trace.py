@@ -6,6 +6,11 @@ import sys
 from collections import defaultdict
 
 
+def is_rccl(name):
+    n = name.lower()
+    return ("nccl" in n or "rccl" in n or "onerankreduce" in n) and "rocclr" not in n
+
+
 def main(path):
     rows = list(csv.DictReader(open(path)))
     if not rows:
@@ -23,11 +28,11 @@ def main(path):
     rccl = []
     other = []
     for q, ks in sorted(by_q.items(), key=lambda kv: -len(kv[1])):
-        n_rccl = [k for k in ks if "ccl" in k[2].lower()]
+        n_rccl = [k for k in ks if is_rccl(k[2])]
         names = sorted({k[2][:48] for k in ks})[:3]
         print("| %s | %d | %.2f | %d | %s |" % (q, len(ks), sum(e - s for s, e, _ in ks) / 1e6, len(n_rccl), "; ".join(names)))
         rccl += n_rccl
-        other += [k for k in ks if "ccl" not in k[2].lower()]
+        other += [k for k in ks if not is_rccl(k[2])]
     if not rccl:
         print("\nno RCCL kernels found in the trace")
         return
@@ -45,7 +50,8 @@ def main(path):
     for s, e, n in rccl:
         names[n[:80]][0] += 1
         names[n[:80]][1] += e - s
-    print("\nRCCL kernels: %d launches, %.3f ms total; %.1f %% of that time overlaps a compute kernel of another stream/queue.\n"
+    print("\nRCCL kernels (a 1-rank group reduces with `oneRankReduce`, a copy-like kernel; N ranks run the ring kernels in the same "
+          "place): %d launches, %.3f ms total; %.1f %% of that time overlaps a compute kernel of another stream.\n"
           % (len(rccl), tot / 1e6, 100.0 * min(ov, tot) / max(tot, 1)))
     for n, (c, t) in sorted(names.items(), key=lambda kv: -kv[1][1]):
         print("* `%s` x %d, avg %.1f us" % (n, c, t / c / 1e3))

@@ -1,7 +1,8 @@
 """rocprofv3 ``*_kernel_stats.csv`` -> committed markdown summary: every obman HIP kernel plus the top-N others, per step.
 
-    python tools/summarize_rocprof.py gpurun_out/r01f_c2_kernel_stats.csv profiles/r01f_c2_kernel_stats.md 110 "command line"
-(110 = steps + warm-up launches of the profiled bench run; MIOpen's naive_conv find-phase kernels are excluded)"""
+    python tools/summarize_rocprof.py gpurun_out/r02_c2_kernel_stats.csv profiles/r02_c2_kernel_stats.md auto "command line"
+(steps: number of train steps the profiled process ran - precondition, warm-up, timed and PCIe-probe steps all count;
+"auto" reads it off a once-per-step kernel; MIOpen's naive_conv find-phase kernels are excluded)"""
 import csv
 import sys
 
@@ -9,9 +10,11 @@ OURS = ("pairmin", "rowmean2", "mano_", "contains_kernel", "contact_", "dec::", 
         "warp_kernel", "mean_kernel")
 
 
-def main(src, dst, steps="1", cmd="", top=30):
-    steps = float(steps)
+def main(src, dst, steps="auto", cmd="", top=30):
     rows = [r for r in csv.DictReader(open(src)) if "naive_conv" not in r["Name"]]
+    if steps == "auto":  # train steps executed by the profiled process = launches of a once-per-step kernel (MANO forward)
+        steps = max([float(r["Calls"]) for r in rows if "mano_fwd_kernel" in r["Name"]] or [1.0])
+    steps = float(steps)
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
     ours = [r for r in rows if any(k in r["Name"] for k in OURS)]
     others = [r for r in rows if r not in ours]
