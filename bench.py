@@ -365,7 +365,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        from obman_train_amd.dp import init_rccl
+
+        init_rccl(dev, rank=rank, world_size=world)  # RCCL on a high-priority stream (own hardware queue)
     import warnings
     warnings.simplefilter("ignore")
     torch.backends.cudnn.benchmark = True

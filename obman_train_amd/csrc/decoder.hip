@@ -1260,6 +1260,10 @@ Dims dims_of(const obman_pointgen_params* p) {
   d.R = (long)d.B * d.N;
   d.rb = (int)((d.R + BM - 1) / BM);
   d.bf16 = p->mfma_bf16 ? 1 : 0;
+  if (d.bf16) {  // the layer-2 GEMM of the bf16 flavour runs on (8 samples x 16 vertices) row tiles: a few more blocks
+    const int tb = ((d.N + 15) / 16) * ((d.B + 7) / 8);
+    if (tb > d.rb) d.rb = tb;
+  }
   d.ps = p->grid_per_sample ? 1 : 0;
   return d;
 }
@@ -1284,27 +1288,28 @@ FwdWs fwd_ws(const Dims& d) {
   w.total = o;
   return w;
 }
-// rows per split-K chunk.  fp32 kernel (256-thread blocks, 3 per CU): tiles x chunks covers the chip ~4x, chunk count a
-// multiple of 8 (whole chunks are dealt to the 8 XCDs), never below 128 rows.  bf16 kernel (512-thread blocks, ONE per CU,
-// 64-row k-tiles): tiles x chunks <= 512 = two full rounds of the 256 CUs - a grid of 528 blocks would run three.
+// rows per split-K chunk of the fp32 weight-gradient kernel.  768 block slots (256 CUs x 3 blocks of 49.7 KB LDS): aim at just
+// under TWO full rounds - 27 tiles x 40 chunks = 1080 blocks ran a full round plus a 41 % one; chunk count a multiple of 8
+// (whole chunks are dealt to the 8 XCDs), never below 128 rows.
 int tn_chunk_rows(int M, int Nc, long R, int bn = BN) {
   const long tiles = (long)((M + BM - 1) / BM) * ((Nc + bn - 1) / bn);
-  long rows;
-  if (bn > BN) {
-    long want = 512 / tiles;
-    if (want < 1) want = 1;
-    rows = (R + want - 1) / want;
-    rows = (rows + BKT - 1) / BKT * BKT;  // whole 64-row k-tiles
-    if (rows < 2 * BKT) rows = 2 * BKT;
-  } else {
-    // 768 block slots (256 CUs x 3 blocks of 49.7 KB LDS): aim at just under TWO full rounds - 27 tiles x 40 chunks = 1080
-    // blocks ran a full round plus a 41 % one
-    long want = (2 * 768 / tiles) / 8 * 8;
-    if (want < 8) want = 8;
-    rows = (R + want - 1) / want;
-    if (rows < 128) rows = 128;
-  }
+  long want = (2 * 768 / tiles) / 8 * 8;
+  if (want < 8) want = 8;
+  long rows = (R + want - 1) / want;
+  if (rows < 128) rows = 128;
   return (int)rows;
+}
+// split-K chunks of the bf16 weight-gradient kernel: output tiles x chunks <= 512 = two full rounds of the 256 CUs (one
+// 512-thread block per CU), at least two k-tiles per chunk
+int tn_bf16_chunks(int M, int Nc, int N, int Bsz, int bn) {
+  const long tiles = (long)((M + BM - 1) / BM) * ((Nc + bn - 1) / bn);
+  const long ntiles = (long)((Bsz + 7) / 8) * ((N + 7) / 8);
+  long want = 512 / tiles;
+  if (want < 1) want = 1;
+  if (want > (ntiles + 1) / 2) want = (ntiles + 1) / 2;
+  if (want < 1) want = 1;
+  const long per = (ntiles + want - 1) / want;
+  return (int)((ntiles + per - 1) / per);
 }
 // l1_reduce geometry: vertex sub-tiles per block such that tiles x sample-groups x channel-tiles ~ 1024 blocks
 struct L1Geo { int S, tiles, groups; };
@@ -1354,7 +1359,8 @@ BwdWs bwd_ws(const Dims& d) {
   }
   {  // split-K partials: the largest of the three weight-gradient products
     auto need = [&](int M, int Nc, long R) {
-      const int rows = tn_chunk_rows(M, Nc, R, d.bf16 ? 64 * wide_wn(Nc) : BN);
+      if (d.bf16 && R == d.R) return (long)tn_bf16_chunks(M, Nc, d.N, d.B, 64 * wide_wn(Nc)) * M * Nc;
+      const int rows = tn_chunk_rows(M, Nc, R, BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
     };
     long a = need(d.C3, d.C2, d.R), b = need(d.C2, d.C1, d.R), c = need(d.C1, d.C1 - 3, d.B);
@@ -1403,7 +1409,7 @@ int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowG
     if (err != hipSuccess) return (int)err;
     granted = (int)lds;
   }
-  dim3 grid((unsigned)geo.blocks(), (unsigned)((Nc + 64 * WN - 1) / (64 * WN)));
+  const unsigned grid = (unsigned)geo.blocks() * (unsigned)((Nc + 64 * WN - 1) / (64 * WN));
   rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
   OBMAN_LAUNCH_CHECK();
   return 0;
@@ -1422,10 +1428,11 @@ int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, 
                                     2 * (BM + 64 * WN) * LPT * (int)sizeof(bfraw));
   }();
   if (once) return once;
-  const int chunk_rows = tn_chunk_rows(M, Nc, R, 64 * WN);
-  const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
-  dim3 grid((unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))), (unsigned)chunks);
-  tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, R, N, Bsz, chunk_rows, part);
+  const int chunks = tn_bf16_chunks(M, Nc, N, Bsz, 64 * WN);
+  const long ntiles = (long)((Bsz + 7) / 8) * ((N + 7) / 8);  // k-tiles of (8 samples) x (8 vertices)
+  const int tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
+  const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))) * (unsigned)chunks;
+  tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, R, N, Bsz, tiles_per_chunk, part);
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
   OBMAN_LAUNCH_CHECK();
@@ -1455,15 +1462,18 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
   bfraw* H2 = reinterpret_cast<bfraw*>(ws + w.H2);
   bfraw* H3 = reinterpret_cast<bfraw*>(ws + w.H3);
   const RowGeo geo{(int)d.R, d.N, d.B, 0, 0};
+  // layer 2 regenerates a1 from Gx[n] + Fx[b]: with (8 samples x 16 vertices) row tiles a block touches 16 rows of Gx and 8 of
+  // Fx instead of 128 + 1..2 (2.2 GB of Gx fetches per call at 16 050 points with linear rows, profiles/r02_kernels.md)
+  const RowGeo tiled{(int)d.R, d.N, d.B, (d.N + 15) / 16, 1};
   int rc;
   {  // h2 = W2 relu(bn1(h1)) + b2
     BGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
     EpiStoreB e{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
     if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st))) return rc;
-    if ((rc = launch_rows_bf16<BGridFeat, EpiStoreB>(a, wb, d.C1, d.C2, geo, e, st))) return rc;
+    if ((rc = launch_rows_bf16<BGridFeat, EpiStoreB>(a, wb, d.C1, d.C2, tiled, e, st))) return rc;
     const double* mom = moments;
-    int mrows = d.rb;
+    int mrows = tiled.blocks();
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C2 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(mom, mrows, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
                                                                p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
@@ -1476,7 +1486,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st))) return rc;
     if ((rc = launch_rows_bf16<BBnRelu, EpiStoreB>(a, wb, d.C2, d.C3, geo, e, st))) return rc;
     const double* mom = moments;
-    int mrows = d.rb;
+    int mrows = geo.blocks();
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C3 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(mom, mrows, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
@@ -1530,7 +1540,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     if ((rc = launch_rows_bf16<BGradH3, EpiMaskB>(a, wt, d.C3, d.C2, lin, e, st))) return rc;
   }
   sp = sums;
-  srows = d.rb;
+  srows = lin.blocks();
   if ((rc = pre_reduce<double>(sp, srows, d.C2 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);

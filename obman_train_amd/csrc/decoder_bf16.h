@@ -83,6 +83,15 @@ struct RowGeo {
   __host__ int blocks() const { return tiled ? NG * ((B + 7) / 8) : (int)(((long)R + BM - 1) / BM); }
 };
 
+// Workgroups are dealt to the 8 XCDs (each with its own 4 MB L2) round-robin by linear id.  -> a virtual id such that
+// CONSECUTIVE virtual ids run on the same XCD at about the same time: blocks that read the same operand rows (the column
+// tiles of one row block; the output tiles of one split-K chunk) are given consecutive virtual ids and meet in one L2
+// instead of fetching the rows once per tile from HBM.
+__device__ __forceinline__ int xcd_virtual_id(int lin, int total) {
+  const int q = total >> 3, r = total & 7, x = lin & 7, s = lin >> 3;
+  return x < r ? x * (q + 1) + s : r * (q + 1) + (x - r) * q + s;
+}
+
 // ------------------------------------------------------------------------------------------------ A operands (rows GEMM)
 // A thread of the rows kernel owns ONE row and one 8-wide k chunk per tile (16-byte accesses).  load() only issues loads;
 // fin() turns a landed chunk into 8 operand values using the per-channel constants staged in LDS (kcs = [NC][Kp]).  Columns
@@ -266,7 +275,7 @@ struct EpiStoreB {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, s
       const int i0 = c.wm * 32 + acc_row(2 * p, c.lane);
       int b, n; long r0; bool ok0;
       geo.map(c.blk, i0, b, n, r0, ok0);
-      const bool ok1 = ok0 && r0 + 1 < geo.R;  // linear rows only (the forward GEMMs)
+      const bool ok1 = ok0 && (geo.tiled ? n + 1 < geo.N : r0 + 1 < geo.R);  // row i0 + 1: the next vertex of the same sample
       bfraw* dst = C + (size_t)(odd ? r0 + 1 : r0) * ldc + (cl & ~1);
       const bool okw = odd ? ok1 : ok0;
 #pragma unroll
@@ -412,7 +421,8 @@ struct EpiL1B {
 };
 
 // ------------------------------------------------------------------------------------------------ rows GEMM
-// C[rows x Nc] = Aop[rows x K] * Wb^T, Wb = bf16 [Nc][Kp] image.  grid (row blocks, column blocks of 64*WN).
+// C[rows x Nc] = Aop[rows x K] * Wb^T, Wb = bf16 [Nc][Kp] image.  1-D grid of row blocks x column blocks (of 64*WN); the
+// column blocks of a row block are neighbours on one XCD (xcd_virtual_id).
 template <class AOp, class Epi, int WN>
 __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, RowGeo geo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -423,12 +433,13 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
   bfraw* Bs = As + 2 * BM * LP;                                        // [2][BNW][LP]
   float* kcs = reinterpret_cast<float*>(Bs + 2 * BNW * LP);            // [AOp::NC][Kp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int bn0 = blockIdx.y * BNW;
+  const int ncol = (Nc + BNW - 1) / BNW, vid = xcd_virtual_id(blockIdx.x, gridDim.x), rblk = vid / ncol;
+  const int bn0 = (vid - rblk * ncol) * BNW;
   const int arow = tid >> 2, kq = (tid & 3) * 8;  // A staging: one row, 8 consecutive k
   typename AOp::Row row;
   {
     int b, n; long r; bool ok;
-    geo.map(blockIdx.x, arow, b, n, r, ok);
+    geo.map(rblk, arow, b, n, r, ok);
     row = aop.row(r, b, n, ok);
   }
   aop.stage(kcs, Kp, tid);
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
       }
     }
   }
-  const EpiCtx ctx{(int)blockIdx.x, lane, wm, wn, bn0};
+  const EpiCtx ctx{rblk, lane, wm, wn, bn0};
   epi.template finish<WN>(acc, ctx, geo, smem);
 }
 
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
 // consecutive ROWS of one channel.  A task = (a pair of adjacent channels) x (8 consecutive rows): 4-byte loads of bf16 pairs
 // (8-byte for fp32 sources), coalesced along the channels; the task packs row pairs and writes two 16-byte pieces of the
 // [channel][row] LDS tile.  A: 64 pairs x 8 row groups = one task per thread; B: 32*WN pairs x 8 groups.
-struct TRows {  // the 8 rows of a task: global row r0 .. r0+7, valid below rend; (b, n) of the first row
+struct TRows {  // the 8 rows of a task: global rows r0 .. r0+7 = vertices n .. n+7 of sample b (never across samples), nvalid of them real
   long r0;
   int nvalid, b, n;
 };
@@ -628,36 +639,29 @@ struct TGradH3 {  // gh3 regenerated from the 3-channel output gradient (see BGr
     }
   }
 };
-struct TGridFeat {  // a1 = relu(gamma*(Gx[n]+Fx[b])+beta) from the fp32 factors; rows advance (b, n) with wrap at N
+struct TGridFeat {  // a1 = relu(gamma*(Gx[n]+Fx[b])+beta) from the fp32 factors; a task's 8 rows are 8 vertices of ONE sample
   const float *Gx, *Fx, *gamma, *beta;
   int N, ld, K;
   struct KC { float g0, g1, b0, b1; };
-  struct Raw { float2 gx[8]; float2 fa, fb; };  // Fx of the first row's sample and of the next sample (a task spans <= 2 samples)
+  struct Raw { float2 gx[8]; float2 f; };
   __device__ KC kc(int c) const { const bool a = c < K, b = c + 1 < K; return KC{a ? gamma[c] : 0.f, b ? gamma[c + 1] : 0.f, a ? beta[c] : 0.f, b ? beta[c + 1] : 0.f}; }
-  __device__ void load(Raw& q, const TRows& w, int c, int B) const {
+  __device__ void load(Raw& q, const TRows& w, int c, int) const {
     const int cc = c + 1 < ld ? c : 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int n = w.n + (i < w.nvalid ? i : 0);
-      if (n >= N) n -= N;
-      q.gx[i] = *reinterpret_cast<const float2*>(Gx + (size_t)n * ld + cc);
-    }
-    q.fa = *reinterpret_cast<const float2*>(Fx + (size_t)w.b * ld + cc);
-    q.fb = *reinterpret_cast<const float2*>(Fx + (size_t)(w.b + 1 < B ? w.b + 1 : w.b) * ld + cc);
+    for (int i = 0; i < 8; ++i) q.gx[i] = *reinterpret_cast<const float2*>(Gx + (size_t)(w.n + (i < w.nvalid ? i : 0)) * ld + cc);
+    q.f = *reinterpret_cast<const float2*>(Fx + (size_t)w.b * ld + cc);
   }
-  __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
+  __device__ void fin(const Raw& q, const KC& k, const TRows&, int, float* o0, float* o1) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool next = w.n + i >= N;  // wrapped into the next sample
-      const float fx = next ? q.fb.x : q.fa.x, fy = next ? q.fb.y : q.fa.y;
-      o0[i] = fmaxf(__fmaf_rn(k.g0, q.gx[i].x + fx, k.b0), 0.f);
-      o1[i] = fmaxf(__fmaf_rn(k.g1, q.gx[i].y + fy, k.b1), 0.f);
+      o0[i] = fmaxf(__fmaf_rn(k.g0, q.gx[i].x + q.f.x, k.b0), 0.f);
+      o1[i] = fmaxf(__fmaf_rn(k.g1, q.gx[i].y + q.f.y, k.b1), 0.f);
     }
   }
 };
 
 template <class AOp, class BOp, int WN>
-__global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, int Nc, long R, int N, int Bsz, int rows_per_chunk,
+__global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, int Nc, long R, int N, int Bsz, int tiles_per_chunk,
                                                       float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BNW = 64 * WN, NPB = 32 * WN;     // B channels / channel pairs per block
@@ -665,9 +669,17 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
   bfraw* As = reinterpret_cast<bfraw*>(smem);    // [2][BM][LPT]   (m, r)
   bfraw* Bs = As + 2 * BM * LPT;                 // [2][BNW][LPT]  (n, r)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int mt = (M + BM - 1) / BM;
-  const int bm0 = (blockIdx.x % mt) * BM, bn0 = (blockIdx.x / mt) * BNW;
-  const long rbeg = (long)blockIdx.y * rows_per_chunk, rend = rbeg + rows_per_chunk < R ? rbeg + rows_per_chunk : R;
+  // 1-D grid of (output tiles) x (split-K chunks); the tiles of a chunk are neighbours on one XCD: they contract the same rows
+  const int mt = (M + BM - 1) / BM, ntile = mt * ((Nc + BNW - 1) / BNW);
+  const int vid = xcd_virtual_id(blockIdx.x, gridDim.x), chunk = vid / ntile, tile = vid - chunk * ntile;
+  const int bm0 = (tile % mt) * BM, bn0 = (tile / mt) * BNW;
+  // The contraction runs over the rows in TILES of (8 samples) x (8 consecutive template vertices): k-tile t = (sample group
+  // t / NV8, vertex group t % NV8), row group g of a tile = sample 8*(t / NV8) + g, its 8 rows = the 8 vertices (contiguous in
+  // memory).  The eight groups of a tile therefore share the same eight rows of the layer-1 grid factor Gx (the operand the
+  // weight gradient of layer 2 regenerates a1 from): with plain row order every 64-row tile pulled 64 distinct Gx rows - 6.3 GB
+  // of the 8.5 GB this kernel fetched per call at 16 050 points (PMC, profiles/r02_kernels.md).
+  const int NV8 = (N + 7) / 8, ntiles = ((Bsz + 7) / 8) * NV8;
+  const int tbeg = chunk * tiles_per_chunk, tend = tbeg + tiles_per_chunk < ntiles ? tbeg + tiles_per_chunk : ntiles;
   const int ga = __builtin_amdgcn_readfirstlane(tid >> 6);  // A task: row group = wave, channel pair = lane
   const int ca = bm0 + 2 * lane;
   const typename AOp::KC kca = aop.kc(ca);
@@ -684,29 +696,20 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
   }
   typename AOp::Raw ra;
   typename BOp::Raw rb[BT];
-  // Row cursor of a task: first row of its 8-row group in the current k-tile, and that row's (sample, vertex).  Advanced by one
-  // k-tile (64 rows) per iteration with a wrap at N - no division in the loop.
-  struct Cursor { long pos; int b, n; };
-  auto cursor_at = [&](long r0) {
-    Cursor c;
-    c.pos = r0;
-    const long rc = r0 < R ? r0 : 0;
-    c.b = (int)(rc / N);
-    c.n = (int)(rc - (long)c.b * N);
-    return c;
-  };
+  // Cursor of a task: the tile it will load next, as (sample group, vertex group); advanced by one tile per iteration
+  struct Cursor { int bg, ng; };
+  auto cursor_at = [&](int t) { return Cursor{t / NV8, t % NV8}; };
   auto advance = [&](Cursor& c) {
-    c.pos += BKT;
-    c.n += BKT;
-    while (c.n >= N) { c.n -= N; ++c.b; }
+    if (++c.ng == NV8) { c.ng = 0; ++c.bg; }
   };
-  auto rows_at = [&](const Cursor& c) {
+  auto rows_at = [&](const Cursor& c, int g) {  // the 8 rows of row group g (= sample) of the tile
     TRows w;
-    const long left = rend - c.pos;
-    w.nvalid = left >= 8 ? 8 : (left > 0 ? (int)left : 0);
-    w.r0 = w.nvalid ? c.pos : rbeg;  // a group wholly beyond the chunk re-reads valid rows and is masked to zero
-    w.b = w.nvalid ? c.b : 0;
-    w.n = w.nvalid ? c.n : 0;
+    const int b = c.bg * 8 + g, n0 = c.ng * 8;
+    const int left = N - n0;
+    w.nvalid = b < Bsz ? (left >= 8 ? 8 : (left > 0 ? left : 0)) : 0;
+    w.b = w.nvalid ? b : 0;   // a group beyond the batch re-reads valid rows and is masked to zero
+    w.n = w.nvalid ? n0 : 0;
+    w.r0 = (long)w.b * N + w.n;
     return w;
   };
   // rows i >= nvalid of a packed 8-row strip -> zero (words hold row pairs)
@@ -718,20 +721,17 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
     v.x &= m0; v.y &= m1; v.z &= m2; v.w &= m3;
     return v;
   };
-  Cursor cura = cursor_at(rbeg + ga * 8), curb[BT];
-#pragma unroll
-  for (int j = 0; j < BT; ++j) curb[j] = cursor_at(rbeg + gb[j] * 8);
+  Cursor cur_t = cursor_at(tbeg);
   TRows wa, wb[BT];
-  auto fetch = [&]() {  // loads of the tile the cursors point at; then the cursors move on
+  auto fetch = [&]() {  // loads of the tile the cursor points at; then the cursor moves on
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
-      wb[j] = rows_at(curb[j]);
+      wb[j] = rows_at(cur_t, gb[j]);
       if (tb_ok[j]) bop.load(rb[j], wb[j], cb[j], Bsz);
-      advance(curb[j]);
     }
-    wa = rows_at(cura);
+    wa = rows_at(cur_t, ga);
     aop.load(ra, wa, ca, Bsz);
-    advance(cura);
+    advance(cur_t);
   };
   auto stash = [&](int buf) {
     float o0[8], o1[8];
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
   for (int j = 0; j < WN; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const int nk = (int)((rend - rbeg + BKT - 1) / BKT);
+  const int nk = tend > tbeg ? tend - tbeg : 0;
   if (nk > 0) {
     fetch();
     stash(0);
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, i
     if (more) stash(cur ^ 1);
     __syncthreads();
   }
-  float* dst = part + (size_t)blockIdx.y * M * Nc;
+  float* dst = part + (size_t)chunk * M * Nc;
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = bn0 + wn * 32 * WN + j * 32 + (lane & 31);

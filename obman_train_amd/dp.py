@@ -126,6 +126,25 @@ class GradientBuckets:
         self._pending = [len(slots) for _, slots in self.buckets]
 
 
+def init_rccl(device, rank=None, world_size=None):
+    """``init_process_group("nccl")`` (= RCCL) for one process per GPU, with the collectives on a HIGH-PRIORITY stream.
+
+    Why the priority matters here: HIP multiplexes a process's streams onto a few hardware queues and kernels of one
+    queue run back to back.  With the default (normal-priority) pool stream the RCCL kernels of this workload landed on
+    the SAME hardware queue as the training stream (rocprofv3 ``Queue_Id``, ``profiles/r02_force_dist_trace.md``): every
+    all-reduce kernel was serialised with ResNet's backward - zero overlap however early its bucket was ready.  A
+    high-priority stream gets a queue of its own, and the few-workgroup ring kernels are scheduled ahead of the
+    chip-filling convolution kernels instead of behind them."""
+    import os
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by this driver for RCCL across processes
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    kw = {}
+    if rank is not None:
+        kw.update(rank=rank, world_size=world_size)
+    dist.init_process_group("nccl", device_id=device, pg_options=opts, **kw)
+
+
 def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank ``src``'s weights and buffers."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -27,7 +27,9 @@ def nccl_group():
     os.environ["MASTER_PORT"] = str(_free_port())
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+    from obman_train_amd.dp import init_rccl
+
+    init_rccl(dev, rank=0, world_size=1)
     try:
         yield dist
     finally:
