@@ -201,8 +201,8 @@ struct Tiles {
 };
 
 // C[R x Nc] = Aop[R x K] * B, B given either as W[n][k] (B_NK, ldb = row stride of W) or W[k][n] (B_KN).
-template <class AOp, bool B_NK, class Epi>
-__global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __restrict__ Bw, int ldb, int K, int Nc, Epi epi, int variant) {
+template <class AOp, bool B_NK, class Epi, int DBG = 0>  // DBG: ablation builds only (-DOBMAN_ABLATION), wrong results by design
+__global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* __restrict__ Bw, int ldb, int K, int Nc, Epi epi, int variant) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Tiles& T = *reinterpret_cast<Tiles*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -243,8 +243,13 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
   };
   auto stash_part = [&](int buf, int k0, int q) {  // q = 0..7: two A elements + one B element
     const int p = q >> 1, j0 = (q & 1) * 2;
-    T.As[buf][kq + j0][rm + 32 * p] = aop.fin(rows[p], kcur[j0], ra[p][j0]);
-    T.As[buf][kq + j0 + 1][rm + 32 * p] = aop.fin(rows[p], kcur[j0 + 1], ra[p][j0 + 1]);
+    if (DBG & 1) {  // no operand transform: the first loaded word as it is
+      T.As[buf][kq + j0][rm + 32 * p] = *reinterpret_cast<const float*>(&ra[p][j0]);
+      T.As[buf][kq + j0 + 1][rm + 32 * p] = *reinterpret_cast<const float*>(&ra[p][j0 + 1]);
+    } else {
+      T.As[buf][kq + j0][rm + 32 * p] = aop.fin(rows[p], kcur[j0], ra[p][j0]);
+      T.As[buf][kq + j0 + 1][rm + 32 * p] = aop.fin(rows[p], kcur[j0 + 1], ra[p][j0 + 1]);
+    }
     if (B_NK) {
       const int n = bn0 + (tid >> 5) + 8 * q, k = k0 + ak;
       T.Bs[buf][ak][(tid >> 5) + 8 * q] = (n < Nc && k < K) ? rb[q] : 0.f;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
   __syncthreads();
   for (int kt = 0; kt + 1 < nk; ++kt) {  // every tile but the last: the next tile's transform rides behind the MFMAs
     const int cur = kt & 1;
-    fetch((kt + 1) * BK);
+    if (!(DBG & 4)) fetch((kt + 1) * BK);
     // The next tile's operand transform + LDS writes are spread over MFMA steps 4..11 (one eighth each): the loads were
     // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
     // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
@@ -297,13 +302,13 @@ __global__ __launch_bounds__(NT) void gemm_rows_kernel(AOp aop, const float* __r
 #pragma unroll
       for (int step = 0; step < BK / 2; ++step) {
         const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
-        const float nb = T.Bs[cur][kn + kh][bcol];
-        const float na0 = T.As[cur][kn + kh][arow];
-        const float na1 = T.As[cur][kn + kh][arow + 32];
+        const float nb = (DBG & 8) ? fb : T.Bs[cur][kn + kh][bcol];
+        const float na0 = (DBG & 8) ? fa0 : T.As[cur][kn + kh][arow];
+        const float na1 = (DBG & 8) ? fa1 : T.As[cur][kn + kh][arow + 32];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
         fb = nb; fa0 = na0; fa1 = na1;
-        if (step >= 4 && step < 12) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
+        if (!(DBG & 2) && step >= 4 && step < 12) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
       }
     } else {
 #pragma unroll
@@ -1229,14 +1234,34 @@ __global__ __launch_bounds__(256) void gfeat_kernel(const float* __restrict__ dF
   g_feat[(size_t)b * Cf + k] = (a0 + a1) + (a2 + a3);
 }
 
-// out[m*ldo + off + n] = sum_c part[c][m][n]   (fixed chunk order)
+// out[m*ldo + off + n] = sum_c part[c][m][n].  Fixed summation order (run-to-run reproducible): wave q of a block sums the chunks
+// q, q+4, q+8, ... of 64 consecutive elements, eight independent loads in flight at a time, and the four partial sums are
+// combined as ((s0 + s1) + s2) + s3.  (One thread per element walking all chunks with a load -> add dependency per chunk took
+// 33 us for 56 chunks x 132 k elements = 30 MB: ~0.9 TB/s, latency-bound.)
+constexpr int RTN_ELEMS = 64;
 __global__ __launch_bounds__(256) void reduce_tn_kernel(const float* __restrict__ part, int chunks, int M, int Nc, int ldo, int off,
                                                         float* __restrict__ out) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)M * Nc) return;
+  __shared__ float red[3][RTN_ELEMS];
+  const int q = threadIdx.x >> 6;
+  const long total = (long)M * Nc, i = (long)blockIdx.x * RTN_ELEMS + (threadIdx.x & 63);
+  const bool ok = i < total;
+  const float* src = part + (ok ? i : 0);
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * M * Nc + i];
-  out[(size_t)(i / Nc) * ldo + off + (i % Nc)] = s;
+  int c = q;
+  for (; c + 28 < chunks; c += 32) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(c + 4 * j) * total];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; c < chunks; c += 4) s += src[(size_t)c * total];
+  if (q) red[q - 1][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && ok) {
+    s = ((s + red[0][threadIdx.x]) + red[1][threadIdx.x]) + red[2][threadIdx.x];
+    out[(size_t)(i / Nc) * ldo + off + (i % Nc)] = s;
+  }
 }
 
 }  // namespace dec
@@ -1377,8 +1402,14 @@ BwdWs bwd_ws(const Dims& d) {
 template <class AOp, bool B_NK, class Epi>
 int launch_rows(const AOp& a, const float* W, int ldb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
   dim3 grid(xcd_grid((R + BM - 1) / BM, (Nc + BN - 1) / BN));
-  static const int variant = [] { const char* v = getenv("OBMAN_GEMM_VARIANT"); return v ? atoi(v) : 0; }();  // ablation knob
-  gemm_rows_kernel<AOp, B_NK, Epi><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e, variant | (xcd_aware() ? 0 : 8));
+#ifdef OBMAN_ABLATION  // tools/ablate_gemm.sh: which resource bounds the main loop?  (results are wrong in every DBG != 0 build)
+  static const int dbg = [] { const char* v = getenv("OBMAN_GEMM_DBG"); return v ? atoi(v) : 0; }();
+#define OBMAN_DBG_CASE(D) \
+  if (dbg == D) { gemm_rows_kernel<AOp, B_NK, Epi, D><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e, xcd_aware() ? 0 : 8); OBMAN_LAUNCH_CHECK(); return 0; }
+  OBMAN_DBG_CASE(1) OBMAN_DBG_CASE(2) OBMAN_DBG_CASE(3) OBMAN_DBG_CASE(4) OBMAN_DBG_CASE(6) OBMAN_DBG_CASE(8) OBMAN_DBG_CASE(10) OBMAN_DBG_CASE(14)
+#undef OBMAN_DBG_CASE
+#endif
+  gemm_rows_kernel<AOp, B_NK, Epi><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e, xcd_aware() ? 0 : 8);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -1389,7 +1420,7 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   dim3 grid(xcd_grid(chunks, ((M + BM - 1) / BM) * ((Nc + BN - 1) / BN)));
   gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part, xcd_aware());
   OBMAN_LAUNCH_CHECK();
-  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
+  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -1434,7 +1465,7 @@ int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, 
   const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))) * (unsigned)chunks;
   tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, R, N, Bsz, tiles_per_chunk, part);
   OBMAN_LAUNCH_CHECK();
-  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, 256), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
+  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
