@@ -17,6 +17,7 @@
 // leaves the VALU free for the fused loaders/epilogues.  Tile: 128 x 64 x 32, 4 waves (2x2), each wave
 // 64 x 32 = two 32x32 accumulators; LDS tiles k-major with +1 padding (conflict-free b32 reads/writes).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "prof.h"
@@ -194,11 +195,23 @@ inline int xcd_aware() {
 }
 inline unsigned xcd_grid(long groups, int members) { return (unsigned)(((groups + 7) / 8) * 8 * members); }
 
-// LDS tiles (k-major, +1 pad): As[buf][k][m], Bs[buf][k][n]
+// LDS tiles (k-major, +1 pad): As[buf][k][m], Bs[buf][k][n]; Sa / Sb: one extra operand column each (the "side" products)
 struct Tiles {
   float As[2][BK][BM + 1];
   float Bs[2][BK][BN + 1];
+  float Sa[2][BK], Sb[2][BK];
 };
+
+// 257 = 4 x 64 + 1 and 515 = 8 x 64 + 3: padding the output to whole 64-column tiles would spend a fifth (a ninth) of the
+// blocks - and at 64 x 642 points a whole third block round - on one (three) live columns.  Instead the tiled dimension is cut
+// to its whole tiles and each of the first `side` members of a group computes ONE leftover column beside its MFMAs, on the
+// VALU, from the operand tile that is in LDS anyway: 4096 FMAs per k-tile and block against 262 144 on the matrix pipe.
+struct TileSplit { int tiles, side; };
+__host__ __device__ inline TileSplit tile_split(int n, int tile) {
+  const int full = n / tile, tail = n - full * tile;
+  if (full >= 1 && tail >= 1 && tail <= 3 && tail <= full) return TileSplit{full, tail};
+  return TileSplit{(n + tile - 1) / tile, 0};
+}
 
 // C[R x Nc] = Aop[R x K] * B, B given either as W[n][k] (B_NK, ldb = row stride of W) or W[k][n] (B_KN).
 template <class AOp, bool B_NK, class Epi, int DBG = 0>  // DBG: ablation builds only (-DOBMAN_ABLATION), wrong results by design
@@ -206,9 +219,12 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Tiles& T = *reinterpret_cast<Tiles*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const XcdOrder bo = xcd_order(blockIdx.x, (Nc + BN - 1) / BN, !(variant & 8));  // group = row block, member = column block
+  const TileSplit cs = tile_split(Nc, BN);
+  const XcdOrder bo = xcd_order(blockIdx.x, cs.tiles, !(variant & 8));  // group = row block, member = column block
   if ((long)bo.group * BM >= aop.R) return;
   const int bm0 = bo.group * BM, bn0 = bo.member * BN;
+  const bool side = bo.member < cs.side;       // this block also owns output column sc (block-uniform)
+  const int sc = cs.tiles * BN + (side ? bo.member : 0);
 
   // A staging: thread = 4 consecutive k (one 16-byte load per source array) x 4 rows (rm, rm+32, rm+64, rm+96)
   const int kq = (tid & 7) * 4, rm = tid >> 3;
@@ -220,9 +236,13 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
   }
   typename AOp::Raw ra[4][4];
   typename AOp::KC kcur[4];
-  float rb[8];
+  float rb[8], rws = 0.f;
   const int ak = tid & 31;  // B staging keeps the scalar mapping (weight rows are not 16-byte aligned)
   auto fetch = [&](int k0) {  // loads only: nothing here consumes a loaded value
+    if (side) {  // the side column's weights of this k-tile (every lane loads, lanes 0..31 of wave 0 stage them)
+      const int k = k0 + ak < K ? k0 + ak : 0;
+      rws = B_NK ? Bw[(size_t)sc * ldb + k] : Bw[(size_t)k * ldb + sc];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) kcur[j] = aop.kc(k0 + kq + j);
 #pragma unroll
@@ -241,8 +261,13 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
       }
     }
   };
+  const bool side_stage = side && tid < BK;
+  auto stash_side = [&](int buf, int k0) {
+    if (side_stage) T.Sb[buf][tid] = k0 + tid < K ? rws : 0.f;
+  };
   auto stash_part = [&](int buf, int k0, int q) {  // q = 0..7: two A elements + one B element
     const int p = q >> 1, j0 = (q & 1) * 2;
+    if (q == 0) stash_side(buf, k0);
     if (DBG & 1) {  // no operand transform: the first loaded word as it is
       T.As[buf][kq + j0][rm + 32 * p] = *reinterpret_cast<const float*>(&ra[p][j0]);
       T.As[buf][kq + j0 + 1][rm + 32 * p] = *reinterpret_cast<const float*>(&ra[p][j0 + 1]);
@@ -259,6 +284,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
     }
   };
   auto stash = [&](int buf, int k0) {
+    stash_side(buf, k0);
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -285,37 +311,46 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
   // other blocks of the CU.
   const bool live = bn0 + wn * 32 < Nc;
   const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
+  // side product: thread = (row srow, k half skh) of the block's 128 x 32 operand tile, one FMA per MFMA step
+  const int srow = tid & (BM - 1), skh = (tid >> 7) * (BK / 2);
+  float sacc = 0.f;
   fetch(0);
   stash(0, 0);
   __syncthreads();
-  for (int kt = 0; kt + 1 < nk; ++kt) {  // every tile but the last: the next tile's transform rides behind the MFMAs
-    const int cur = kt & 1;
-    if (!(DBG & 4)) fetch((kt + 1) * BK);
-    // The next tile's operand transform + LDS writes are spread over MFMA steps 4..11 (one eighth each): the loads were
-    // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
-    // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
-    // (No run-time condition inside the 16 steps: one scheduling region, fragment reads can move ahead of the MFMAs.)
-    if (live) {
-      // fragments are double-buffered in registers: step i+1's LDS reads are issued before step i's MFMAs.  (Running them two
-      // steps ahead behind a sched_barrier changed the waits from lgkmcnt(0) to lgkmcnt(4..8) but not the time: r02 notes.)
-      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
+  auto sweep = [&](auto side_c) {
+    constexpr bool SIDE = decltype(side_c)::value;
+    for (int kt = 0; kt + 1 < nk; ++kt) {  // every tile but the last: the next tile's transform rides behind the MFMAs
+      const int cur = kt & 1;
+      if (!(DBG & 4)) fetch((kt + 1) * BK);
+      // The next tile's operand transform + LDS writes are spread over MFMA steps 4..11 (one eighth each): the loads were
+      // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
+      // pair, so the matrix pipe never waits for a write/barrier phase that all co-resident blocks would hit together.
+      // (No run-time condition inside the 16 steps: one scheduling region, fragment reads can move ahead of the MFMAs.)
+      if (live) {
+        // fragments are double-buffered in registers: step i+1's LDS reads are issued before step i's MFMAs.  (Running them
+        // two steps ahead behind a sched_barrier changed the waits from lgkmcnt(0) to lgkmcnt(4..8) but not the time: r02 notes.)
+        float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
-      for (int step = 0; step < BK / 2; ++step) {
-        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
-        const float nb = (DBG & 8) ? fb : T.Bs[cur][kn + kh][bcol];
-        const float na0 = (DBG & 8) ? fa0 : T.As[cur][kn + kh][arow];
-        const float na1 = (DBG & 8) ? fa1 : T.As[cur][kn + kh][arow + 32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
-        fb = nb; fa0 = na0; fa1 = na1;
-        if (!(DBG & 2) && step >= 4 && step < 12) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
+        for (int step = 0; step < BK / 2; ++step) {
+          const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+          const float nb = (DBG & 8) ? fb : T.Bs[cur][kn + kh][bcol];
+          const float na0 = (DBG & 8) ? fa0 : T.As[cur][kn + kh][arow];
+          const float na1 = (DBG & 8) ? fa1 : T.As[cur][kn + kh][arow + 32];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+          fb = nb; fa0 = na0; fa1 = na1;
+          if (SIDE) sacc = __fmaf_rn(T.As[cur][skh + step][srow], T.Sb[cur][skh + step], sacc);
+          if (!(DBG & 2) && step >= 4 && step < 12) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, (kt + 1) * BK, q);
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, (kt + 1) * BK, q);
+      __syncthreads();
     }
-    __syncthreads();
-  }
+  };
+  if (side) sweep(std::true_type{});
+  else sweep(std::false_type{});
   if (live) {  // last tile: only the k-steps that hold real columns (K = 515 -> 2 of 16, K = 257 -> 1 of 16)
     const int cur = (nk - 1) & 1, steps = (K - (nk - 1) * BK + 1) / 2;
     for (int step = 0; step < steps; ++step) {
@@ -324,12 +359,48 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
     }
   }
+  if (side) {  // last tile of the side column (columns >= K of either operand are staged as zeros)
+    const int cur = (nk - 1) & 1;
+#pragma unroll
+    for (int step = 0; step < BK / 2; ++step) sacc = __fmaf_rn(T.As[cur][skh + step][srow], T.Sb[cur][skh + step], sacc);
+  }
   __syncthreads();
   epi.finish(acc0, acc1, bm0 + wm * 64, bn0 + wn * 32, lane, wm, wn, bo.group, smem);
+  if (side) {  // the two k halves of a row meet in LDS (tiles and the epilogue's scratch are dead), then the column's epilogue
+    float* sred = reinterpret_cast<float*>(smem);
+    __syncthreads();
+    if (tid >= BM) sred[tid - BM] = sacc;
+    __syncthreads();
+    const float v = tid < BM ? sacc + sred[tid] : 0.f;
+    __syncthreads();
+    epi.finish_side(v, bm0 + srow, sc, tid, bo.group, smem);
+  }
 }
 
 // ---- epilogue bodies (members defined here to keep the kernel readable)
+// block sum of (s1, s2) held by threads 0..127 (zeros elsewhere) -> dst[0..1]; every thread of the block calls it
+__device__ __forceinline__ void side_reduce(double s1, double s2, int tid, char* smem, double* dst) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  double* red = reinterpret_cast<double*>(smem);
+  if (tid == 64) { red[0] = s1; red[1] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    dst[0] = s1 + red[0];
+    dst[1] = s2 + red[1];
+  }
+}
 struct EpiStoreImpl : EpiStore {
+  // side column `col` of the block's rows: thread tid < 128 holds the finished dot product of row r
+  __device__ __forceinline__ void finish_side(float acc, int r, int col, int tid, int rblk, char* smem) const {
+    const bool ok = tid < BM && r < R;
+    const float v = acc + (bias ? bias[col] : 0.f);
+    if (ok) C[(size_t)r * ldc + col] = v;
+    if (moments) side_reduce(ok ? (double)v : 0.0, ok ? (double)v * (double)v : 0.0, tid, smem, moments + ((size_t)rblk * mstride + col) * 2);
+  }
   __device__ __forceinline__ void finish(const f32x16& a0, const f32x16& a1, int r0, int c0, int lane, int wm, int wn, int rblk, char* smem) const {
     const int col = c0 + (lane & 31);
     const float bv = (bias && col < Nc) ? bias[col] : 0.f;
@@ -365,6 +436,25 @@ struct EpiStoreImpl : EpiStore {
 };
 
 struct EpiMaskStatsImpl : EpiMaskStats {
+  __device__ __forceinline__ void finish_side(float acc, int r, int col, int tid, int rblk, char* smem) const {
+    const bool ok = tid < BM && r < R;
+    float v = 0.f, xh = 0.f;
+    if (ok) {
+      float y;
+      if (mode == 0) {
+        const float h = H[(size_t)r * ldc + col];
+        y = __fmaf_rn(s[col], h, t[col]);
+        xh = (h - mean[col]) * rstd[col];
+      } else {
+        const int b = r / N, n = r - b * N;
+        xh = Gx[(size_t)(ps ? r : n) * ldc + col] + Fx[(size_t)b * ldc + col];
+        y = __fmaf_rn(gamma[col], xh, beta[col]);
+      }
+      v = y > 0.f ? acc : 0.f;
+      C[(size_t)r * ldc + col] = v;
+    }
+    side_reduce((double)v, (double)v * (double)xh, tid, smem, sums + ((size_t)rblk * sstride + col) * 2);
+  }
   // One 32x32 accumulator tile: C = acc * (y > 0) and this lane's column partials S1 = sum C, S2 = sum C * xhat.
   // The 16 rows a lane holds are r0 + (reg&3) + 8 (reg>>2) + 4 (lane>>5); their (sample, vertex) split advances
   // incrementally from one division per tile.  Partials stay fp32 inside the lane (16 terms), fp64 across lanes/blocks.
@@ -1401,7 +1491,7 @@ BwdWs bwd_ws(const Dims& d) {
 
 template <class AOp, bool B_NK, class Epi>
 int launch_rows(const AOp& a, const float* W, int ldb, int K, int Nc, long R, const Epi& e, hipStream_t st) {
-  dim3 grid(xcd_grid((R + BM - 1) / BM, (Nc + BN - 1) / BN));
+  dim3 grid(xcd_grid((R + BM - 1) / BM, tile_split(Nc, BN).tiles));
 #ifdef OBMAN_ABLATION  // tools/ablate_gemm.sh: which resource bounds the main loop?  (results are wrong in every DBG != 0 build)
   static const int dbg = [] { const char* v = getenv("OBMAN_GEMM_DBG"); return v ? atoi(v) : 0; }();
 #define OBMAN_DBG_CASE(D) \
