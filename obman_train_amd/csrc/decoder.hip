@@ -527,10 +527,25 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Tiles& T = *reinterpret_cast<Tiles*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int mt = (M + BM - 1) / BM, ntile = mt * ((Nc + BN - 1) / BN);
+  // Output rows / columns beyond the whole tiles (M = 257: one row; Nc = 515: three columns) are "side" products on the VALU
+  // (tile_split): tile (mi, nj) also accumulates side row mi < ms.side against its 64 columns and side column nj < ns.side against
+  // its 128 rows - both from the operand tiles it has in LDS plus ONE extra operand column per k-tile - and, when it has both,
+  // their corner element.  257 x 515 is then 2 x 8 = 16 tiles instead of 3 x 9 = 27.
+  const TileSplit ms = tile_split(M, BM), ns = tile_split(Nc, BN);
+  const int mt = ms.tiles, ntile = mt * ns.tiles;
   const XcdOrder bo = xcd_order(blockIdx.x, ntile, order);  // group = row chunk, member = output tile
   if ((long)bo.group * rows_per_chunk >= R) return;
-  const int bm0 = (bo.member % mt) * BM, bn0 = (bo.member / mt) * BN;
+  const int mi = bo.member % mt, nj = bo.member / mt;
+  const int bm0 = mi * BM, bn0 = nj * BN;
+  const bool hasrow = mi < ms.side, hascol = nj < ns.side;  // block-uniform
+  const int m_s = ms.tiles * BM + (hasrow ? mi : 0), n_s = ns.tiles * BN + (hascol ? nj : 0);
+  const bool side_a = hasrow && tid < BK, side_b = hascol && tid >= 64 && tid < 64 + BK;  // who stages Sa[k] / Sb[k], k = tid % 32
+  const typename AOp::KC kcsa = aop.kc(m_s);
+  const typename BOp::KC kcsb = bop.kc(n_s);
+  typename AOp::Row rowsa;
+  typename BOp::Row rowsb;
+  typename AOp::Raw rsa;
+  typename BOp::Raw rsb;
   const int rbeg = bo.group * rows_per_chunk, rend = min(R, rbeg + rows_per_chunk);
   // staging: A tile [32 rows][128 m]: thread = 4 consecutive channels (16-byte loads) x rows (tid>>5) + 8p, p < 4;
   // B tile [32 rows][64 n]: 4 channels x rows (tid>>4) + 16p, p < 2.  A thread's channels are fixed for the whole
@@ -546,6 +561,16 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
   typename BOp::Row rowb[2];
   auto fetch = [&](int r0) {
     const int bha = r0 / rows_N(aop), bhb = r0 / rows_N(bop);
+    if (side_a) {
+      const int r = r0 + tid;
+      rowsa = aop.row(r < rend ? r : 0x7ffffff0, bha);
+      rsa = aop.raw(rowsa, m_s);
+    }
+    if (side_b) {
+      const int r = r0 + tid - 64;
+      rowsb = bop.row(r < rend ? r : 0x7ffffff0, bhb);
+      rsb = bop.raw(rowsb, n_s);
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int r = r0 + ra0 + 8 * p;
@@ -559,14 +584,20 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
       bop.raw4(rowb[p], bn0 + nb, rb[p]);
     }
   };
+  auto stash_side = [&](int buf) {
+    if (side_a) T.Sa[buf][tid] = aop.fin(rowsa, kcsa, rsa);
+    if (side_b) T.Sb[buf][tid - 64] = bop.fin(rowsb, kcsb, rsb);
+  };
   auto stash_part = [&](int buf, int q) {  // q = 0..7: two A elements + one B element
     const int p = q >> 1, j0 = (q & 1) * 2;
+    if (q == 0) stash_side(buf);
     T.As[buf][ra0 + 8 * p][ma + j0] = aop.fin(rowa[p], kca[j0], ra[p][j0]);
     T.As[buf][ra0 + 8 * p][ma + j0 + 1] = aop.fin(rowa[p], kca[j0 + 1], ra[p][j0 + 1]);
     const int pb = q >> 2, jb = q & 3;
     T.Bs[buf][rb0 + 16 * pb][nb + jb] = bop.fin(rowb[pb], kcb[jb], rb[pb][jb]);
   };
   auto stash = [&](int buf) {
+    stash_side(buf);
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -583,34 +614,55 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     stash(0);
   }
   __syncthreads();
-  // Waves whose output rows (M = 257 leaves ONE live row in the third 128-row tile) or columns (Nc = 515: three live columns in
-  // the ninth 64-wide tile) are all beyond the matrix issue no MFMA for them.
+  // Without side products (a dimension that tile_split leaves padded): waves whose output rows or columns are all beyond the
+  // matrix issue no MFMA for them.
   const bool ncol = bn0 + wn * 32 < Nc;
   const bool live0 = ncol && bm0 + wm * 64 < M, live1 = ncol && bm0 + wm * 64 + 32 < M;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) fetch(rbeg + (kt + 1) * BK);
-    const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
-    const bool more = kt + 1 < nk;
-    if (live0) {
-      float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
+  // side accumulators: row side = thread (column tid % 64, k quarter tid / 64), 8 k per tile; column side = thread (row tid % 128,
+  // k half tid / 128), 16 k per tile; corner = lane k of wave 0
+  const int scol = tid & 63, sk4 = (tid >> 6) * (BK / 4), srow = tid & (BM - 1), sk2 = (tid >> 7) * (BK / 2);
+  float acc_r = 0.f, acc_c = 0.f, acc_x = 0.f;
+  auto side_step = [&](int cur, int step) {
+    if (hascol) acc_c = __fmaf_rn(T.As[cur][sk2 + step][srow], T.Sb[cur][sk2 + step], acc_c);
+    if (hasrow && step < BK / 4) acc_r = __fmaf_rn(T.Sa[cur][sk4 + step], T.Bs[cur][sk4 + step][scol], acc_r);
+  };
+  auto sweep = [&](auto side_c) {
+    constexpr bool SIDE = decltype(side_c)::value;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) fetch(rbeg + (kt + 1) * BK);
+      const int arow = wm * 64 + (lane & 31), bcol = wn * 32 + (lane & 31), kh = lane >> 5;
+      const bool more = kt + 1 < nk;
+      if (live0) {
+        float fb = T.Bs[cur][kh][bcol], fa0 = T.As[cur][kh][arow], fa1 = T.As[cur][kh][arow + 32];
 #pragma unroll
-      for (int step = 0; step < BK / 2; ++step) {  // register double-buffered fragments; next tile's transform spread over steps 4..11
-        const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
-        const float nb = T.Bs[cur][kn + kh][bcol];
-        const float na0 = T.As[cur][kn + kh][arow];
-        const float na1 = T.As[cur][kn + kh][arow + 32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
-        if (live1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
-        fb = nb; fa0 = na0; fa1 = na1;
-        if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
+        for (int step = 0; step < BK / 2; ++step) {  // register double-buffered fragments; next tile's transform spread over steps 4..11
+          const int kn = (step + 1 < BK / 2 ? step + 1 : step) * 2;
+          const float nb = T.Bs[cur][kn + kh][bcol];
+          const float na0 = T.As[cur][kn + kh][arow];
+          const float na1 = T.As[cur][kn + kh][arow + 32];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc0, 0, 0, 0);
+          if (live1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
+          fb = nb; fa0 = na0; fa1 = na1;
+          if (SIDE) side_step(cur, step);
+          if (step >= 4 && step < 12 && more) stash_part(cur ^ 1, step - 4);
+        }
+      } else {  // a wave without live output still carries its share of the side products and of the staging
+        if (SIDE) {
+#pragma unroll
+          for (int step = 0; step < BK / 2; ++step) side_step(cur, step);
+        }
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, q);
+        }
       }
-    } else if (more) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, q);
+      if (SIDE && hasrow && hascol && tid < BK) acc_x = __fmaf_rn(T.Sa[cur][tid], T.Sb[cur][tid], acc_x);
+      __syncthreads();
     }
-    __syncthreads();
-  }
+  };
+  if (hasrow || hascol) sweep(std::true_type{});
+  else sweep(std::false_type{});
   float* dst = part + (size_t)bo.group * M * Nc;
   const int col = bn0 + wn * 32 + (lane & 31);
 #pragma unroll
@@ -620,6 +672,20 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
       const int m = bm0 + wm * 64 + t * 32 + acc_row(reg, lane);
       if (m < M && col < Nc) dst[(size_t)m * Nc + col] = t == 0 ? acc0[reg] : acc1[reg];
     }
+  if (hasrow || hascol) {  // partial side sums meet in LDS (the tiles are dead: the sweep ended on a barrier), fixed order
+    float* red = reinterpret_cast<float*>(smem);  // [256] row-side partials, [256] column-side partials
+    red[tid] = acc_r;
+    red[NT + tid] = acc_c;
+    if (tid < BK) {  // corner: the 32 lane partials of wave 0
+      float x = acc_x;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+      if (tid == 0 && hasrow && hascol) dst[(size_t)m_s * Nc + n_s] = x;
+    }
+    __syncthreads();
+    if (hasrow && tid < BN && bn0 + tid < Nc) dst[(size_t)m_s * Nc + bn0 + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    if (hascol && tid < BM && bm0 + tid < M) dst[(size_t)(bm0 + tid) * Nc + n_s] = red[NT + tid] + red[NT + BM + tid];
+  }
 }
 
 // out[i] = scale * sum_c part[c][i]  (fixed chunk order)
@@ -1407,7 +1473,7 @@ FwdWs fwd_ws(const Dims& d) {
 // under TWO full rounds - 27 tiles x 40 chunks = 1080 blocks ran a full round plus a 41 % one; chunk count a multiple of 8
 // (whole chunks are dealt to the 8 XCDs), never below 128 rows.
 int tn_chunk_rows(int M, int Nc, long R, int bn = BN) {
-  const long tiles = (long)((M + BM - 1) / BM) * ((Nc + bn - 1) / bn);
+  const long tiles = (long)tile_split(M, BM).tiles * tile_split(Nc, bn).tiles;
   long want = (2 * 768 / tiles) / 8 * 8;
   if (want < 8) want = 8;
   long rows = (R + want - 1) / want;
@@ -1507,7 +1573,7 @@ template <class AOp, class BOp>
 int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* part, float* out, int ldo, int off, hipStream_t st) {
   const int chunk_rows = tn_chunk_rows(M, Nc, R);
   const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
-  dim3 grid(xcd_grid(chunks, ((M + BM - 1) / BM) * ((Nc + BN - 1) / BN)));
+  dim3 grid(xcd_grid(chunks, tile_split(M, BM).tiles * tile_split(Nc, BN).tiles));
   gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part, xcd_aware());
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
