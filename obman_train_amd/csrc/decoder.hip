@@ -202,6 +202,15 @@ struct Tiles {
   float Sa[2][BK], Sb[2][BK];
 };
 
+// The weight-gradient kernel stages its tiles in load order (the contraction index is the row): a thread writes four consecutive
+// channels of a row with ONE 16-byte store; rows are 16-byte aligned (pad 4).  With the +1 pad and four 4-byte stores per thread
+// half of the kernel's LDS cycles were bank conflicts (PMC SQ_LDS_BANK_CONFLICT 1.6e7 of 3.3e7 active, profiles/r02_kernels.md).
+struct TilesT {
+  float As[2][BK][BM + 4];
+  float Bs[2][BK][BN + 4];
+  float Sa[2][BK], Sb[2][BK];
+};
+
 // 257 = 4 x 64 + 1 and 515 = 8 x 64 + 3: padding the output to whole 64-column tiles would spend a fifth (a ninth) of the
 // blocks - and at 64 x 642 points a whole third block round - on one (three) live columns.  Instead the tiled dimension is cut
 // to its whole tiles and each of the first `side` members of a group computes ONE leftover column beside its MFMAs, on the
@@ -340,7 +349,8 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc1, 0, 0, 0);
           fb = nb; fa0 = na0; fa1 = na1;
           if (SIDE) sacc = __fmaf_rn(T.As[cur][skh + step][srow], T.Sb[cur][skh + step], sacc);
-          if (!(DBG & 2) && step >= 4 && step < 12) stash_part(cur ^ 1, (kt + 1) * BK, step - 4);
+          constexpr int S0 = (DBG & 16) ? 8 : ((DBG & 32) ? 6 : 4);
+          if (!(DBG & 2) && step >= S0 && step < S0 + 8) stash_part(cur ^ 1, (kt + 1) * BK, step - S0);
         }
       } else {
 #pragma unroll
@@ -525,7 +535,7 @@ struct EpiMaskStatsImpl : EpiMaskStats {
 template <class AOp, class BOp>
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, int Nc, int R, int rows_per_chunk, float* __restrict__ part, int order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  Tiles& T = *reinterpret_cast<Tiles*>(smem);
+  TilesT& T = *reinterpret_cast<TilesT*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   // Output rows / columns beyond the whole tiles (M = 257: one row; Nc = 515: three columns) are "side" products on the VALU
   // (tile_split): tile (mi, nj) also accumulates side row mi < ms.side against its 64 columns and side column nj < ns.side against
@@ -588,24 +598,25 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(AOp aop, BOp bop, int M, in
     if (side_a) T.Sa[buf][tid] = aop.fin(rowsa, kcsa, rsa);
     if (side_b) T.Sb[buf][tid - 64] = bop.fin(rowsb, kcsb, rsb);
   };
-  auto stash_part = [&](int buf, int q) {  // q = 0..7: two A elements + one B element
-    const int p = q >> 1, j0 = (q & 1) * 2;
-    if (q == 0) stash_side(buf);
-    T.As[buf][ra0 + 8 * p][ma + j0] = aop.fin(rowa[p], kca[j0], ra[p][j0]);
-    T.As[buf][ra0 + 8 * p][ma + j0 + 1] = aop.fin(rowa[p], kca[j0 + 1], ra[p][j0 + 1]);
-    const int pb = q >> 2, jb = q & 3;
-    T.Bs[buf][rb0 + 16 * pb][nb + jb] = bop.fin(rowb[pb], kcb[jb], rb[pb][jb]);
+  auto put_a = [&](int buf, int p) {
+    *reinterpret_cast<float4*>(&T.As[buf][ra0 + 8 * p][ma]) = make_float4(aop.fin(rowa[p], kca[0], ra[p][0]), aop.fin(rowa[p], kca[1], ra[p][1]),
+                                                                        aop.fin(rowa[p], kca[2], ra[p][2]), aop.fin(rowa[p], kca[3], ra[p][3]));
+  };
+  auto put_b = [&](int buf, int p) {
+    *reinterpret_cast<float4*>(&T.Bs[buf][rb0 + 16 * p][nb]) = make_float4(bop.fin(rowb[p], kcb[0], rb[p][0]), bop.fin(rowb[p], kcb[1], rb[p][1]),
+                                                                         bop.fin(rowb[p], kcb[2], rb[p][2]), bop.fin(rowb[p], kcb[3], rb[p][3]));
+  };
+  auto stash_part = [&](int buf, int q) {  // q = 0..7: A row groups at even q, B row groups at q = 1 and 5, side columns at q = 3
+    if ((q & 1) == 0) put_a(buf, q >> 1);
+    else if (q == 1 || q == 5) put_b(buf, q >> 2);
+    else if (q == 3) stash_side(buf);
   };
   auto stash = [&](int buf) {
     stash_side(buf);
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 4; ++p) put_a(buf, p);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) T.As[buf][ra0 + 8 * p][ma + j] = aop.fin(rowa[p], kca[j], ra[p][j]);
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) T.Bs[buf][rb0 + 16 * p][nb + j] = bop.fin(rowb[p], kcb[j], rb[p][j]);
+    for (int p = 0; p < 2; ++p) put_b(buf, p);
   };
   f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
   const int nk = (rend - rbeg + BK - 1) / BK;
@@ -706,19 +717,22 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 namespace dec {
 
 constexpr int PREP_COLS = 4;  // 129 blocks at C1 = 515
+constexpr int PREP_NT = 1024;  // threads of prep_kernel: 16 waves walk the 64 samples / the template vertices of a block's 4 channels
 
 // Layer 1 in factored form + closed-form BN-1 statistics.  One block = PREP_COLS output channels.
 //   G[n,c] = W1[c,0:3].grid[n],  F[b,c] = b1[c] + W1[c,3:].feat[b]
 //   train: mean = mean_n G + mean_b F, var = var_n G + var_b F (biased; exact for the B x N product set)
 //   Gx = rstd*(G - gm), Fx = rstd*(F - fm)  with gm + fm = mean  =>  xhat1[b,n,c] = Gx[n,c] + Fx[b,c]
-__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+__global__ __launch_bounds__(PREP_NT) void prep_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                                    const float* __restrict__ grid, const float* __restrict__ feat, int B, int N,
                                                    int C1, int ld1, int training, float eps, float momentum,
                                                    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ Gx,
                                                    float* __restrict__ Fx, float* __restrict__ mean1, float* __restrict__ rstd1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Cf = C1 - 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* sW = reinterpret_cast<float*>(smem);          // [PREP_COLS][C1]
+  constexpr int NW = PREP_NT / 64, NPART = NW / PREP_COLS;  // 16 waves: 4 per channel in the statistics pass
+  double* sPart = reinterpret_cast<double*>(smem);      // [PREP_COLS][NPART][2]: partial (sum, sum of squares) over n
+  float* sW = reinterpret_cast<float*>(sPart + PREP_COLS * NPART * 2);  // [PREP_COLS][C1]
   float* sF = sW + PREP_COLS * C1;                      // [PREP_COLS][B]
   float* sStat = sF + PREP_COLS * B;                    // [PREP_COLS][4]: gm, fm, rstd
   // G[n,c] (3 MACs) is recomputed wherever needed instead of being staged: N reaches 64 050 (25 x 2562)
@@ -726,12 +740,12 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1,
     return sW[j * C1] * grid[n * 3] + sW[j * C1 + 1] * grid[n * 3 + 1] + sW[j * C1 + 2] * grid[n * 3 + 2];
   };
   const int c0 = blockIdx.x * PREP_COLS;
-  for (int i = tid; i < PREP_COLS * C1; i += 256) {
+  for (int i = tid; i < PREP_COLS * C1; i += PREP_NT) {
     const int c = c0 + i / C1;
     sW[i] = c < C1 ? W1[(size_t)c * C1 + i % C1] : 0.f;
   }
   __syncthreads();
-  for (int b = wave; b < B; b += 4) {  // one wave per sample: lanes stride over the feature
+  for (int b = wave; b < B; b += NW) {  // one wave per sample: lanes stride over the feature
     float acc[PREP_COLS];
 #pragma unroll
     for (int j = 0; j < PREP_COLS; ++j) acc[j] = 0.f;
@@ -755,17 +769,23 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1,
     }
   }
   __syncthreads();
-  // per-channel statistics: wave j/2.. handles channels; fp64 accumulation
-  for (int j = wave; j < PREP_COLS; j += 4) {
+  // per-channel statistics in fp64: wave = (channel j, part); the parts split the template vertices and meet in LDS (fixed order)
+  {
+    const int j = wave % PREP_COLS, part = wave / PREP_COLS;
+    double sg = 0, sgg = 0;
+    for (int n = part * 64 + lane; n < N; n += 64 * NPART) { const double v = Gval(j, n); sg += v; sgg += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgg += __shfl_xor(sgg, off, 64); }
+    if (lane == 0) { sPart[(j * NPART + part) * 2] = sg; sPart[(j * NPART + part) * 2 + 1] = sgg; }
+  }
+  __syncthreads();
+  for (int j = wave; j < PREP_COLS; j += NW) {
     const int c = c0 + j;
     double sg = 0, sgg = 0, sf = 0, sff = 0;
-    for (int n = lane; n < N; n += 64) { const double v = Gval(j, n); sg += v; sgg += v * v; }
+    for (int q = 0; q < NPART; ++q) { sg += sPart[(j * NPART + q) * 2]; sgg += sPart[(j * NPART + q) * 2 + 1]; }
     for (int b = lane; b < B; b += 64) { const double v = sF[j * B + b]; sf += v; sff += v * v; }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      sg += __shfl_xor(sg, off, 64); sgg += __shfl_xor(sgg, off, 64);
-      sf += __shfl_xor(sf, off, 64); sff += __shfl_xor(sff, off, 64);
-    }
+    for (int off = 32; off > 0; off >>= 1) { sf += __shfl_xor(sf, off, 64); sff += __shfl_xor(sff, off, 64); }
     if (lane == 0 && c < C1) {
       float gm, fm, var;
       if (training) {
@@ -789,11 +809,11 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W1,
   __syncthreads();
   // columns C1 .. ld1-1 (the pitch padding, covered by the extra blocks of the grid) are written as zeros: the bf16 flavour's
   // operand generators read whole 8-wide chunks and rely on finite padding
-  for (int i = tid; i < PREP_COLS * N; i += 256) {
+  for (int i = tid; i < PREP_COLS * N; i += PREP_NT) {
     const int n = i / PREP_COLS, j = i % PREP_COLS;  // consecutive lanes -> consecutive channels (32-byte segments)
     if (c0 + j < ld1) Gx[(size_t)n * ld1 + c0 + j] = c0 + j < C1 ? (Gval(j, n) - sStat[j * 4]) * sStat[j * 4 + 2] : 0.f;
   }
-  for (int i = tid; i < PREP_COLS * B; i += 256) {
+  for (int i = tid; i < PREP_COLS * B; i += PREP_NT) {
     const int b = i / PREP_COLS, j = i % PREP_COLS;
     if (c0 + j < ld1) Fx[(size_t)b * ld1 + c0 + j] = c0 + j < C1 ? (sF[j * B + b] - sStat[j * 4 + 1]) * sStat[j * 4 + 2] : 0.f;
   }
@@ -1219,6 +1239,7 @@ __global__ __launch_bounds__(256) void l1_reduce2_kernel(const float* __restrict
 // BN-1 backward in factored form.  Block = 64 channels x 16 row groups (coalesced along channels; the rows of P/Fx
 // (B) and Q/Gx (N) are split over the 16 groups and merged through LDS in group order => deterministic).
 // Produces g_gamma1, g_beta1, dF [B,ld1], dG [N,ld1], g_b1 = sum_b dF, and gW1[:, 0:3] = dG^T grid.
+constexpr int L1F_CH = 64;  // 16 channels x 64 row groups per block (33 blocks instead of 9) measured 151 us instead of 35 at 642 points: kept at 64
 __global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restrict__ P, const float* __restrict__ Q,
                                                            const float* __restrict__ Gx, const float* __restrict__ Fx, int ld1,
                                                            int B, int N, int C1, int training, const float* __restrict__ gamma,
@@ -1226,18 +1247,19 @@ __global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restri
                                                            float* __restrict__ g_gamma, float* __restrict__ g_beta,
                                                            float* __restrict__ g_b1, float* __restrict__ gW1, float* __restrict__ dF,
                                                            float* __restrict__ dG) {
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;  // rg = row group 0..15 (= wave)
-  const int c = blockIdx.x * 64 + cl;
+  constexpr int CH = L1F_CH, RG = 1024 / L1F_CH;
+  const int cl = threadIdx.x % CH, rg = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl;
   const bool ok = c < C1;
-  __shared__ double red[16][4][64];
-  __shared__ float redf[16][4][64];
+  __shared__ double red[RG][4][CH];
+  __shared__ float redf[RG][4][CH];
   double s1 = 0, s2 = 0, sgx = 0, sfx = 0;
   if (ok) {
-    for (int b = rg; b < B; b += 16) {
+    for (int b = rg; b < B; b += RG) {
       const double p = P[(size_t)b * ld1 + c], fx = Fx[(size_t)b * ld1 + c];
       s1 += p; s2 += p * fx; sfx += fx;
     }
-    for (int n = rg; n < N; n += 16) {
+    for (int n = rg; n < N; n += RG) {
       const double gx = Gx[(size_t)n * ld1 + c];
       s2 += gx * (double)Q[(size_t)n * ld1 + c];
       sgx += gx;
@@ -1246,18 +1268,18 @@ __global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restri
   red[rg][0][cl] = s1; red[rg][1][cl] = s2; red[rg][2][cl] = sgx; red[rg][3][cl] = sfx;
   __syncthreads();
   s1 = s2 = sgx = sfx = 0;
-  for (int g = 0; g < 16; ++g) { s1 += red[g][0][cl]; s2 += red[g][1][cl]; sgx += red[g][2][cl]; sfx += red[g][3][cl]; }
+  for (int g = 0; g < RG; ++g) { s1 += red[g][0][cl]; s2 += red[g][1][cl]; sgx += red[g][2][cl]; sfx += red[g][3][cl]; }
   const double R = (double)B * N;
   const float k1 = ok ? gamma[c] * rstd1[c] : 0.f;
   const float k2 = training ? (float)(s1 / R) : 0.f, k3 = training ? (float)(s2 / R) : 0.f;
   float gb = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
   if (ok) {
-    for (int b = rg; b < B; b += 16) {
+    for (int b = rg; b < B; b += RG) {
       const float v = k1 * (P[(size_t)b * ld1 + c] - N * k2 - k3 * ((float)sgx + N * Fx[(size_t)b * ld1 + c]));
       dF[(size_t)b * ld1 + c] = v;
       gb += v;
     }
-    for (int n = rg; n < N; n += 16) {
+    for (int n = rg; n < N; n += RG) {
       const float v = k1 * (Q[(size_t)n * ld1 + c] - B * k2 - k3 * (B * Gx[(size_t)n * ld1 + c] + (float)sfx));
       dG[(size_t)n * ld1 + c] = v;
       w0 = __fmaf_rn(v, grid[n * 3], w0); w1 = __fmaf_rn(v, grid[n * 3 + 1], w1); w2 = __fmaf_rn(v, grid[n * 3 + 2], w2);
@@ -1267,7 +1289,7 @@ __global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restri
   __syncthreads();
   if (rg == 0 && ok) {
     gb = w0 = w1 = w2 = 0.f;
-    for (int g = 0; g < 16; ++g) { gb += redf[g][0][cl]; w0 += redf[g][1][cl]; w1 += redf[g][2][cl]; w2 += redf[g][3][cl]; }
+    for (int g = 0; g < RG; ++g) { gb += redf[g][0][cl]; w0 += redf[g][1][cl]; w1 += redf[g][2][cl]; w2 += redf[g][3][cl]; }
     g_gamma[c] = (float)s2;
     g_beta[c] = (float)s1;
     g_b1[c] = gb;
@@ -1371,23 +1393,30 @@ __global__ __launch_bounds__(256) void l1_seg_w_kernel(const float* __restrict__
 // MFMA kernel (one row block, 17 serial k-tiles); thread = (b, k), dF broadcast within the wave, W1 coalesced over k.
 __global__ __launch_bounds__(256) void gfeat_kernel(const float* __restrict__ dF, int ld1, const float* __restrict__ W1, int C1, int B,
                                                     float* __restrict__ g_feat) {
-  const int Cf = C1 - 3, k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (k >= Cf) return;
+  // g_feat[b,k] = sum_c dF[b,c] W1[c,3+k].  Block = 64 features x 4 channel quarters (one per wave), sample = blockIdx.y: a
+  // quarter is ~129 channels = 8 batches of 16 independent strided loads (one thread per feature walking all 515 channels was
+  // 33 dependent batches: 16 us at 64 samples); the quarters meet in LDS in fixed order.
+  __shared__ float red[3][64];
+  const int Cf = C1 - 3, kk = threadIdx.x & 63, cq = threadIdx.x >> 6, k = blockIdx.x * 64 + kk, b = blockIdx.y;
+  const int per = (C1 + 3) / 4, cbeg = cq * per, cend = cbeg + per < C1 ? cbeg + per : C1;
   const float* d = dF + (size_t)b * ld1;
-  const float* w = W1 + 3 + k;
+  const float* w = W1 + 3 + (k < Cf ? k : 0);
   float acc[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-  int c = 0;
-  for (; c + 15 < C1; c += 16) {  // 16 independent strided loads in flight per lane
+  int c = cbeg;
+  for (; c + 15 < cend; c += 16) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc[u] = __fmaf_rn(d[c + u], w[(size_t)(c + u) * C1], acc[u]);
   }
-  for (; c < C1; ++c) acc[0] = __fmaf_rn(d[c], w[(size_t)c * C1], acc[0]);
+  for (; c < cend; ++c) acc[0] = __fmaf_rn(d[c], w[(size_t)c * C1], acc[0]);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
   for (int u = 0; u < 16; u += 4) { a0 += acc[u]; a1 += acc[u + 1]; a2 += acc[u + 2]; a3 += acc[u + 3]; }
-  g_feat[(size_t)b * Cf + k] = (a0 + a1) + (a2 + a3);
+  const float part = (a0 + a1) + (a2 + a3);
+  if (cq) red[cq - 1][kk] = part;
+  __syncthreads();
+  if (cq == 0 && k < Cf) g_feat[(size_t)b * Cf + k] = ((part + red[0][kk]) + red[1][kk]) + red[2][kk];
 }
 
 // out[m*ldo + off + n] = sum_c part[c][m][n].  Fixed summation order (run-to-run reproducible): wave q of a block sums the chunks
@@ -1562,7 +1591,7 @@ int launch_rows(const AOp& a, const float* W, int ldb, int K, int Nc, long R, co
   static const int dbg = [] { const char* v = getenv("OBMAN_GEMM_DBG"); return v ? atoi(v) : 0; }();
 #define OBMAN_DBG_CASE(D) \
   if (dbg == D) { gemm_rows_kernel<AOp, B_NK, Epi, D><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e, xcd_aware() ? 0 : 8); OBMAN_LAUNCH_CHECK(); return 0; }
-  OBMAN_DBG_CASE(1) OBMAN_DBG_CASE(2) OBMAN_DBG_CASE(3) OBMAN_DBG_CASE(4) OBMAN_DBG_CASE(6) OBMAN_DBG_CASE(8) OBMAN_DBG_CASE(10) OBMAN_DBG_CASE(14)
+  OBMAN_DBG_CASE(1) OBMAN_DBG_CASE(2) OBMAN_DBG_CASE(3) OBMAN_DBG_CASE(4) OBMAN_DBG_CASE(6) OBMAN_DBG_CASE(8) OBMAN_DBG_CASE(10) OBMAN_DBG_CASE(14) OBMAN_DBG_CASE(16) OBMAN_DBG_CASE(32)
 #undef OBMAN_DBG_CASE
 #endif
   gemm_rows_kernel<AOp, B_NK, Epi><<<grid, NT, sizeof(Tiles), st>>>(a, W, ldb, K, Nc, e, xcd_aware() ? 0 : 8);
@@ -1574,7 +1603,7 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   const int chunk_rows = tn_chunk_rows(M, Nc, R);
   const int chunks = (int)((R + chunk_rows - 1) / chunk_rows);
   dim3 grid(xcd_grid(chunks, tile_split(M, BM).tiles * tile_split(Nc, BN).tiles));
-  gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(Tiles), st>>>(a, b, M, Nc, (int)R, chunk_rows, part, xcd_aware());
+  gemm_tn_kernel<AOp, BOp><<<grid, NT, sizeof(TilesT), st>>>(a, b, M, Nc, (int)R, chunk_rows, part, xcd_aware());
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
   OBMAN_LAUNCH_CHECK();
@@ -1781,12 +1810,13 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
   ObmanProfScope prof(OBMAN_K_DECODER_FWD, st);
   {
     const size_t sm = sizeof(float) * ((size_t)PREP_COLS * (d.C1 + d.B) + PREP_COLS * 4);
+    const size_t sm_prep = sm + sizeof(double) * PREP_COLS * (PREP_NT / 64 / PREP_COLS) * 2;
     if (d.ps)
       prep_ps_kernel<<<obman_cdiv(d.C1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
                                                                     p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
                                                                     ws + w.mean1, ws + w.rstd1);
     else
-      prep_kernel<<<obman_cdiv(d.ld1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
+      prep_kernel<<<obman_cdiv(d.ld1, PREP_COLS), PREP_NT, sm_prep, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
                                                                  p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
                                                                  ws + w.mean1, ws + w.rstd1);
     OBMAN_LAUNCH_CHECK();
@@ -1930,7 +1960,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     l1_seg_w_kernel<<<obman_cdiv(3 * d.C1, 256), 256, 0, st>>>(ws2 + v.segw, nseg, d.C1, g->w1);
     OBMAN_LAUNCH_CHECK();
   } else {
-    l1_finalize_kernel<<<obman_cdiv(d.C1, 64), 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
+    l1_finalize_kernel<<<obman_cdiv(d.C1, L1F_CH), 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
                                                                ws + w.rstd1, p->grid, g->bn_w[0], g->bn_b[0], g->b1, g->w1, ws2 + v.dF, ws2 + v.dG);
     OBMAN_LAUNCH_CHECK();
   }
@@ -1942,7 +1972,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     if (rc) return rc;
   }
   if (g->feat) {  // g_feat[b,k] = sum_c dF[b,c] W1[c,3+k]
-    gfeat_kernel<<<dim3(obman_cdiv(Cf, 256), d.B), 256, 0, st>>>(ws2 + v.dF, d.ld1, p->w1, d.C1, d.B, g->feat);
+    gfeat_kernel<<<dim3(obman_cdiv(Cf, 64), d.B), 256, 0, st>>>(ws2 + v.dF, d.ld1, p->w1, d.C1, d.B, g->feat);
     OBMAN_LAUNCH_CHECK();
   }
   return 0;
