@@ -35,6 +35,9 @@ def _oracle(dec, feats, grid, training, mfma_round=None):
 
 @pytest.mark.parametrize("c1,B,subdiv,training,patches", [(35, 3, 1, True, 1), (35, 2, 1, False, 1), (515, 4, 3, True, 1),
                                                           (515, 2, 2, False, 1), (131, 5, 2, True, 1), (515, 2, 1, True, 25),
+                                                          # 259 -> 129 -> 64 channels: one / three leftover columns and one leftover row beyond whole
+                                                          # 64 / 128 tiles in every GEMM (side products of the fp32 kernels, incl. the corner elements)
+                                                          (259, 3, 1, True, 1), (259, 2, 2, False, 1),
                                                           # 4 050 template vertices: the segmented layer-1 finalize of large templates (N > 2048)
                                                           (35, 2, 2, True, 25), (131, 3, 2, False, 25),
                                                           # 68 850 rows = 538 row blocks: the pre-reduction of the per-block BatchNorm partials (> 512 blocks)
