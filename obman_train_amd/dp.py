@@ -6,9 +6,9 @@ replicas behave: every rank runs the whole path on its own shard of the batch (B
 the batch-global masked means stay rank-local) and only gradients are exchanged: mean over ranks.
 
 MI355X specifics: xGMI is point-to-point, so a ring all-reduce is bound by one ~77 GB/s link direction;
-the 51.7 MB of fp32 gradients are packed into flat 8 MB buckets (one multi-tensor copy per bucket): large
-enough to run near link rate, small enough that only the LAST bucket (conv1/layer1, ready at the very end of backward,
-< 8 MB ~ 0.2 ms on the ring) is exposed; the others are on the wire while ResNet's backward is still running.  Buckets
+the 51.7 MB of fp32 gradients are packed into flat >= 8 MB buckets (one multi-tensor copy per bucket), large
+enough to run near link rate, followed by a few shrinking tail buckets so that only a 0.3 MB LAST bucket (layer1 + stem,
+ready at the very end of backward) is exposed; the others are on the wire while ResNet's backward is still running.  Buckets
 are laid out in reverse parameter order, all-reduced (AVG) asynchronously on RCCL's own stream as soon as their last
 gradient has been accumulated, and waited for before the optimizer step (``finish()``).  With ``world_size == 1`` everything is a no-op.
 """
@@ -32,7 +32,7 @@ class GradientBuckets:
     same update everywhere.  Parameters that can never receive a gradient (``base_net.fc``, unused by the feature
     extractor) are passed in ``exclude``: they are left out of the buckets and keep ``grad = None`` as in the reference."""
 
-    def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None, force=False, exclude=()):
+    def __init__(self, params, bucket_bytes=8 * 1024 * 1024, group=None, force=False, exclude=(), tail_bytes=512 * 1024):
         self.group = group
         live = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if live else 1
@@ -48,13 +48,21 @@ class GradientBuckets:
         if not self.enabled:
             return
         self._avg = dist.get_backend(group) == "nccl"  # RCCL averages in the collective; gloo has no AVG
+        # Bucket targets shrink towards the end of backward: the LAST bucket's all-reduce is the only exposed one (nothing is
+        # left to hide it behind), so once less than one full bucket of gradients remains the target halves each time
+        # (never below tail_bytes).  The configs[1] model: 13.7 / 9.0 / 9.5 / 9.0 MB, then 3.5 MB (layer3.0), 1.7 MB, 0.56 MB and a
+        # final 0.32 MB (layer1 + stem) instead of one 6.1 MB bucket that waits for conv1's gradient.
+        remaining = sum(p.numel() * p.element_size() for p in self.params)
         cur, cur_bytes = [], 0
+        target = bucket_bytes if remaining > bucket_bytes else max(remaining // 2, tail_bytes)
         for p in reversed(self.params):  # backward produces the last layers' gradients first
             cur.append(p)
             cur_bytes += p.numel() * p.element_size()
-            if cur_bytes >= bucket_bytes:
+            if cur_bytes >= target:
                 self._close(cur)
+                remaining -= cur_bytes
                 cur, cur_bytes = [], 0
+                target = bucket_bytes if remaining > bucket_bytes else max(remaining // 2, tail_bytes)
         if cur:
             self._close(cur)
         for p in self.params:
