@@ -1424,8 +1424,9 @@ __global__ __launch_bounds__(256) void gfeat_kernel(const float* __restrict__ dF
 // combined as ((s0 + s1) + s2) + s3.  (One thread per element walking all chunks with a load -> add dependency per chunk took
 // 33 us for 56 chunks x 132 k elements = 30 MB: ~0.9 TB/s, latency-bound.)
 constexpr int RTN_ELEMS = 64;
+// `transposed`: the product was formed as [Nc-major] = out^T (the bf16 layer-2 weight gradient), out[n*ldo + off + m] receives it.
 __global__ __launch_bounds__(256) void reduce_tn_kernel(const float* __restrict__ part, int chunks, int M, int Nc, int ldo, int off,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int transposed = 0) {
   __shared__ float red[3][RTN_ELEMS];
   const int q = threadIdx.x >> 6;
   const long total = (long)M * Nc, i = (long)blockIdx.x * RTN_ELEMS + (threadIdx.x & 63);
@@ -1445,7 +1446,8 @@ __global__ __launch_bounds__(256) void reduce_tn_kernel(const float* __restrict_
   __syncthreads();
   if (q == 0 && ok) {
     s = ((s + red[0][threadIdx.x]) + red[1][threadIdx.x]) + red[2][threadIdx.x];
-    out[(size_t)(i / Nc) * ldo + off + (i % Nc)] = s;
+    if (transposed) out[(size_t)(i % Nc) * ldo + off + (i / Nc)] = s;
+    else out[(size_t)(i / Nc) * ldo + off + (i % Nc)] = s;
   }
 }
 
@@ -1569,7 +1571,10 @@ BwdWs bwd_ws(const Dims& d) {
   }
   {  // split-K partials: the largest of the three weight-gradient products
     auto need = [&](int M, int Nc, long R) {
-      if (d.bf16 && R == d.R) return (long)tn_bf16_chunks(M, Nc, d.N, d.B, 64 * wide_wn(Nc)) * M * Nc;
+      if (d.bf16 && R == d.R) {  // the bf16 flavour forms the layer-2 product transposed (backward_bf16)
+        if (M == d.C2 && Nc == d.C1) { M = d.C1; Nc = d.C2; }
+        return (long)tn_bf16_chunks(M, Nc, d.N, d.B, 64 * wide_wn(Nc)) * M * Nc;
+      }
       const int rows = tn_chunk_rows(M, Nc, R, BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
     };
@@ -1637,7 +1642,7 @@ int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo&
 }
 template <class AOp, class BOp, int WN>
 int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
-                      hipStream_t st) {
+                      hipStream_t st, int transposed) {
   const size_t lds = (size_t)2 * (BM + 64 * WN) * LPT * sizeof(bfraw);
   static const int once = [] {
     return (int)hipFuncSetAttribute((const void*)tn_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1650,15 +1655,15 @@ int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, 
   const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))) * (unsigned)chunks;
   tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, R, N, Bsz, tiles_per_chunk, part);
   OBMAN_LAUNCH_CHECK();
-  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out);
+  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out, transposed);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
 template <class AOp, class BOp>
 int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
-                   hipStream_t st) {
-  return wide_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st)
-                          : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st);
+                   hipStream_t st, int transposed = 0) {
+  return wide_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st, transposed)
+                          : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st, transposed);
 }
 // -> pointer / row count the finalize kernels should read: the partials themselves, or their 64-segment pre-reduction
 template <class T>
@@ -1761,10 +1766,13 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
-  {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c]
-    TGradH ta{GY2, H2, k1, k2, k3, d.ld2, d.C2};
-    TGridFeat tb{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, d.C1};
-    if ((rc = launch_tn_bf16<TGradH, TGridFeat>(ta, tb, d.C2, d.C1, d.R, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
+  {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c], formed TRANSPOSED (M = the 515 channels of a1, one 320-wide tile for the 257 of gh2):
+     // every operand is regenerated once per tile of the OTHER operand, and a1 (fp32 factors, add + fma + max per element) is the
+     // expensive one - as the A operand of five 128 x 320 tiles it is generated once (640 channel columns per k-tile) and gh2 five
+     // times (1 600), against 1 920 + 768 with gh2 as A on 3 x 2 tiles
+    TGridFeat ta{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, d.C1};
+    TGradH tb{GY2, H2, k1, k2, k3, d.ld2, d.C2};
+    if ((rc = launch_tn_bf16<TGridFeat, TGradH>(ta, tb, d.C1, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
   }
   const L1Geo lg = l1_geo(d);
   {  // dA(gy1) with the (8 samples x 16 vertices) row tiling: P / Q partials straight from the accumulators
