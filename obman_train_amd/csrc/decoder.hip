@@ -53,6 +53,9 @@ struct AGridFeat {  // a1[r,k] = relu(gamma[k] * (Gx[n,k] + Fx[b,k]) + beta[k]),
     split_row(ok ? r : R - 1, N, ok ? bhint : (R - 1) / N, b, n);
     return Row{(ps ? (ok ? r : R - 1) : n) * ld, b * ld, ok};
   }
+  static constexpr int NC = 2;  // per-channel constants: kcv(j, k), j < NC (the rows GEMM stages them per k-tile in LDS)
+  __device__ float kcv(int j, int k) const { return k < K ? (j == 0 ? gamma : beta)[k] : 0.f; }
+  __device__ static KC make(const float* v, bool ok) { return KC{v[0], v[1], ok}; }
   __device__ KC kc(int k) const { const bool ok = k < K; const int c = ok ? k : 0; return KC{gamma[c], beta[c], ok}; }
   __device__ Raw raw(const Row& w, int k) const { const int c = k < K ? k : 0; return Raw{Gx[w.g + c], Fx[w.f + c]}; }
   __device__ void raw4(const Row& w, int k, Raw* o) const {  // k % 4 == 0; columns >= K are masked by kc().ok
@@ -72,6 +75,9 @@ struct ABnRelu {  // a[r,k] = relu(s[k] * H[r,k] + t[k])
   struct KC { float s, t; bool ok; };
   struct Raw { float h; };
   __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
+  static constexpr int NC = 2;
+  __device__ float kcv(int j, int k) const { return k < K ? (j == 0 ? s : t)[k] : 0.f; }
+  __device__ static KC make(const float* v, bool ok) { return KC{v[0], v[1], ok}; }
   __device__ KC kc(int k) const { const bool ok = k < K; const int c = ok ? k : 0; return KC{s[c], t[c], ok}; }
   __device__ Raw raw(const Row& w, int k) const { return Raw{H[w.o + (k < K ? k : 0)]}; }
   __device__ void raw4(const Row& w, int k, Raw* o) const {
@@ -90,6 +96,9 @@ struct APlain {  // a[r,k] = X[r,k]
   struct KC { bool ok; };
   struct Raw { float x; };
   __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
+  static constexpr int NC = 0;
+  __device__ float kcv(int, int) const { return 0.f; }
+  __device__ static KC make(const float*, bool ok) { return KC{ok}; }
   __device__ KC kc(int k) const { return KC{k < K}; }
   __device__ Raw raw(const Row& w, int k) const { return Raw{X[w.o + (k < K ? k : 0)]}; }
   __device__ void raw4(const Row& w, int k, Raw* o) const {  // rows of X need not be 16-byte aligned: scalar loads
@@ -111,6 +120,9 @@ struct AGradH {  // gy materialised
   struct KC { float a, b, c; bool ok; };
   struct Raw { float gy, h; };
   __device__ Row row(int r, int) const { const bool ok = r < R; return Row{(long)(ok ? r : 0) * ld, ok}; }
+  static constexpr int NC = 3;
+  __device__ float kcv(int j, int k) const { return k < K ? (j == 0 ? ka : (j == 1 ? kb : kc_))[k] : 0.f; }
+  __device__ static KC make(const float* v, bool ok) { return KC{v[0], v[1], v[2], ok}; }
   __device__ KC kc(int k) const {
     const bool ok = k < K; const int c = ok ? k : 0;
     return KC{ka[c], kb[c], kc_[c], ok};
@@ -131,16 +143,29 @@ struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o
   float f;
   int ld, R, K;
   struct Row { long o; float g0, g1, g2; bool ok; };
-  struct KC { float s, t, a, b, c, w0, w1, w2; bool ok; };
+  struct KC { float s, t, b, c, w0, w1, w2; bool ok; };  // w_j = ka * W4[j]: gh3 = (y3 > 0 ? g . w : 0) + (kb * h + kc)
   struct Raw { float h; };
   __device__ Row row(int r, int) const {
     const bool ok = r < R;
     const long rr = ok ? r : 0;
     return Row{rr * ld, f * G[rr * 3], f * G[rr * 3 + 1], f * G[rr * 3 + 2], ok};
   }
+  static constexpr int NC = 7;
+  __device__ float kcv(int j, int k) const {
+    if (k >= K) return 0.f;
+    switch (j) {
+      case 0: return s[k];
+      case 1: return t[k];
+      case 2: return kb[k];
+      case 3: return kc_[k];
+      default: return ka[k] * W4[(j - 4) * K + k];
+    }
+  }
+  __device__ static KC make(const float* v, bool ok) { return KC{v[0], v[1], v[2], v[3], v[4], v[5], v[6], ok}; }
   __device__ KC kc(int k) const {
     const bool ok = k < K; const int c = ok ? k : 0;
-    return KC{s[c], t[c], ka[c], kb[c], kc_[c], W4[c], W4[K + c], W4[2 * K + c], ok};
+    const float a = ka[c];
+    return KC{s[c], t[c], kb[c], kc_[c], a * W4[c], a * W4[K + c], a * W4[2 * K + c], ok};
   }
   __device__ Raw raw(const Row& w, int k) const { return Raw{H[w.o + (k < K ? k : 0)]}; }
   __device__ void raw4(const Row& w, int k, Raw* o) const {
@@ -149,7 +174,7 @@ struct AGradH3 {  // gy3 regenerated from the 3-channel output gradient: gy3[r,o
   }
   __device__ float fin(const Row& w, const KC& c, const Raw& x) const {
     const float gy = __fmaf_rn(c.s, x.h, c.t) > 0.f ? (w.g0 * c.w0 + w.g1 * c.w1 + w.g2 * c.w2) : 0.f;
-    const float v = __fmaf_rn(c.a, gy, __fmaf_rn(c.b, x.h, c.c));
+    const float v = gy + __fmaf_rn(c.b, x.h, c.c);
     return (w.ok && c.ok) ? v : 0.f;
   }
 };
@@ -200,6 +225,7 @@ struct Tiles {
   float As[2][BK][BM + 1];
   float Bs[2][BK][BN + 1];
   float Sa[2][BK], Sb[2][BK];
+  float Kc[2][8][BK];  // the A operand's per-channel constants of a k-tile (rows GEMM): [constant][k]
 };
 
 // The weight-gradient kernel stages its tiles in load order (the contraction index is the row): a thread writes four consecutive
@@ -247,13 +273,31 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
   typename AOp::KC kcur[4];
   float rb[8], rws = 0.f;
   const int ak = tid & 31;  // B staging keeps the scalar mapping (weight rows are not 16-byte aligned)
+  // Per-channel constants of the A operand (BN scale / shift, folded BN-backward coefficients, layer-4 weights: up to 7 per
+  // channel) travel through LDS: thread (constant tid / 32, channel tid % 32) loads ONE value per k-tile, two tiles ahead, and
+  // every thread reads the NC x 4 values of its four channels with NC 16-byte LDS reads when it transforms the tile - instead of
+  // 4 x NC global loads per thread and k-tile (32 for the gy2 GEMM, against its 32 MFMAs).
+  constexpr int NC = AOp::NC;
+  const bool kc_stager = tid < NC * BK;
+  const int kc_j = tid / BK, kc_k = tid % BK;
+  float kc_reg = 0.f;
+  auto fetch_kc = [&](int k0) { if (NC > 0 && kc_stager) kc_reg = aop.kcv(kc_j, k0 + kc_k); };
+  auto put_kc = [&](int buf) { if (NC > 0 && kc_stager) T.Kc[buf][kc_j][kc_k] = kc_reg; };
+  auto read_kc = [&](int buf, int k0) {  // -> kcur[0..3] for the channels k0 + kq .. + 3
+    float v[4][NC > 0 ? NC : 1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float4 q = *reinterpret_cast<const float4*>(&T.Kc[buf][c][kq]);
+      v[0][c] = q.x; v[1][c] = q.y; v[2][c] = q.z; v[3][c] = q.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kcur[j] = AOp::make(v[j], k0 + kq + j < K);
+  };
   auto fetch = [&](int k0) {  // loads only: nothing here consumes a loaded value
     if (side) {  // the side column's weights of this k-tile (every lane loads, lanes 0..31 of wave 0 stage them)
       const int k = k0 + ak < K ? k0 + ak : 0;
       rws = B_NK ? Bw[(size_t)sc * ldb + k] : Bw[(size_t)k * ldb + sc];
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kcur[j] = aop.kc(k0 + kq + j);
 #pragma unroll
     for (int p = 0; p < 4; ++p) aop.raw4(rows[p], k0 + kq, ra[p]);
     if (B_NK) {  // W[n][k]: consecutive lanes along k
@@ -276,7 +320,10 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
   };
   auto stash_part = [&](int buf, int k0, int q) {  // q = 0..7: two A elements + one B element
     const int p = q >> 1, j0 = (q & 1) * 2;
-    if (q == 0) stash_side(buf, k0);
+    if (q == 0) {
+      stash_side(buf, k0);
+      read_kc(buf, k0);
+    }
     if (DBG & 1) {  // no operand transform: the first loaded word as it is
       T.As[buf][kq + j0][rm + 32 * p] = *reinterpret_cast<const float*>(&ra[p][j0]);
       T.As[buf][kq + j0 + 1][rm + 32 * p] = *reinterpret_cast<const float*>(&ra[p][j0 + 1]);
@@ -294,6 +341,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
   };
   auto stash = [&](int buf, int k0) {
     stash_side(buf, k0);
+    read_kc(buf, k0);
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -323,13 +371,19 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
   // side product: thread = (row srow, k half skh) of the block's 128 x 32 operand tile, one FMA per MFMA step
   const int srow = tid & (BM - 1), skh = (tid >> 7) * (BK / 2);
   float sacc = 0.f;
+  fetch_kc(0);
   fetch(0);
+  put_kc(0);
+  fetch_kc(BK);
+  __syncthreads();  // constants of tile 0 visible
   stash(0, 0);
+  put_kc(1);        // constants of tile 1: read while tile 0 is multiplied
   __syncthreads();
   auto sweep = [&](auto side_c) {
     constexpr bool SIDE = decltype(side_c)::value;
     for (int kt = 0; kt + 1 < nk; ++kt) {  // every tile but the last: the next tile's transform rides behind the MFMAs
       const int cur = kt & 1;
+      fetch_kc((kt + 2) * BK);  // constants of tile kt + 2 -> Kc[cur] (last read while tile kt was transformed, one sweep ago)
       if (!(DBG & 4)) fetch((kt + 1) * BK);
       // The next tile's operand transform + LDS writes are spread over MFMA steps 4..11 (one eighth each): the loads were
       // issued at the top of the sweep (landed by step 4) and ~12 VALU/LDS instructions fit in the shadow of every MFMA
@@ -356,6 +410,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_rows_kernel(AOp aop, const float* 
 #pragma unroll
         for (int q = 0; q < 8; ++q) stash_part(cur ^ 1, (kt + 1) * BK, q);
       }
+      put_kc(cur);
       __syncthreads();
     }
   };
