@@ -193,6 +193,24 @@ int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, floa
 int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, const float* gamma, const float* stats, int B, int H, int W,
                      int C, int training, float* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream);
 
+/* The same four entry points for bf16 ACTIVATIONS (raw bf16 bits; x, skip, y, dy, dx, dskip, y_pool, d_pool), used when the encoder
+ * runs under bf16 autocast (BASELINE configs[2]).  Parameters, running statistics, stats and ws stay fp32; the arithmetic and the
+ * batch statistics are fp32 / fp64 exactly as above, the result is rounded to bf16 (nearest even) once, at the store. */
+int obman_bnact_fwd_bf16(const uint16_t* x, const uint16_t* skip, const float* gamma, const float* beta, float* rmean, float* rvar, long R,
+                         int C, int training, float eps, float momentum, int relu, uint16_t* y, float* stats, float* ws,
+                         obman_stream_t stream);
+int obman_bnact_bwd_bf16(const uint16_t* x, const uint16_t* y, const uint16_t* dy, const float* gamma, const float* stats, long R, int C,
+                         int training, int relu, int has_skip, uint16_t* dx, float* dgamma, float* dbeta, uint16_t* dskip, float* ws,
+                         obman_stream_t stream);
+/* The stem's forward additionally writes amax [B,Ho,Wo,C] bytes: the 3x3 window tap (0..8, row-major; 255 = none, all taps <= 0) of
+ * the FIRST maximum - torch's max_pool2d arg-max - and the backward routes d_pool by it.  (The fp32 entry points route to the taps
+ * that equal the pooled value; bf16 inputs tie far too often for that.) */
+int obman_bnpool_fwd_bf16(const uint16_t* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
+                          int training, float eps, float momentum, uint16_t* y_pool, uint8_t* amax, float* stats, float* ws,
+                          obman_stream_t stream);
+int obman_bnpool_bwd_bf16(const uint16_t* x, const uint8_t* amax, const uint16_t* d_pool, const float* gamma, const float* stats, int B,
+                          int H, int W, int C, int training, uint16_t* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream);
+
 /* ---- K10: GPU-side image input stream -----------------------------------------------------------
  * Replaces the CPU pixel pipeline of HandDataset.get_sample (handobjectdatasets/handataset.py:373-405): per sample
  * Gaussian blur (PIL ImageFilter.GaussianBlur = 3+3 extended-box passes) and colour jitter (imgtrans.py:31-53:

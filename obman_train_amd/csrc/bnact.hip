@@ -19,6 +19,35 @@ namespace bnact {
 
 constexpr int CT = 64;  // channels per block column
 
+// Activation element type: fp32, or bf16 (raw bits) for the bf16-autocast encoder of BASELINE configs[2].  A lane always moves
+// four consecutive channels (16 bytes of fp32, 8 bytes of bf16); the arithmetic and every statistic are fp32 / fp64 in both
+// flavours, the bf16 flavour rounds once (to nearest even) when it stores.
+typedef unsigned short bfraw;
+template <class T> struct Act;
+template <> struct Act<float> {
+  static __device__ __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ float4 round(const float4 v) { return v; }
+};
+__device__ __forceinline__ unsigned bf_bits(float f) {  // round to nearest even; NaN stays NaN
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x7fffffffu) > 0x7f800000u ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <> struct Act<bfraw> {
+  static __device__ __forceinline__ float4 ld(const bfraw* p) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void st(bfraw* p, const float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(bf_bits(v.x) | (bf_bits(v.y) << 16), bf_bits(v.z) | (bf_bits(v.w) << 16));
+  }
+  static __device__ __forceinline__ float4 round(const float4 v) {
+    return make_float4(__uint_as_float(bf_bits(v.x) << 16), __uint_as_float(bf_bits(v.y) << 16), __uint_as_float(bf_bits(v.z) << 16),
+                       __uint_as_float(bf_bits(v.w) << 16));
+  }
+};
+
 struct Geo { long R; int C, rows_per_blk, nblk; };
 
 __device__ __forceinline__ double wsum64(double v) {
@@ -28,11 +57,11 @@ __device__ __forceinline__ double wsum64(double v) {
 }
 
 // accumulate two per-channel quantities over a chunk of rows; partial[blk][C][2]
-template <int MODE>  // 0: (x, x^2)   1: (dz, dz*xhat) mask from s*x+t   2: same, mask from y, optional dz store   3: no relu
-__global__ __launch_bounds__(256) void sums_kernel(const float* __restrict__ X, const float* __restrict__ DY, const float* __restrict__ Y,
+template <int MODE, class T>  // 0: (x, x^2)   1: (dz, dz*xhat) mask from s*x+t   2: same, mask from y, optional dz store   3: no relu
+__global__ __launch_bounds__(256) void sums_kernel(const T* __restrict__ X, const T* __restrict__ DY, const T* __restrict__ Y,
                                                    const float* __restrict__ sc, const float* __restrict__ sh,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, Geo g,
-                                                   float* __restrict__ DZ, double* __restrict__ partial) {
+                                                   T* __restrict__ DZ, double* __restrict__ partial) {
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.y * CT + cl * 4;
   const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);
@@ -45,19 +74,19 @@ __global__ __launch_bounds__(256) void sums_kernel(const float* __restrict__ X, 
   }
   for (long r = r0 + rl; r < r1; r += 16) {
     const size_t o = (size_t)r * g.C + c;
-    const float4 x = *reinterpret_cast<const float4*>(X + o);
+    const float4 x = Act<T>::ld(X + o);
     if (MODE == 0) {
       a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
       b.x = __fmaf_rn(x.x, x.x, b.x); b.y = __fmaf_rn(x.y, x.y, b.y); b.z = __fmaf_rn(x.z, x.z, b.z); b.w = __fmaf_rn(x.w, x.w, b.w);
     } else {
-      float4 d = *reinterpret_cast<const float4*>(DY + o);
+      float4 d = Act<T>::ld(DY + o);
       if (MODE == 1) {
         d.x = __fmaf_rn(vs.x, x.x, vt.x) > 0.f ? d.x : 0.f; d.y = __fmaf_rn(vs.y, x.y, vt.y) > 0.f ? d.y : 0.f;
         d.z = __fmaf_rn(vs.z, x.z, vt.z) > 0.f ? d.z : 0.f; d.w = __fmaf_rn(vs.w, x.w, vt.w) > 0.f ? d.w : 0.f;
       } else if (MODE == 2) {
-        const float4 y = *reinterpret_cast<const float4*>(Y + o);
+        const float4 y = Act<T>::ld(Y + o);
         d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f; d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
-        if (DZ) *reinterpret_cast<float4*>(DZ + o) = d;
+        if (DZ) Act<T>::st(DZ + o, d);
       }
       a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
       b.x = __fmaf_rn(d.x, (x.x - vm.x) * vr.x, b.x); b.y = __fmaf_rn(d.y, (x.y - vm.y) * vr.y, b.y);
@@ -109,22 +138,23 @@ __global__ __launch_bounds__(256) void fwd_finalize_kernel(const double* __restr
 }
 
 // y = act(s*x + t [+ skip])
-__global__ __launch_bounds__(256) void fwd_apply_kernel(const float* __restrict__ X, const float* __restrict__ S, const float* __restrict__ sc,
-                                                        const float* __restrict__ sh, Geo g, int relu, float* __restrict__ Y) {
+template <class T>
+__global__ __launch_bounds__(256) void fwd_apply_kernel(const T* __restrict__ X, const T* __restrict__ S, const float* __restrict__ sc,
+                                                        const float* __restrict__ sh, Geo g, int relu, T* __restrict__ Y) {
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.y * CT + cl * 4;
   const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);
   const float4 vs = *reinterpret_cast<const float4*>(sc + c), vt = *reinterpret_cast<const float4*>(sh + c);
   for (long r = r0 + rl; r < r1; r += 16) {
     const size_t o = (size_t)r * g.C + c;
-    const float4 x = *reinterpret_cast<const float4*>(X + o);
+    const float4 x = Act<T>::ld(X + o);
     float4 y = make_float4(__fmaf_rn(vs.x, x.x, vt.x), __fmaf_rn(vs.y, x.y, vt.y), __fmaf_rn(vs.z, x.z, vt.z), __fmaf_rn(vs.w, x.w, vt.w));
     if (S) {
-      const float4 k = *reinterpret_cast<const float4*>(S + o);
+      const float4 k = Act<T>::ld(S + o);
       y.x += k.x; y.y += k.y; y.z += k.z; y.w += k.w;
     }
     if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-    *reinterpret_cast<float4*>(Y + o) = y;
+    Act<T>::st(Y + o, y);
   }
 }
 
@@ -146,11 +176,11 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restr
 }
 
 // dx = k1 * (dz - k2 - xhat*k3); dz = DZ (materialised) or dy masked by s*x+t > 0 (relu) or dy (no relu)
-template <int MODE>  // 1: mask from x   2: dz given   3: no relu
-__global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ sc,
+template <int MODE, class T>  // 1: mask from x   2: dz given   3: no relu
+__global__ __launch_bounds__(256) void bwd_apply_kernel(const T* __restrict__ X, const T* __restrict__ D, const float* __restrict__ sc,
                                                         const float* __restrict__ sh, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ k, Geo g,
-                                                        float* __restrict__ DX) {
+                                                        T* __restrict__ DX) {
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.y * CT + cl * 4;
   const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);
@@ -161,8 +191,8 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
   if (MODE == 1) { vs = *reinterpret_cast<const float4*>(sc + c); vt = *reinterpret_cast<const float4*>(sh + c); }
   for (long r = r0 + rl; r < r1; r += 16) {
     const size_t o = (size_t)r * g.C + c;
-    const float4 x = *reinterpret_cast<const float4*>(X + o);
-    float4 d = *reinterpret_cast<const float4*>(D + o);
+    const float4 x = Act<T>::ld(X + o);
+    float4 d = Act<T>::ld(D + o);
     if (MODE == 1) {
       d.x = __fmaf_rn(vs.x, x.x, vt.x) > 0.f ? d.x : 0.f; d.y = __fmaf_rn(vs.y, x.y, vt.y) > 0.f ? d.y : 0.f;
       d.z = __fmaf_rn(vs.z, x.z, vt.z) > 0.f ? d.z : 0.f; d.w = __fmaf_rn(vs.w, x.w, vt.w) > 0.f ? d.w : 0.f;
@@ -172,7 +202,7 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
     o4.y = k1.y * (d.y - k2.y - (x.y - vm.y) * vr.y * k3.y);
     o4.z = k1.z * (d.z - k2.z - (x.z - vm.z) * vr.z * k3.z);
     o4.w = k1.w * (d.w - k2.w - (x.w - vm.w) * vr.w * k3.w);
-    *reinterpret_cast<float4*>(DX + o) = o4;
+    Act<T>::st(DX + o, o4);
   }
 }
 
@@ -198,8 +228,9 @@ __device__ __forceinline__ void pix_advance(Pix& p, int step, int H, int W) {
   }
 }
 
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ X, const float* __restrict__ sc, const float* __restrict__ sh,
-                                                       Geo g, PoolGeo pg, float* __restrict__ Yp) {
+template <class T>  // Ia (bf16 flavour): window tap index (0..8, row-major; 255 = none) of the FIRST maximum, for the backward's routing
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ X, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                       Geo g, PoolGeo pg, T* __restrict__ Yp, unsigned char* __restrict__ Ia) {
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.y * CT + cl * 4;
   const long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = min(g.R, r0 + g.rows_per_blk);  // rows = pooled pixels
@@ -218,15 +249,31 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
         const int w = min(max(2 * wo + dx, 0), pg.W - 1);
-        xs[(dy + 1) * 3 + dx + 1] = *reinterpret_cast<const float4*>(X + ((size_t)(b * pg.H + h) * pg.W + w) * g.C + c);
+        xs[(dy + 1) * 3 + dx + 1] = Act<T>::ld(X + ((size_t)(b * pg.H + h) * pg.W + w) * g.C + c);
       }
     }
+    if (Ia) {  // strict > over the in-image taps in scan order: torch's max_pool2d arg-max (first maximum); relu floor 0 = no tap
+      unsigned i0 = 255, i1 = 255, i2 = 255, i3 = 255;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      m.x = fmaxf(m.x, __fmaf_rn(vs.x, xs[t].x, vt.x)); m.y = fmaxf(m.y, __fmaf_rn(vs.y, xs[t].y, vt.y));
-      m.z = fmaxf(m.z, __fmaf_rn(vs.z, xs[t].z, vt.z)); m.w = fmaxf(m.w, __fmaf_rn(vs.w, xs[t].w, vt.w));
+      for (int t = 0; t < 9; ++t) {
+        const int hh = 2 * ho + t / 3 - 1, ww = 2 * wo + t % 3 - 1;
+        const bool in = hh >= 0 && hh < pg.H && ww >= 0 && ww < pg.W;
+        const float v0 = __fmaf_rn(vs.x, xs[t].x, vt.x), v1 = __fmaf_rn(vs.y, xs[t].y, vt.y), v2 = __fmaf_rn(vs.z, xs[t].z, vt.z),
+                    v3 = __fmaf_rn(vs.w, xs[t].w, vt.w);
+        if (in && v0 > m.x) { m.x = v0; i0 = t; }
+        if (in && v1 > m.y) { m.y = v1; i1 = t; }
+        if (in && v2 > m.z) { m.z = v2; i2 = t; }
+        if (in && v3 > m.w) { m.w = v3; i3 = t; }
+      }
+      *reinterpret_cast<unsigned*>(Ia + (size_t)r * g.C + c) = i0 | (i1 << 8) | (i2 << 16) | (i3 << 24);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        m.x = fmaxf(m.x, __fmaf_rn(vs.x, xs[t].x, vt.x)); m.y = fmaxf(m.y, __fmaf_rn(vs.y, xs[t].y, vt.y));
+        m.z = fmaxf(m.z, __fmaf_rn(vs.z, xs[t].z, vt.z)); m.w = fmaxf(m.w, __fmaf_rn(vs.w, xs[t].w, vt.w));
+      }
     }
-    *reinterpret_cast<float4*>(Yp + (size_t)r * g.C + c) = m;
+    Act<T>::st(Yp + (size_t)r * g.C + c, m);
   }
 }
 
@@ -244,12 +291,19 @@ __device__ __forceinline__ void route(float4& dz, const float4 y, const float4 y
   dz.z += (ok && y.z > 0.f && y.z == yp.z) ? dp.z : 0.f; dz.w += (ok && y.w > 0.f && y.w == yp.w) ? dp.w : 0.f;
 }
 
-template <bool APPLY>  // false: per-block sums (dz, dz*xhat); true: dx = k1*(dz - k2 - xhat*k3).  g describes the QUAD rows.
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yp, const float* __restrict__ Dp,
+// index flavour of route(): the window's recorded arg-max tap (byte per channel) against this pixel's tap index in that window
+__device__ __forceinline__ void route_idx(float4& dz, const float4 y, unsigned ia, const float4 dp, bool ok, unsigned tap) {
+  dz.x += (ok && y.x > 0.f && (ia & 255u) == tap) ? dp.x : 0.f; dz.y += (ok && y.y > 0.f && ((ia >> 8) & 255u) == tap) ? dp.y : 0.f;
+  dz.z += (ok && y.z > 0.f && ((ia >> 16) & 255u) == tap) ? dp.z : 0.f; dz.w += (ok && y.w > 0.f && (ia >> 24) == tap) ? dp.w : 0.f;
+}
+
+template <bool APPLY, class T>  // false: per-block sums (dz, dz*xhat); true: dx = k1*(dz - k2 - xhat*k3).  g describes the QUAD rows.
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ X, const float* __restrict__ Yp, const unsigned char* __restrict__ Ia,
+                                                       const T* __restrict__ Dp,
                                                        const float* __restrict__ sc, const float* __restrict__ sh,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ k, Geo g, PoolGeo pg, double* __restrict__ partial,
-                                                       float* __restrict__ DX) {
+                                                       T* __restrict__ DX) {
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.y * CT + cl * 4;
   const int Hq = (pg.H + 1) / 2, Wq = (pg.W + 1) / 2;
@@ -274,10 +328,15 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const size_t op[4] = {((pb + q.h) * pg.Wo + q.w) * g.C + c, ((pb + q.h) * pg.Wo + j1) * g.C + c, ((pb + i1) * pg.Wo + q.w) * g.C + c,
                           ((pb + i1) * pg.Wo + j1) * g.C + c};
     float4 x[4], yp[4], dp[4];
+    unsigned ia[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) x[t] = *reinterpret_cast<const float4*>(X + ox[t]);
+    for (int t = 0; t < 4; ++t) x[t] = Act<T>::ld(X + ox[t]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { yp[t] = *reinterpret_cast<const float4*>(Yp + op[t]); dp[t] = *reinterpret_cast<const float4*>(Dp + op[t]); }
+    for (int t = 0; t < 4; ++t) {
+      if (Ia) { ia[t] = *reinterpret_cast<const unsigned*>(Ia + op[t]); yp[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      else { yp[t] = *reinterpret_cast<const float4*>(Yp + op[t]); ia[t] = 0; }
+      dp[t] = Act<T>::ld(Dp + op[t]);
+    }
     const bool pix_ok[4] = {true, pw, ph, ph && pw};
     const bool win_ok[4] = {true, ww, wh, wh && ww};
 #pragma unroll
@@ -285,14 +344,23 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
       if (!pix_ok[t]) continue;  // uniform per quad position except at odd image borders
       const float4 y = relu_bn(x[t], vs, vt);
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-      route(d, y, yp[0], dp[0], true);                       // window (i, j) covers every pixel of the quad
-      if (t & 1) route(d, y, yp[1], dp[1], win_ok[1]);       // (i, j+1) covers the odd column
-      if (t & 2) route(d, y, yp[2], dp[2], win_ok[2]);       // (i+1, j) covers the odd row
-      if (t == 3) route(d, y, yp[3], dp[3], win_ok[3]);
+      if (Ia) {  // bf16 flavour: bf16 inputs tie often and equality would route to every tie; tap of pixel (a, b) of the quad in
+                 // window (i + wi, j + wj) is (a - 2 wi + 1) * 3 + (b - 2 wj + 1)
+        const unsigned a = t >> 1, b = t & 1;
+        route_idx(d, y, ia[0], dp[0], true, (a + 1) * 3 + b + 1);
+        if (t & 1) route_idx(d, y, ia[1], dp[1], win_ok[1], (a + 1) * 3);
+        if (t & 2) route_idx(d, y, ia[2], dp[2], win_ok[2], b + 1);
+        if (t == 3) route_idx(d, y, ia[3], dp[3], win_ok[3], 0);
+      } else {
+        route(d, y, yp[0], dp[0], true);                       // window (i, j) covers every pixel of the quad
+        if (t & 1) route(d, y, yp[1], dp[1], win_ok[1]);       // (i, j+1) covers the odd column
+        if (t & 2) route(d, y, yp[2], dp[2], win_ok[2]);       // (i+1, j) covers the odd row
+        if (t == 3) route(d, y, yp[3], dp[3], win_ok[3]);
+      }
       const float4 xh = make_float4((x[t].x - vm.x) * vr.x, (x[t].y - vm.y) * vr.y, (x[t].z - vm.z) * vr.z, (x[t].w - vm.w) * vr.w);
       if (APPLY) {
-        *reinterpret_cast<float4*>(DX + ox[t]) = make_float4(k1.x * (d.x - k2.x - xh.x * k3.x), k1.y * (d.y - k2.y - xh.y * k3.y),
-                                                             k1.z * (d.z - k2.z - xh.z * k3.z), k1.w * (d.w - k2.w - xh.w * k3.w));
+        Act<T>::st(DX + ox[t], make_float4(k1.x * (d.x - k2.x - xh.x * k3.x), k1.y * (d.y - k2.y - xh.y * k3.y),
+                                           k1.z * (d.z - k2.z - xh.z * k3.z), k1.w * (d.w - k2.w - xh.w * k3.w)));
       } else {
         a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
         bb.x = __fmaf_rn(d.x, xh.x, bb.x); bb.y = __fmaf_rn(d.y, xh.y, bb.y); bb.z = __fmaf_rn(d.z, xh.z, bb.z); bb.w = __fmaf_rn(d.w, xh.w, bb.w);
@@ -337,9 +405,15 @@ long obman_bnact_ws_floats(long R, int C) {
   return (long)g.nblk * C * 2 * 2 + 3L * C + 16;  // fp64 partials + backward coefficients
 }
 
+}  // extern "C"
+
+namespace {
+using bnact::Act;
+
 /* stats: [mean C | rstd C | scale C | shift C] written by fwd and read by bwd */
-int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const float* beta, float* rmean, float* rvar, long R, int C,
-                    int training, float eps, float momentum, int relu, float* y, float* stats, float* ws, obman_stream_t stream) {
+template <class T>
+int bnact_fwd(const T* x, const T* skip, const float* gamma, const float* beta, float* rmean, float* rvar, long R, int C,
+              int training, float eps, float momentum, int relu, T* y, float* stats, float* ws, obman_stream_t stream) {
   if (!x || !y || !stats || !ws || !gamma || !beta || R <= 0 || C <= 0 || C % bnact::CT) return -1;
   if (!training && (!rmean || !rvar)) return -2;
   hipStream_t st = (hipStream_t)stream;
@@ -348,13 +422,13 @@ int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const
   double* partial = reinterpret_cast<double*>(ws);
   float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   if (training) {
-    bnact::sums_kernel<0><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
+    bnact::sums_kernel<0, T><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
     OBMAN_LAUNCH_CHECK();
   }
   bnact::fwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, eps, momentum, gamma, beta, rmean, rvar, mean,
                                                                 rstd, sc, sh);
   OBMAN_LAUNCH_CHECK();
-  bnact::fwd_apply_kernel<<<grid, 256, 0, st>>>(x, skip, sc, sh, g, relu, y);
+  bnact::fwd_apply_kernel<T><<<grid, 256, 0, st>>>(x, skip, sc, sh, g, relu, y);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -362,8 +436,9 @@ int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const
 /* dy -> dx, dgamma, dbeta [, dskip].  y is needed only with a skip connection (mask of the post-add ReLU).  dskip (the
  * gradient flowing into the skip branch = masked dy) is written when non-NULL; it doubles as the dz scratch, so it is
  * required whenever relu && has_skip. */
-int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats, long R, int C, int training,
-                    int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream) {
+template <class T>
+int bnact_bwd(const T* x, const T* y, const T* dy, const float* gamma, const float* stats, long R, int C, int training,
+              int relu, int has_skip, T* dx, float* dgamma, float* dbeta, T* dskip, float* ws, obman_stream_t stream) {
   if (!x || !dy || !stats || !ws || !dx || !dgamma || !dbeta || R <= 0 || C % bnact::CT) return -1;
   if (relu && has_skip && (!y || !dskip)) return -2;
   hipStream_t st = (hipStream_t)stream;
@@ -373,23 +448,24 @@ int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float
   float* k = ws + (size_t)g.nblk * C * 2 * 2;  // 3*C coefficients live behind the partials
   const float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   const int mode = !relu ? 3 : (has_skip ? 2 : 1);
-  if (mode == 1) bnact::sums_kernel<1><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
-  else if (mode == 2) bnact::sums_kernel<2><<<grid, 256, 0, st>>>(x, dy, y, sc, sh, mean, rstd, g, dskip, partial);
-  else bnact::sums_kernel<3><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
+  if (mode == 1) bnact::sums_kernel<1, T><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
+  else if (mode == 2) bnact::sums_kernel<2, T><<<grid, 256, 0, st>>>(x, dy, y, sc, sh, mean, rstd, g, dskip, partial);
+  else bnact::sums_kernel<3, T><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
   OBMAN_LAUNCH_CHECK();
   bnact::bwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, gamma, rstd, dgamma, dbeta, k);
   OBMAN_LAUNCH_CHECK();
-  if (mode == 1) bnact::bwd_apply_kernel<1><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
-  else if (mode == 2) bnact::bwd_apply_kernel<2><<<grid, 256, 0, st>>>(x, dskip, sc, sh, mean, rstd, k, g, dx);
-  else bnact::bwd_apply_kernel<3><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
+  if (mode == 1) bnact::bwd_apply_kernel<1, T><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
+  else if (mode == 2) bnact::bwd_apply_kernel<2, T><<<grid, 256, 0, st>>>(x, dskip, sc, sh, mean, rstd, k, g, dx);
+  else bnact::bwd_apply_kernel<3, T><<<grid, 256, 0, st>>>(x, dy, sc, sh, mean, rstd, k, g, dx);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
 
 /* Stem: y_pool = maxpool3x3/s2/p1(relu(bn(x))).  x [B,H,W,C] NHWC, y_pool [B,Ho,Wo,C], Ho = (H-1)/2+1.
  * ws: obman_bnact_ws_floats(B*H*W, C) floats. */
-int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
-                     int training, float eps, float momentum, float* y_pool, float* stats, float* ws, obman_stream_t stream) {
+template <class T>
+int bnpool_fwd(const T* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
+               int training, float eps, float momentum, T* y_pool, unsigned char* amax, float* stats, float* ws, obman_stream_t stream) {
   if (!x || !y_pool || !stats || !ws || !gamma || !beta || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % bnact::CT) return -1;
   if ((long)B * H * W >= (1L << 31)) return -1;  // pixel indices are 32-bit
   if (!training && (!rmean || !rvar)) return -2;
@@ -399,7 +475,7 @@ int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, floa
   double* partial = reinterpret_cast<double*>(ws);
   float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   if (training) {
-    bnact::sums_kernel<0><<<dim3(g.nblk, C / bnact::CT), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
+    bnact::sums_kernel<0, T><<<dim3(g.nblk, C / bnact::CT), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
     OBMAN_LAUNCH_CHECK();
   }
   bnact::fwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, eps, momentum, gamma, beta, rmean, rvar, mean,
@@ -407,14 +483,15 @@ int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, floa
   OBMAN_LAUNCH_CHECK();
   const bnact::PoolGeo pg{H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
   const bnact::Geo gp = bnact::geo((long)B * pg.Ho * pg.Wo, C);
-  bnact::pool_fwd_kernel<<<dim3(gp.nblk, C / bnact::CT), 256, 0, st>>>(x, sc, sh, gp, pg, y_pool);
+  bnact::pool_fwd_kernel<T><<<dim3(gp.nblk, C / bnact::CT), 256, 0, st>>>(x, sc, sh, gp, pg, y_pool, amax);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
 
-int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, const float* gamma, const float* stats, int B, int H, int W,
-                     int C, int training, float* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream) {
-  if (!x || !y_pool || !d_pool || !stats || !ws || !dx || !dgamma || !dbeta || B <= 0 || C % bnact::CT) return -1;
+template <class T>
+int bnpool_bwd(const T* x, const float* y_pool, const unsigned char* amax, const T* d_pool, const float* gamma, const float* stats, int B, int H, int W,
+               int C, int training, T* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream) {
+  if (!x || (!y_pool && !amax) || !d_pool || !stats || !ws || !dx || !dgamma || !dbeta || B <= 0 || C % bnact::CT) return -1;
   if ((long)B * H * W >= (1L << 31)) return -1;  // pixel indices are 32-bit
   hipStream_t st = (hipStream_t)stream;
   const long R = (long)B * H * W;
@@ -424,13 +501,56 @@ int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, c
   float* k = ws + (size_t)bnact::geo(R, C).nblk * C * 2 * 2;  // workspace is sized for the pixel geometry (>= quad geometry)
   const float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   dim3 grid(g.nblk, C / bnact::CT);
-  bnact::pool_bwd_kernel<false><<<grid, 256, 0, st>>>(x, y_pool, d_pool, sc, sh, mean, rstd, nullptr, g, pg, partial, nullptr);
+  bnact::pool_bwd_kernel<false, T><<<grid, 256, 0, st>>>(x, y_pool, amax, d_pool, sc, sh, mean, rstd, nullptr, g, pg, partial, nullptr);
   OBMAN_LAUNCH_CHECK();
   bnact::bwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, gamma, rstd, dgamma, dbeta, k);
   OBMAN_LAUNCH_CHECK();
-  bnact::pool_bwd_kernel<true><<<grid, 256, 0, st>>>(x, y_pool, d_pool, sc, sh, mean, rstd, k, g, pg, nullptr, dx);
+  bnact::pool_bwd_kernel<true, T><<<grid, 256, 0, st>>>(x, y_pool, amax, d_pool, sc, sh, mean, rstd, k, g, pg, nullptr, dx);
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const float* beta, float* rmean, float* rvar, long R, int C,
+                    int training, float eps, float momentum, int relu, float* y, float* stats, float* ws, obman_stream_t stream) {
+  return bnact_fwd<float>(x, skip, gamma, beta, rmean, rvar, R, C, training, eps, momentum, relu, y, stats, ws, stream);
+}
+int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats, long R, int C, int training,
+                    int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream) {
+  return bnact_bwd<float>(x, y, dy, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
+}
+int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
+                     int training, float eps, float momentum, float* y_pool, float* stats, float* ws, obman_stream_t stream) {
+  return bnpool_fwd<float>(x, gamma, beta, rmean, rvar, B, H, W, C, training, eps, momentum, y_pool, nullptr, stats, ws, stream);
+}
+int obman_bnpool_bwd(const float* x, const float* y_pool, const float* d_pool, const float* gamma, const float* stats, int B, int H, int W,
+                     int C, int training, float* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream) {
+  return bnpool_bwd<float>(x, y_pool, nullptr, d_pool, gamma, stats, B, H, W, C, training, dx, dgamma, dbeta, ws, stream);
+}
+/* bf16 activations (raw bits), everything else as above */
+int obman_bnact_fwd_bf16(const uint16_t* x, const uint16_t* skip, const float* gamma, const float* beta, float* rmean, float* rvar, long R,
+                         int C, int training, float eps, float momentum, int relu, uint16_t* y, float* stats, float* ws,
+                         obman_stream_t stream) {
+  return bnact_fwd<bnact::bfraw>(x, skip, gamma, beta, rmean, rvar, R, C, training, eps, momentum, relu, y, stats, ws, stream);
+}
+int obman_bnact_bwd_bf16(const uint16_t* x, const uint16_t* y, const uint16_t* dy, const float* gamma, const float* stats, long R, int C,
+                         int training, int relu, int has_skip, uint16_t* dx, float* dgamma, float* dbeta, uint16_t* dskip, float* ws,
+                         obman_stream_t stream) {
+  return bnact_bwd<bnact::bfraw>(x, y, dy, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
+}
+int obman_bnpool_fwd_bf16(const uint16_t* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
+                          int training, float eps, float momentum, uint16_t* y_pool, uint8_t* amax, float* stats, float* ws,
+                          obman_stream_t stream) {
+  if (!amax) return -1;
+  return bnpool_fwd<bnact::bfraw>(x, gamma, beta, rmean, rvar, B, H, W, C, training, eps, momentum, y_pool, amax, stats, ws, stream);
+}
+int obman_bnpool_bwd_bf16(const uint16_t* x, const uint8_t* amax, const uint16_t* d_pool, const float* gamma, const float* stats, int B,
+                          int H, int W, int C, int training, uint16_t* dx, float* dgamma, float* dbeta, float* ws, obman_stream_t stream) {
+  if (!amax) return -1;
+  return bnpool_bwd<bnact::bfraw>(x, nullptr, amax, d_pool, gamma, stats, B, H, W, C, training, dx, dgamma, dbeta, ws, stream);
 }
 
 }  // extern "C"

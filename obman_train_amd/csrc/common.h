@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define OBMAN_ABI_VERSION 2
+#define OBMAN_ABI_VERSION 3
 #define OBMAN_WAVE 64
 
 #define OBMAN_LAUNCH_CHECK()                       \

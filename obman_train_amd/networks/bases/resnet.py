@@ -117,7 +117,7 @@ class ResNet(nn.Module):
         dtype = getattr(self, "autocast_dtype", None)
         if dtype is not None and x.is_cuda and not torch.is_autocast_enabled():
             # opt-in reduced-precision encoder (BASELINE configs[2] "bf16"): convolutions on the bf16 MFMA path, features
-            # handed to the fp32 heads.  The fused fp32 BN kernels are bypassed (stock bf16 BatchNorm) in this mode.
+            # handed to the fp32 heads; the fused BN kernels take the bf16 activations (fp32 statistics and parameters).
             with torch.autocast("cuda", dtype=dtype):
                 feats, extra = self.forward(x)
             return feats.float(), extra

@@ -386,8 +386,16 @@ def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
+_BN_DTYPES = (torch.float32, torch.bfloat16)
+
+
+def _bn_entry(name, dtype):
+    """C-ABI entry point of the fused BN family for fp32 / bf16 activations."""
+    return getattr(_lib.lib(), name + ("_bf16" if dtype == torch.bfloat16 else ""))
+
+
 class _BNAct(torch.autograd.Function):
-    """BatchNorm2d (+ skip) (+ ReLU) on a channels_last fp32 tensor (csrc/bnact.hip)."""
+    """BatchNorm2d (+ skip) (+ ReLU) on a channels_last fp32 or bf16 tensor (csrc/bnact.hip; parameters and statistics fp32)."""
 
     @staticmethod
     def forward(ctx, x, skip, weight, bias, rmean, rvar, training, eps, momentum, relu):
@@ -397,9 +405,9 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty_like(x)  # preserves channels_last
         stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.obman_bnact_ws_floats(R, C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.obman_bnact_fwd(x.data_ptr(), _ptr(skip), weight.data_ptr(), bias.data_ptr(), _ptr(rmean), _ptr(rvar), R, C,
-                                       int(training), float(eps), float(momentum), int(relu), y.data_ptr(), stats.data_ptr(),
-                                       ws.data_ptr(), _stream()), "obman_bnact_fwd")
+        _lib.check(_bn_entry("obman_bnact_fwd", x.dtype)(x.data_ptr(), _ptr(skip), weight.data_ptr(), bias.data_ptr(), _ptr(rmean),
+                                                         _ptr(rvar), R, C, int(training), float(eps), float(momentum), int(relu),
+                                                         y.data_ptr(), stats.data_ptr(), ws.data_ptr(), _stream()), "obman_bnact_fwd")
         ctx.save_for_backward(x, y if (relu and skip is not None) else None, weight, stats)
         ctx.cfg = (R, C, int(training), int(relu), skip is not None)
         return y
@@ -409,6 +417,8 @@ class _BNAct(torch.autograd.Function):
         x, y, weight, stats = ctx.saved_tensors
         R, C, training, relu, has_skip = ctx.cfg
         lib = _lib.lib()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         if not _is_nhwc(dy):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
@@ -416,19 +426,20 @@ class _BNAct(torch.autograd.Function):
         dbeta = torch.empty_like(weight)
         dskip = torch.empty_like(x) if (has_skip and relu) else None
         ws = torch.empty(lib.obman_bnact_ws_floats(R, C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.obman_bnact_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), weight.data_ptr(), stats.data_ptr(), R, C, training, relu,
-                                       int(has_skip), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dskip), ws.data_ptr(),
-                                       _stream()), "obman_bnact_bwd")
+        _lib.check(_bn_entry("obman_bnact_bwd", x.dtype)(x.data_ptr(), _ptr(y), dy.data_ptr(), weight.data_ptr(), stats.data_ptr(), R, C,
+                                                         training, relu, int(has_skip), dx.data_ptr(), dgamma.data_ptr(),
+                                                         dbeta.data_ptr(), _ptr(dskip), ws.data_ptr(), _stream()), "obman_bnact_bwd")
         if has_skip and not relu:
             dskip = dy
         return dx, dskip, dgamma, dbeta, None, None, None, None, None, None
 
 
 def bn_act(bn, x, skip=None, relu=True, count=True):
-    """``relu(bn(x) [+ skip])`` for an ``nn.BatchNorm2d`` module ``bn``.  Fused HIP path for channels_last fp32 ROCm tensors
-    whose channel count is a multiple of 64 (every ResNet-18/50 stage); anything else takes the stock PyTorch ops."""
-    fused = (x.is_cuda and x.dtype == torch.float32 and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
-             and (skip is None or (_is_nhwc(skip) and skip.dtype == torch.float32 and skip.shape == x.shape)))
+    """``relu(bn(x) [+ skip])`` for an ``nn.BatchNorm2d`` module ``bn``.  Fused HIP path for channels_last fp32 or bf16 (autocast
+    encoder) ROCm tensors whose channel count is a multiple of 64 (every ResNet-18/50 stage); anything else takes the stock ops."""
+    fused = (x.is_cuda and x.dtype in _BN_DTYPES and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
+             and bn.weight.dtype == torch.float32
+             and (skip is None or (_is_nhwc(skip) and skip.dtype == x.dtype and skip.shape == x.shape)))
     training = bn.training or bn.running_mean is None
     if count and bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1  # callers with many layers pass count=False and bump all counters in one launch
@@ -513,13 +524,20 @@ class _BNReLUPool(torch.autograd.Function):
         B, C, H, W = x.shape
         lib = _lib.lib()
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
         stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.obman_bnact_ws_floats(B * H * W, C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.obman_bnpool_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(rmean), _ptr(rvar), B, H, W, C,
-                                        int(training), float(eps), float(momentum), y.data_ptr(), stats.data_ptr(), ws.data_ptr(),
-                                        _stream()), "obman_bnpool_fwd")
-        ctx.save_for_backward(x, y, weight, stats)
+        if x.dtype == torch.bfloat16:  # arg-max taps for the backward: equality routing would hit every tie of the bf16 inputs
+            y32 = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.obman_bnpool_fwd_bf16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(rmean), _ptr(rvar), B, H, W, C,
+                                                 int(training), float(eps), float(momentum), y.data_ptr(), y32.data_ptr(),
+                                                 stats.data_ptr(), ws.data_ptr(), _stream()), "obman_bnpool_fwd_bf16")
+        else:
+            y32 = y
+            _lib.check(lib.obman_bnpool_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(rmean), _ptr(rvar), B, H, W, C,
+                                            int(training), float(eps), float(momentum), y.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                            _stream()), "obman_bnpool_fwd")
+        ctx.save_for_backward(x, y32, weight, stats)
         ctx.cfg = (B, H, W, C, int(training))
         return y
 
@@ -528,25 +546,27 @@ class _BNReLUPool(torch.autograd.Function):
         x, y, weight, stats = ctx.saved_tensors
         B, H, W, C, training = ctx.cfg
         lib = _lib.lib()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         if not _is_nhwc(dy):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(weight), torch.empty_like(weight)
         ws = torch.empty(lib.obman_bnact_ws_floats(B * H * W, C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.obman_bnpool_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), weight.data_ptr(), stats.data_ptr(), B, H, W, C,
-                                        training, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream()),
-                   "obman_bnpool_bwd")
+        _lib.check(_bn_entry("obman_bnpool_bwd", x.dtype)(x.data_ptr(), y.data_ptr(), dy.data_ptr(), weight.data_ptr(), stats.data_ptr(),
+                                                          B, H, W, C, training, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                          ws.data_ptr(), _stream()), "obman_bnpool_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
 def bn_relu_maxpool(bn, x, pool, count=True):
-    """``pool(relu(bn(x)))`` for ``nn.MaxPool2d(3, stride=2, padding=1)``; fused for channels_last fp32 ROCm tensors with
+    """``pool(relu(bn(x)))`` for ``nn.MaxPool2d(3, stride=2, padding=1)``; fused for channels_last fp32 / bf16 ROCm tensors with
     C % 64 == 0, stock ops otherwise."""
     def _t(v):
         return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
-    fused = (x.is_cuda and x.dtype == torch.float32 and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
-             and _t(pool.kernel_size) == (3, 3) and _t(pool.stride) == (2, 2) and _t(pool.padding) == (1, 1)
+    fused = (x.is_cuda and x.dtype in _BN_DTYPES and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
+             and bn.weight.dtype == torch.float32 and _t(pool.kernel_size) == (3, 3) and _t(pool.stride) == (2, 2) and _t(pool.padding) == (1, 1)
              and _t(pool.dilation) == (1, 1) and not pool.ceil_mode and not pool.return_indices)
     if not fused:
         return pool(bn_act(bn, x, relu=True, count=count))

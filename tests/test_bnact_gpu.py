@@ -111,3 +111,82 @@ def test_resnet18_with_fused_bn_matches_stock_blocks():
         err = (p1.grad.cpu() - p2.grad).abs().max().item()
         assert err <= 2e-2 * p2.grad.abs().max().item() + 1e-6, (n1, err)
     np.testing.assert_allclose(net.layer3[0].bn1.running_var.cpu().numpy(), ref.layer3[0].bn1.running_var.numpy(), rtol=1e-3)
+
+
+def _bf16_close(a, b, name, tol):
+    """relative L2 error of a bf16 result against the fp32 reference"""
+    a, b = a.float(), b.float()
+    err = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+    assert err <= tol, (name, err)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (2, 128, 9, 7), (16, 64, 32, 32)])
+@pytest.mark.parametrize("relu,has_skip,training", [(True, False, True), (True, True, True), (False, False, True), (True, True, False)])
+def test_bn_act_bf16_activations(shape, relu, has_skip, training):
+    """bf16 flavour (autocast encoder of BASELINE configs[2]): bf16 x / skip / dy in, bf16 y / dx / dskip out, fp32 parameters and
+    statistics.  Reference: the fp32 op sequence on the SAME bf16-rounded inputs; the fused kernel rounds once at each store, so
+    values agree to bf16 precision (2^-8 relative per element) and the fp32 outputs (dgamma, dbeta, running stats) much closer."""
+    from obman_train_amd import ops
+
+    torch.manual_seed(2)
+    B, C, H, W = shape
+    bn = nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+    bn.train(training)
+    bn_ref = copy.deepcopy(bn)
+    nhwc = dict(memory_format=torch.channels_last)
+    x = (torch.randn(shape, device="cuda") * 2 + 0.7).bfloat16().contiguous(**nhwc)
+    skip = torch.randn(shape, device="cuda").bfloat16().contiguous(**nhwc) if has_skip else None
+    w = torch.randn(shape, device="cuda").bfloat16().contiguous(**nhwc)
+    xa, xb = x.clone().requires_grad_(), x.float().requires_grad_()
+    sa = skip.clone().requires_grad_() if has_skip else None
+    sb = skip.float().requires_grad_() if has_skip else None
+    ya = ops.bn_act(bn, xa, skip=sa, relu=relu)
+    yb = _ref(bn_ref, xb, sb, relu)
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous(**nhwc)
+    torch.testing.assert_close(ya.float(), yb, rtol=2 ** -7, atol=1e-2)   # one bf16 rounding of the fp32 result
+    (ya.float() * w.float()).sum().backward()
+    (yb * w.float()).sum().backward()
+    assert xa.grad.dtype == torch.bfloat16
+    _bf16_close(xa.grad, xb.grad, "dx", 1e-2)
+    if has_skip:
+        _bf16_close(sa.grad, sb.grad, "dskip", 1e-2)
+    # the reductions are fp32 / fp64 in both: they differ only through the bf16 rounding of y's ReLU mask inputs
+    _bf16_close(bn.weight.grad, bn_ref.weight.grad, "dgamma", 2e-3)
+    _bf16_close(bn.bias.grad, bn_ref.bias.grad, "dbeta", 2e-3)
+    torch.testing.assert_close(bn.running_mean, bn_ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, bn_ref.running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,training", [((2, 64, 16, 16), True), ((3, 64, 13, 9), True), ((8, 64, 64, 64), True), ((2, 128, 8, 8), False)])
+def test_bn_relu_maxpool_bf16_activations(shape, training):
+    from obman_train_amd import ops
+
+    torch.manual_seed(3)
+    B, C, H, W = shape
+    bn = nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(-1.0, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+    bn.train(training)
+    bn_ref = copy.deepcopy(bn)
+    pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    x = (torch.randn(shape, device="cuda") * 2 + 0.3).bfloat16().contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(), x.float().requires_grad_()
+    ya = ops.bn_relu_maxpool(bn, xa, pool)
+    yb = pool(torch.relu(bn_ref(xb)))
+    assert ya.dtype == torch.bfloat16 and ya.shape == yb.shape
+    torch.testing.assert_close(ya.float(), yb, rtol=2 ** -7, atol=1e-2)
+    w = torch.randn_like(yb).bfloat16()
+    (ya.float() * w.float()).sum().backward()
+    (yb * w.float()).sum().backward()
+    # arg-max routing can differ where two window taps round to the same bf16 value: compare in relative L2
+    _bf16_close(xa.grad, xb.grad, "dx", 5e-2)
+    _bf16_close(bn.weight.grad, bn_ref.weight.grad, "dgamma", 2e-2)
+    _bf16_close(bn.bias.grad, bn_ref.bias.grad, "dbeta", 2e-2)
+    torch.testing.assert_close(bn.running_var, bn_ref.running_var, rtol=1e-5, atol=1e-6)
