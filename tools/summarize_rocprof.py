@@ -10,11 +10,13 @@ OURS = ("pairmin", "rowmean2", "mano_", "contains_kernel", "contact_", "dec::", 
         "warp_kernel", "mean_kernel")
 
 
-def main(src, dst, steps="auto", cmd="", top=30):
+def main(src, dst, steps="auto", cmd="", top=30, steady=""):
     rows = [r for r in csv.DictReader(open(src)) if "naive_conv" not in r["Name"]]
     if steps == "auto":  # train steps executed by the profiled process = launches of a once-per-step kernel (MANO forward)
         steps = max([float(r["Calls"]) for r in rows if "mano_fwd_kernel" in r["Name"]] or [1.0])
     steps = float(steps)
+    if steady:  # drop kernels launched in fewer than half of the steps: MIOpen's find-phase candidates, probes after the timed region
+        rows = [r for r in rows if float(r["Calls"]) >= 0.5 * steps]
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
     ours = [r for r in rows if any(k in r["Name"] for k in OURS)]
     others = [r for r in rows if r not in ours]
@@ -37,4 +39,4 @@ def main(src, dst, steps="auto", cmd="", top=30):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:5], steady=sys.argv[5] if len(sys.argv) > 5 else "")
