@@ -50,6 +50,10 @@ def _worker(rank, world, port, out_dir):
     broadcast_parameters(net)
     buckets = GradientBuckets(net.parameters(), bucket_bytes=256, exclude=net.unused.parameters())
     assert len(buckets.buckets) >= 3
+    # bucket targets shrink once less than one full bucket remains: the last (exposed) bucket is the smallest
+    probe = GradientBuckets(nn.ModuleList([nn.Linear(8, 8) for _ in range(23)]).parameters(), bucket_bytes=1024, tail_bytes=64)
+    sizes = [flat.numel() * 4 for flat, _ in probe.buckets]  # 23 x (256 + 32) bytes, walked from the last layer
+    assert sizes == [1152] * 5 + [576, 288], sizes
     x, y = _data()
     shard = slice(rank * 4, rank * 4 + 4)
     for step in range(2):  # twice: bucket state must reset between steps
