@@ -1039,6 +1039,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // layer-4 blocks): out[seg][col] = sum of in[r][col] over the rows of segment seg, lanes along the contiguous columns,
 // fixed order.  The one-wave-per-channel finalize kernels below then see <= 64 rows instead of striding through megabytes.
 constexpr int PRE_SEGMENTS = 64, PRE_MIN_ROWS = 512;
+constexpr int PRE_SEGMENTS_NARROW = 256;  // arrays of <= 1024 columns (per-channel partials): 3 column blocks x 64 segments = 192
+                                         // blocks walked 125 rows each in 32 us at 8 032 row blocks; 768 blocks of 32 rows do it in a third
 template <class T>
 __global__ __launch_bounds__(256) void colsum_segments_kernel(const T* __restrict__ in, long rows, int cols, int rows_per_seg,
                                                               T* __restrict__ out) {
@@ -1549,7 +1551,7 @@ FwdWs fwd_ws(const Dims& d) {
   w.H2 = take(d.R * d.ld2 / act); w.mean2 = take(d.ld2); w.rstd2 = take(d.ld2); w.s2 = take(d.ld2); w.t2 = take(d.ld2);
   w.H3 = take(d.R * d.ld3 / act); w.mean3 = take(d.ld3); w.rstd3 = take(d.ld3); w.s3 = take(d.ld3); w.t3 = take(d.ld3);
   w.moments = take((long)d.rb * d.C2 * 2 * 2);  // doubles
-  w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
+  w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS_NARROW * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
   w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
   w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
   w.total = o;
@@ -1606,10 +1608,10 @@ BwdWs bwd_ws(const Dims& d) {
   w.GY2 = take(d.bf16 ? d.R * d.ld2 / 2 : d.R * d.ld2);
   w.GY1 = take(d.bf16 ? 0 : d.R * d.ld1);  // bf16 flavour: gy1 is never materialised (EpiL1B)
   w.sums = take((long)(d.rb > l4b ? d.rb : l4b) * d.C1 * 2 * 2);
-  w.sred = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.C1 * 2 * 2 : 0);  // doubles
+  w.sred = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS_NARROW * d.C1 * 2 * 2 : 0);  // doubles
   w.k = take(3 * d.ld1);
   w.l4p = take((long)l4b * (3 * d.C3 + 4));
-  w.l4red = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * (3 * d.C3 + 4) : 0);
+  w.l4red = take(l4b > PRE_MIN_ROWS ? (long)PRE_SEGMENTS_NARROW * (3 * d.C3 + 4) : 0);
   w.P = take((long)d.B * d.ld1); w.Q = take((long)d.N * d.ld1); w.dF = take((long)d.B * d.ld1); w.dG = take((long)d.N * d.ld1);
   if (d.ps) {  // per-sample grid: partial dF / gW1[:, 0:3] per (sample, chunk of L1PS_ROWS rows)
     const long ch = (d.N + L1PS_ROWS - 1) / L1PS_ROWS;
@@ -1724,7 +1726,8 @@ int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int
 template <class T>
 int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) {
   if (rows <= PRE_MIN_ROWS) return 0;
-  const int per = (rows + PRE_SEGMENTS - 1) / PRE_SEGMENTS, segs = (rows + per - 1) / per;
+  const int want = cols <= 1024 ? PRE_SEGMENTS_NARROW : PRE_SEGMENTS;
+  const int per = (rows + want - 1) / want, segs = (rows + per - 1) / per;
   colsum_segments_kernel<T><<<dim3(obman_cdiv(cols, 256), segs), 256, 0, st>>>(part, rows, cols, per, scratch);
   OBMAN_LAUNCH_CHECK();
   part = scratch;
