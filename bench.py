@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--trace", default=None, help="write per-step host/GPU times of every phase to this JSON file")
     ap.add_argument("--deterministic-convs", action="store_true",
                     help="experiment: torch.backends.cudnn.deterministic = True (MIOpen solutions without atomics: no output "
-                         "zeroing launches for split-K weight gradients, run-to-run identical bits)")
+                         "zeroing launches for split-K weight gradients, run-to-run identical bits).  Measured: 2327 ms/step "
+                         "(27 img/s) at configs[1] - MIOpen falls back to direct kernels; never the default")
     return ap.parse_args()
 
 
