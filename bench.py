@@ -41,6 +41,9 @@ def parse():
                     help="bf16 = AtlasNet decoder GEMMs on the bf16 matrix pipe (configs[2] flavour; NOT the headline fp32 config)")
     ap.add_argument("--force-dist", action="store_true",
                     help="self-test: run the RCCL process group + gradient buckets even with a single rank")
+    ap.add_argument("--dp-accumulate-in-place", action="store_true",
+                    help="experiment: gradients accumulate into persistent bucket views (no pack copy, one add kernel per "
+                         "parameter) instead of stolen gradients + one multi-tensor copy per bucket (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget (all legs together)")
     ap.add_argument("--precondition-max", type=int, default=60,
@@ -391,7 +394,8 @@ def main():
     model.atlas_branch.decoder.mfma_dtype = args.decoder_dtype
     broadcast_parameters(model)
     opt = make_optimizer(model, "adam", lr=1e-4)
-    buckets = GradientBuckets(model.parameters(), force=args.force_dist, exclude=model.unused_parameters()) if use_dist else None
+    buckets = GradientBuckets(model.parameters(), force=args.force_dist, exclude=model.unused_parameters(),
+                              accumulate_in_place=args.dp_accumulate_in_place) if use_dist else None
     sample = make_batch(args.batch, dev, seed=rank, image_size=args.image_size)
     # resident in the layout the input stream (DeviceImageStage(channels_last=True)) delivers: same [B,3,H,W] tensor, NHWC strides
     sample[TransQueries.images] = sample[TransQueries.images].contiguous(memory_format=torch.channels_last)
@@ -459,6 +463,18 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    # evidence for a scaling run that RCCL really saw N ranks on N devices: every rank reports where it ran
+    ranks_info = None
+    if use_dist:
+        import socket
+
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local, "hostname": socket.gethostname(), "device_index": dev.index,
+                "device_name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "device_uuid": str(getattr(props, "uuid", "")) or None, "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES"),
+                "rocr_visible_devices": os.environ.get("ROCR_VISIBLE_DEVICES"), "pid": os.getpid()}
+        ranks_info = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_info, mine)
     if args.trace and rank == 0:
         with open(args.trace, "w") as fh:
             json.dump(trace, fh)
@@ -519,6 +535,12 @@ def main():
             "roofline": roof,
             "decoder_roofline": decoder,
         }
+        if use_dist:
+            out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "launcher_world_size": world,
+                           "rccl_high_priority_stream": True, "buckets": buckets.describe(),
+                           "accumulate_in_place": bool(args.dp_accumulate_in_place), "ranks": ranks_info,
+                           "distinct_devices": len({(r["hostname"], r["pci_bus_id"] or r["device_uuid"] or r["device_index"])
+                                                    for r in ranks_info})}
         if world == 1:
             roof["throughput_bound_point"] = chamfer_throughput_probe(args.batch)
             out["input_stream"] = input_stream_probe(args.batch, args.image_size)

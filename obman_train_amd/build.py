@@ -43,21 +43,44 @@ def _run(cmd, verbose):
 
 
 def build_library(force=False, verbose=False):
+    """Compile + link under an exclusive file lock: the ranks of one ``torch.distributed.run`` launch that all find the
+    library stale take turns (the first one builds, the others find it fresh), and every output is written to a
+    process-private temporary and renamed into place, so nobody ever links or loads a half-written file."""
     if not force and not _stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    import fcntl
+
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():  # another process built it while this one waited
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = _headers()
+    tag = ".tmp.%d" % os.getpid()
     jobs, objs = [], []
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append((obj, [hipcc] + FLAGS + ["-c", src, "-o", obj + tag]))
+
+    def compile_one(job):
+        obj, cmd = job
+        _run(cmd, verbose)
+        os.replace(obj + tag, obj)
+
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as pool:
-        list(pool.map(lambda c: _run(c, verbose), jobs))
-    _run([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", LIB + ".tmp"] + objs, verbose)
-    os.replace(LIB + ".tmp", LIB)
+        list(pool.map(compile_one, jobs))
+    _run([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", LIB + tag] + objs, verbose)
+    os.replace(LIB + tag, LIB)
     return LIB
 
 

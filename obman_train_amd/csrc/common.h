@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #define OBMAN_ABI_VERSION 3
 #define OBMAN_WAVE 64
 
@@ -12,6 +14,14 @@
   } while (0)
 
 static inline int obman_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Per-device caches of one-time function attributes (hipFuncSetAttribute is per device): index by the calling thread's device.
+constexpr int MAX_DEVICES = 16;
+static inline int current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev >= 0 && dev < MAX_DEVICES ? dev : 0;
+}
 
 // Squared distance with a pinned evaluation order (no contraction differences between the
 // streaming pass and the index-resolution pass): fma(dz,dz, fma(dy,dy, dx*dx)).

@@ -1040,6 +1040,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // fixed order.  The one-wave-per-channel finalize kernels below then see <= 64 rows instead of striding through megabytes.
 constexpr int PRE_SEGMENTS = 64, PRE_MIN_ROWS = 512;
 constexpr int PRE_SEGMENTS_NARROW = 256;  // arrays of <= 1024 columns (per-channel partials): 3 column blocks x 64 segments = 192
+// segment count of pre_reduce for an array of `cols` columns: allocation (bwd_ws / fwd_ws) and launch share this rule
+constexpr int pre_segments(long cols) { return cols <= 1024 ? PRE_SEGMENTS_NARROW : PRE_SEGMENTS; }
                                          // blocks walked 125 rows each in 32 us at 8 032 row blocks; 768 blocks of 32 rows do it in a third
 template <class T>
 __global__ __launch_bounds__(256) void colsum_segments_kernel(const T* __restrict__ in, long rows, int cols, int rows_per_seg,
@@ -1620,7 +1622,7 @@ BwdWs bwd_ws(const Dims& d) {
     const L1Geo g = l1_geo(d);
     w.Pp = take((long)g.tiles * d.B * d.ld1); w.Qp = take((long)g.groups * d.N * d.ld1);
   }
-  w.Ppre = take(d.bf16 && l1_geo(d).tiles > PRE_MIN_ROWS ? (long)PRE_SEGMENTS * d.B * d.ld1 : 0);
+  w.Ppre = take(d.bf16 && l1_geo(d).tiles > PRE_MIN_ROWS ? (long)pre_segments((long)d.B * d.ld1) * d.B * d.ld1 : 0);  // same rule as pre_reduce
   {  // large-template layer-1 finalize: per-segment partials
     const long nseg = d.N > L1_SPLIT_N ? (d.N + L1_SEG_ROWS - 1) / L1_SEG_ROWS : 0;
     w.seg = take(nseg * 2 * d.C1 * 2);  // doubles
@@ -1681,11 +1683,13 @@ template <class AOp, class Epi, int WN>
 int launch_rows_bf16_wn(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo& geo, const Epi& e, hipStream_t st) {
   const int Kp = kpad(K);
   const size_t lds = (size_t)2 * (BM + 64 * WN) * LP * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
-  static int granted = 0;  // largest dynamic-LDS size already enabled for this instantiation
-  if ((int)lds > granted) {
+  // largest dynamic-LDS size already enabled for this instantiation, per device (a process may drive several GPUs)
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if ((int)lds > granted[dev].load(std::memory_order_relaxed)) {
     const hipError_t err = hipFuncSetAttribute((const void*)rows_bf16_kernel<AOp, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return (int)err;
-    granted = (int)lds;
+    granted[dev].store((int)lds, std::memory_order_relaxed);  // racing threads at worst repeat the (idempotent) call
   }
   const unsigned grid = (unsigned)geo.blocks() * (unsigned)((Nc + 64 * WN - 1) / (64 * WN));
   rows_bf16_kernel<AOp, Epi, WN><<<grid, NTB, lds, st>>>(a, Wb, Kp, Nc, e, geo);
@@ -1701,11 +1705,13 @@ template <class AOp, class BOp, int WN>
 int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
                       hipStream_t st, int transposed) {
   const size_t lds = (size_t)2 * (BM + 64 * WN) * LPT * sizeof(bfraw);
-  static const int once = [] {
-    return (int)hipFuncSetAttribute((const void*)tn_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * (BM + 64 * WN) * LPT * (int)sizeof(bfraw));
-  }();
-  if (once) return once;
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if (!granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)tn_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store(1, std::memory_order_relaxed);
+  }
   const int chunks = tn_bf16_chunks(M, Nc, N, Bsz, 64 * WN);
   const long ntiles = (long)((Bsz + 7) / 8) * ((N + 7) / 8);  // k-tiles of (8 samples) x (8 vertices)
   const int tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
@@ -1726,7 +1732,7 @@ int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int
 template <class T>
 int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) {
   if (rows <= PRE_MIN_ROWS) return 0;
-  const int want = cols <= 1024 ? PRE_SEGMENTS_NARROW : PRE_SEGMENTS;
+  const int want = pre_segments(cols);
   const int per = (rows + want - 1) / want, segs = (rows + per - 1) / per;
   colsum_segments_kernel<T><<<dim3(obman_cdiv(cols, 256), segs), 256, 0, st>>>(part, rows, cols, per, scratch);
   OBMAN_LAUNCH_CHECK();

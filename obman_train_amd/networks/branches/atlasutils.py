@@ -10,7 +10,8 @@ constructor arguments, parameter names (``conv1..4``, ``bn1..3``) and call signa
   multiply it by conv1; here layer 1 is split exactly into ``W1[:, :3].grid + W1[:, 3:].feature``
   (a [N,3] and a [B,C] product) and BatchNorm-1 batch statistics are obtained in closed form from
   the two small factors (mean and variance of a sum over the product set B x N add).
-  ``PointGenCon.forward(x)`` keeps the reference's generic [B,C,N] entry point.
+  ``PointGenCon.forward(x)`` keeps the reference's generic [B,C,N] entry point and routes the concatenation the
+  reference builds to the same fused decoder.
 """
 import torch
 from torch import nn
@@ -50,7 +51,25 @@ class PointGenCon(nn.Module):
         return self.out_factor * (torch.tanh(h) if self.use_tanh else h)
 
     def forward(self, x):
-        """Generic entry point of the reference: x [B,C,N] -> [B,3,N]."""
+        """Generic entry point of the reference: x [B,C,N] -> [B,3,N] (``atlasutils.py:65-75``).
+
+        The only tensor the reference ever passes here is the concatenation it builds in ``atlasbranch.py:117-132`` /
+        ``:92-101``: rows 0..2 = the sphere points, rows 3.. = the image feature repeated for every point.  On a ROCm tensor
+        that layout is recognised (one device-side comparison, one host read - this entry point is not on the training path,
+        ``AtlasBranch`` calls ``decode``) and routed to the fused HIP decoder with the points as a per-sample grid; the
+        result is transposed back to [B,3,N].  Any other input (features that vary along N) cannot be factorised and takes
+        the stock ops below - with a one-time warning, so leaving the fused path is never silent."""
+        if x.is_cuda and x.dim() == 3 and x.shape[1] == self.bottleneck_size and x.shape[2] > 0 and not self.use_tanh:
+            feat = x[:, 3:, :]
+            if bool((feat == feat[:, :, :1]).all()):
+                pts = self.decode(feat[:, :, 0].contiguous(), x[:, :3, :].transpose(1, 2).contiguous())
+                return pts.transpose(1, 2)
+            if not getattr(PointGenCon, "_warned_generic", False):
+                PointGenCon._warned_generic = True
+                import warnings
+
+                warnings.warn("PointGenCon.forward(x): x is not the [grid ; broadcast feature] concatenation of atlasbranch.py:117-132, "
+                              "running the generic stock-op path (use PointGenCon.decode(features, grid) for the fused HIP decoder)")
         return self._tail(torch_f.relu(self.bn1(self.conv1(x))))
 
     def decode(self, features, grid):

@@ -443,10 +443,14 @@ def bn_act(bn, x, skip=None, relu=True, count=True):
     training = bn.training or bn.running_mean is None
     if count and bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1  # callers with many layers pass count=False and bump all counters in one launch
-    if bn.momentum is None:
-        momentum = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
-    else:
+    if bn.momentum is not None:
         momentum = bn.momentum
+    elif bn.training and bn.running_mean is not None and bn.num_batches_tracked is not None:
+        # cumulative moving average: only evaluated where nn.BatchNorm2d.forward evaluates it (training with tracked statistics;
+        # it costs a device->host read of the counter), and a counter the caller has not bumped yet (count=False) reads as 1
+        momentum = 1.0 / max(float(bn.num_batches_tracked), 1.0)
+    else:
+        momentum = 0.0
     if not fused:  # stock ops, same bookkeeping as nn.BatchNorm2d.forward (counter bumped above, cumulative momentum)
         y = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, momentum, bn.eps)
         if skip is not None:
@@ -573,10 +577,14 @@ def bn_relu_maxpool(bn, x, pool, count=True):
     training = bn.training or bn.running_mean is None
     if count and bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
-    if bn.momentum is None:
-        momentum = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
-    else:
+    if bn.momentum is not None:
         momentum = bn.momentum
+    elif bn.training and bn.running_mean is not None and bn.num_batches_tracked is not None:
+        # cumulative moving average: only evaluated where nn.BatchNorm2d.forward evaluates it (training with tracked statistics;
+        # it costs a device->host read of the counter), and a counter the caller has not bumped yet (count=False) reads as 1
+        momentum = 1.0 / max(float(bn.num_batches_tracked), 1.0)
+    else:
+        momentum = 0.0
     return _BNReLUPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum)
 
 

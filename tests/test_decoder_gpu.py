@@ -91,22 +91,45 @@ def test_decoder_forward_backward_matches_oracle(c1, B, subdiv, training, patche
 
 
 def test_decoder_matches_reference_golden_pointgen(golden):
-    """The reference's own PointGenCon output (tests/golden/pointgen.npz) for an input that IS a grid x feature
-    product cannot be formed from an arbitrary x; instead check the generic forward(x) entry point of the mirror
-    (stock conv1d path) against the golden, and decode() against forward() on a product input."""
+    """`PointGenCon.forward(x)`, the reference's generic entry point (atlasutils.py:65-75).  (1) The golden input of
+    tests/golden/pointgen.npz is an arbitrary x (its feature rows vary along N, it cannot be factorised): the mirror runs the
+    stock-op path, says so once, and matches the reference's output.  (2) The tensor the reference actually passes - the
+    [grid ; broadcast feature] concatenation of atlasbranch.py:117-132 - is recognised and routed to the fused HIP decoder:
+    same result as decode(), as the stock ops on the same x, and the same gradient for the feature leaf."""
+    import torch.nn.functional as F
+
     from obman_train_amd.networks.branches.atlasutils import PointGenCon
 
     g = golden("pointgen")
     dec = load_seeded(PointGenCon(bottleneck_size=35, out_factor=200), int(g["seed"])).cuda().train()
-    y = dec(torch.from_numpy(g["x"]).cuda())
+    PointGenCon._warned_generic = False
+    with pytest.warns(UserWarning, match="generic stock-op path"):
+        y = dec(torch.from_numpy(g["x"]).cuda())
     np.testing.assert_allclose(y.detach().cpu().numpy(), g["y_train"], rtol=1e-4, atol=1e-3)
-    dec2 = load_seeded(PointGenCon(bottleneck_size=35, out_factor=200), int(g["seed"])).cuda().train()
+
+    mk = lambda: load_seeded(PointGenCon(bottleneck_size=35, out_factor=200), int(g["seed"])).cuda().train()  # noqa: E731
     grid = torch.from_numpy(icosphere(1)[0].astype(np.float32)).cuda()
     feats = torch.randn(3, 32, device="cuda")
-    x = torch.cat((grid.t().unsqueeze(0).expand(3, -1, -1), feats.unsqueeze(2).expand(-1, -1, 42)), 1)
-    dec3 = load_seeded(PointGenCon(bottleneck_size=35, out_factor=200), int(g["seed"])).cuda().train()
-    np.testing.assert_allclose(dec2.decode(feats, grid).detach().cpu().numpy(), dec3(x).transpose(2, 1).detach().cpu().numpy(),
-                               rtol=2e-4, atol=2e-2)
+    cot = torch.randn(3, 3, 42, device="cuda")
+    outs = {}
+    for how in ("forward", "decode", "stock"):
+        dec_k, f = mk(), feats.clone().requires_grad_()
+        x = torch.cat((grid.t().unsqueeze(0).expand(3, -1, -1), f.unsqueeze(2).expand(-1, -1, 42)), 1)
+        if how == "forward":
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.filterwarnings("error", message=".*generic stock-op path.*")  # the concatenation must NOT take the generic path
+                out = dec_k(x)
+        elif how == "decode":
+            out = dec_k.decode(f, grid).transpose(1, 2)
+        else:
+            out = dec_k._tail(F.relu(dec_k.bn1(dec_k.conv1(x))))
+        (out * cot).sum().backward()
+        outs[how] = (out.detach().cpu().numpy(), f.grad.cpu().numpy(), dec_k.conv2.weight.grad.cpu().numpy())
+    for other in ("decode", "stock"):
+        for a, b in zip(outs["forward"], outs[other]):
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * np.abs(b).max())
 
 
 def test_decoder_multi_patch_and_determinism():

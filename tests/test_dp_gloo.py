@@ -21,7 +21,8 @@ class _Net(nn.Module):
     def __init__(self):
         super().__init__()
         self.body = nn.Sequential(nn.Linear(12, 32), nn.ReLU(), nn.Linear(32, 16), nn.ReLU(), nn.Linear(16, 3))
-        self.unused = nn.Linear(5, 5)  # never used in forward: no gradient, like base_net.fc
+        self.unused = nn.Linear(5, 5)  # never used in forward: no gradient, like base_net.fc (passed in `exclude`)
+        self.dormant = nn.Linear(4, 4)  # in the buckets, but no rank ever produces a gradient: must end with grad = None
 
     def forward(self, x):
         return self.body(x)
@@ -53,7 +54,9 @@ def _worker(rank, world, port, out_dir):
     # bucket targets shrink once less than one full bucket remains: the last (exposed) bucket is the smallest
     probe = GradientBuckets(nn.ModuleList([nn.Linear(8, 8) for _ in range(23)]).parameters(), bucket_bytes=1024, tail_bytes=64)
     sizes = [flat.numel() * 4 for flat, _ in probe.buckets]  # 23 x (256 + 32) bytes, walked from the last layer
-    assert sizes == [1152] * 5 + [576, 288], sizes
+    assert sizes == [1152] * 5 + [576, 288 + 46 * 4], sizes  # + one "some rank had a gradient" flag per parameter in the last one
+    info = probe.describe()
+    assert info["world_size"] == 2 and info["backend"] == "gloo" and info["bucket_bytes"] == sizes and info["parameters"] == 46
     x, y = _data()
     shard = slice(rank * 4, rank * 4 + 4)
     for step in range(2):  # twice: bucket state must reset between steps
@@ -137,6 +140,39 @@ def test_rank_divergent_graphs_issue_identical_collectives(tmp_path):
     for k in want:
         torch.testing.assert_close(got0[k], want[k], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(got1[k], got0[k], rtol=0, atol=0)
+
+
+def _in_place_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from obman_train_amd.dp import GradientBuckets
+
+    net = _model()
+    buckets = GradientBuckets(net.parameters(), bucket_bytes=256, exclude=net.unused.parameters(), accumulate_in_place=True)
+    x, y = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    for step in range(2):
+        buckets.zero_grad()  # zero fills of the flat buffers; .grad stays the bucket view and autograd accumulates into it
+        ((net(x[shard]) - y[shard]) ** 2).mean().backward()
+        buckets.finish()
+    torch.save({k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()},
+               os.path.join(out_dir, "inplace_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_accumulate_in_place_mode_gives_the_same_average(tmp_path):
+    world, port = 2, _free_port()
+    mp.start_processes(_in_place_worker, args=(world, port, str(tmp_path)), nprocs=world, start_method="spawn")
+    net = _model()
+    x, y = _data()
+    ((net(x) - y) ** 2).mean().backward()
+    for rank in range(world):
+        got = torch.load(os.path.join(str(tmp_path), "inplace_%d.pt" % rank))
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                assert got[k] is None, k
+            else:
+                torch.testing.assert_close(got[k], p.grad, rtol=1e-5, atol=1e-6)
 
 
 def test_single_process_is_a_noop():

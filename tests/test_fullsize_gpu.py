@@ -30,7 +30,7 @@ def _rel_l2(g, w):
     return ((g.detach().cpu().double() - w.double()).norm() / w.double().norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("subdiv,flavour", [(3, "f32"), (3, "bf16"), (4, "f32")])
+@pytest.mark.parametrize("subdiv,flavour", [(3, "f32"), (3, "bf16"), (4, "f32"), (4, "bf16")])
 def test_decoder_full_size(subdiv, flavour):
     from obman_train_amd import ops
 
@@ -82,23 +82,30 @@ def _graze_free(origins, verts, faces, patches):
     return ok
 
 
-def _c3_scene(B, seed):
+def _c3_scene(B, seed, subdiv=3):
     """Hand vertices (mm) around a 25-patch object (blobs of ~40 mm spread over ~+-150 mm): some vertices inside patches."""
     from tests.test_contact_gpu import _blob
 
-    obj, faces = _blob(3, B, seed, radius=38.0, patches=25)
+    obj, faces = _blob(subdiv, B, seed, radius=38.0, patches=25)
     hand, _, _ = synth_hand_object(B, 600, seed + 1, hand_template()[0])
     hand = hand * 1.2
     return hand, obj, faces
 
 
-@pytest.mark.parametrize("cmode,kmode,zones,target", [("dist_tanh", "dist_tanh", "zones", "all"), ("dist_sq", "dist", "all", "obj")])
-def test_contact_loss_full_size(cmode, kmode, zones, target):
+# (subdivision, batch, scene seed): configs[2] (25 x 642 vertices, 32 000 faces) and configs[4] (25 x 2562 vertices, 128 000 faces: what
+# `bench.py --config c5` times).  Seeds are graze-free under the fp64 margin (checked on the CPU: tools/find_graze_free_seed.py).
+_CONTACT_SIZES = {3: (2, 12, 16050, 32000), 4: (1, 13, 64050, 128000)}
+
+
+@pytest.mark.parametrize("subdiv,cmode,kmode,zones,target", [(3, "dist_tanh", "dist_tanh", "zones", "all"), (3, "dist_sq", "dist", "all", "obj"),
+                                                             (4, "dist_tanh", "dist_tanh", "zones", "all")])
+def test_contact_loss_full_size(subdiv, cmode, kmode, zones, target):
     from obman_train_amd.networks.branches.contactloss import compute_contact_loss
 
-    B, patches = 2, 25
-    hand, obj, faces = _c3_scene(B, 12)  # graze-free under the fp64 margin (seed 11 has one grazing vertex)
-    assert obj.shape[1] == 16050 and faces.shape[0] == 32000
+    patches = 25
+    B, seed, n_obj, n_faces = _CONTACT_SIZES[subdiv]
+    hand, obj, faces = _c3_scene(B, seed, subdiv)
+    assert obj.shape[1] == n_obj and faces.shape[0] == n_faces
     kw = dict(contact_thresh=10, contact_mode=cmode, collision_thresh=20, collision_mode=kmode, contact_target=target,
               contact_zones=zones)
     h_o, o_o = hand.clone().requires_grad_(), obj.clone().requires_grad_()
@@ -188,6 +195,14 @@ def test_configs2_model_matches_oracle_at_full_size(inject):
     total, res, losses = model.forward(sample)
     total.backward()
     tol, gtol = (1e-4, 1e-3) if inject else (1e-3, 2e-2)
+    from tests.conftest import record_measurement
+
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)  # noqa: E731
+    record_measurement("configs2_model_vs_oracle[inject=%s]" % inject, {
+        "total": rel(total, o_total),
+        "worst_loss": max(rel(losses[k], v) for k, v in o_losses.items() if v is not None and abs(float(v)) > 1e-5),
+        "objpoints3d_of_scale": float((res["objpoints3d"].detach().cpu() - o_res["objpoints3d"].detach()).abs().max()
+                                      / o_res["objpoints3d"].detach().abs().max())})
     np.testing.assert_allclose(float(total), float(o_total), rtol=tol)
     for k, v in o_losses.items():
         if v is None:

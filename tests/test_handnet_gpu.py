@@ -9,6 +9,9 @@ from tests.handnet_common import assert_matches_fixture, build_fixture_model, fi
 
 pytestmark = pytest.mark.gpu
 
+# real-ResNet18 whole-model bounds against the CPU oracle (see test_handnet_resnet18_matches_cpu_oracle)
+TOL_TOTAL, TOL_LOSS, TOL_POINTS, TOL_GRAD = 1e-3, 2e-3, 1e-3, 2e-2
+
 
 @pytest.mark.parametrize("tag", ["train", "eval"])
 def test_handnet_matches_reference_golden(golden, monkeypatch, tag):
@@ -71,52 +74,96 @@ def test_handnet_resnet18_matches_cpu_oracle(contact, patches):
     model.cuda()
     total, res, losses = model.forward(sample)
     total.backward()
-    np.testing.assert_allclose(float(total), float(o_total), rtol=1e-3)
+    from tests.conftest import record_measurement
+
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)  # noqa: E731
+    measured = {"total": rel(total, o_total)}
+    measured["worst_loss"] = max(rel(losses[k], v) for k, v in o_losses.items() if v is not None and abs(float(v)) > 1e-5)
+    for k in ("verts", "objpoints3d"):
+        w = o_res[k].detach()
+        measured[k + "_of_scale"] = float((res[k].detach().cpu() - w).abs().max() / w.abs().max())
+    grads = {}
+    for name in ("mano_branch.pose_reg.weight", "atlas_branch.decoder.conv2.weight", "base_net.layer4.1.conv2.weight"):
+        got = dict(model.named_parameters())[name].grad.cpu().numpy()
+        want = named[name].grad.numpy()
+        grads[name] = float(np.abs(got - want).max() / np.abs(want).max())
+    measured["worst_grad_of_max"] = max(grads.values())
+    record_measurement("handnet_resnet18_vs_oracle[contact=%s,patches=%d]" % (contact, patches), measured)
+    # Bounds = ~2x the errors measured on MI355X (profiles/r03_parity_measured.md), not a guess: MIOpen's fp32 implicit-GEMM
+    # convolutions and oneDNN's differ in summation order, 18 layers deep (north_star's 1e-4 holds where the encoder is the
+    # same on both sides: tests/test_fullsize_gpu.py with injected features, the golden-vector tests above).
+    assert measured["total"] <= TOL_TOTAL, measured
     for k, v in o_losses.items():
         if v is None:
             assert losses[k] is None
         else:
-            np.testing.assert_allclose(float(losses[k]), float(v), rtol=2e-3, atol=1e-5, err_msg=k)
-    np.testing.assert_allclose(res["verts"].detach().cpu().numpy(), o_res["verts"].detach().numpy(), rtol=1e-3, atol=0.05)
-    np.testing.assert_allclose(res["objpoints3d"].detach().cpu().numpy(), o_res["objpoints3d"].detach().numpy(), rtol=1e-3, atol=0.05)
-    for name in ("mano_branch.pose_reg.weight", "atlas_branch.decoder.conv2.weight", "base_net.layer4.1.conv2.weight"):
-        got = dict(model.named_parameters())[name].grad.cpu().numpy()
-        want = named[name].grad.numpy()
-        err = np.abs(got - want).max()
-        assert err <= 2e-2 * np.abs(want).max(), (name, err, np.abs(want).max())
+            np.testing.assert_allclose(float(losses[k]), float(v), rtol=TOL_LOSS, atol=1e-5, err_msg=k)
+    assert measured["verts_of_scale"] <= TOL_POINTS and measured["objpoints3d_of_scale"] <= TOL_POINTS, measured
+    assert measured["worst_grad_of_max"] <= TOL_GRAD, (grads, measured)
 
 
-def test_bf16_flavour_trains_and_tracks_the_fp32_model():
-    """BASELINE configs[2] precision.  (1) Decoder contractions on the bf16 matrix pipe, everything else fp32, same weights
-    and batch: the smooth loss terms stay within 5 % of the fp32 model (decoder outputs move by ~0.5 % of their scale).
-    (2) Additionally the ResNet under bf16 autocast: at this tiny test size (bs 4, 64x64: BatchNorm statistics over 16
-    values in the last stage, MIOpen's bf16 kernels use atomics) the loss moves by several per cent from run to run, so only
-    sanity is asserted: finite losses over a few Adam steps, total within 30 % of the fp32 model."""
+# configs[2] in its stated precision: bounds = ~2x what MI355X produced (profiles/r03_parity_measured.md), frozen.
+FLAVOUR_BOUNDS = {
+    # flavour: (smooth loss terms rel., total rel., objpoints3d max |diff| / scale, repulsion-mask Hamming fraction, 5-step trajectory rel.)
+    "dec_bf16": dict(loss=2e-2, total=2e-2, points=1e-2, hamming=1e-2, track=2e-2),
+    "all_bf16": dict(loss=2e-2, total=2e-2, points=1e-2, hamming=1e-2, track=2e-2),
+}
+
+
+def test_configs2_precision_flavours_track_the_fp32_model_at_size():
+    """BASELINE configs[2] (25 x 642 points, trans + scale heads, shape, contact + penetration) at bs 16, 256 x 256, same weights
+    and batch, three flavours: `f32` (the oracle-pinned path), `dec_bf16` (decoder contractions on the bf16 matrix pipe) and
+    `all_bf16` (additionally the ResNet under bf16 autocast with the fused bf16 BatchNorm kernels) = the configuration's
+    stated precision, what `bench.py --config c3 --encoder-dtype bf16 --decoder-dtype bf16` times.  Every smooth loss term,
+    the total, the predicted object points, the penetration mask and five Adam steps are held to measured-then-frozen bounds."""
     from obman_train_amd.networks.handnet import HandNet
     from obman_train_amd.synthetic import CONFIGS, make_batch
     from obman_train_amd.trainer import make_optimizer, read_losses, train_step
+    from tests.conftest import record_measurement
 
+    import warnings
+    warnings.simplefilter("ignore")
     dev = torch.device("cuda", 0)
-    sample = make_batch(4, dev, seed=3, image_size=64)
+    B = 16
+    sample = make_batch(B, dev, seed=3, image_size=256)
     out = {}
     for flavour in ("f32", "dec_bf16", "all_bf16"):
         torch.manual_seed(0)
-        model = HandNet(**CONFIGS["c3p1"]).to(dev).train()
+        model = HandNet(**CONFIGS["c3"]).to(dev).train()
         if flavour != "f32":
             model.atlas_branch.decoder.mfma_dtype = "bf16"
         if flavour == "all_bf16":
             model.base_net.autocast_dtype = torch.bfloat16
         total, results, losses = model.forward(sample)
-        out[flavour] = (float(total), {k: float(v) for k, v in read_losses(losses).items() if v is not None})
-        if flavour == "all_bf16":
-            opt = make_optimizer(model)
-            vals = [float(train_step(model, opt, sample)[0]) for _ in range(4)]
-            assert all(np.isfinite(v) for v in vals), vals
-    t32, l32 = out["f32"]
-    t16, l16 = out["dec_bf16"]
-    assert abs(t16 - t32) <= 5e-2 * abs(t32), (t32, t16)
-    for k, v in l32.items():
-        # contact / penetration terms are means over thresholded vertex sets (masks may flip under bf16 noise): smooth terms only
-        if abs(v) > 1e-6 and k in l16 and k.startswith(("mano", "atlas", "final")):
-            assert abs(l16[k] - v) <= 5e-2 * abs(v) + 1e-3, (k, v, l16[k])
-    assert np.isfinite(out["all_bf16"][0]) and abs(out["all_bf16"][0] - t32) <= 0.3 * abs(t32), (t32, out["all_bf16"][0])
+        rec = dict(total=float(total), losses={k: v for k, v in read_losses(losses).items() if v is not None},
+                   points=results["objpoints3d"].detach().float().cpu(),
+                   rep=results["contact_info"]["repulsion_masks"].cpu())
+        opt = make_optimizer(model)
+        rec["track"] = [float(train_step(model, opt, sample)[0]) for _ in range(5)]
+        out[flavour] = rec
+        del model, opt, total, results, losses
+    ref = out["f32"]
+    assert ref["points"].shape == (B, 16050, 3)
+    scale = ref["points"].abs().max().item()
+    measured = {}
+    for flavour, bounds in FLAVOUR_BOUNDS.items():
+        got = out[flavour]
+        m = {"total": abs(got["total"] - ref["total"]) / abs(ref["total"]),
+             "points": (got["points"] - ref["points"]).abs().max().item() / scale,
+             "hamming": (got["rep"] != ref["rep"]).float().mean().item(),
+             "track": max(abs(a - b) / abs(b) for a, b in zip(got["track"], ref["track"]))}
+        terms = {}
+        for k, v in ref["losses"].items():
+            # penetration / attraction terms are means over thresholded vertex sets: covered by the mask distance and the total
+            if abs(v) > 1e-6 and k in got["losses"] and k.startswith(("mano", "atlas", "final")):
+                terms[k] = abs(got["losses"][k] - v) / abs(v)
+        m["loss"] = max(terms.values())
+        m["terms"] = terms
+        assert all(np.isfinite(t) for t in got["track"]), got["track"]
+        measured[flavour] = m
+    record_measurement("configs2_precision_flavours[bs16,256x256]", measured)
+    for flavour, bounds in FLAVOUR_BOUNDS.items():
+        for key, bound in bounds.items():
+            assert measured[flavour][key] <= bound, (flavour, key, measured[flavour])
+
+
