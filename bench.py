@@ -455,7 +455,8 @@ def main():
     dt = time.perf_counter() - t0
     step_gpu_ms = sorted(close_phase("timed", evs, host))
     loss_val = float(total)
-    pm_ms, pm_n = _lib.prof_summary(1)
+    pm_ms, pm_n = _lib.prof_summary(10)  # ChamferLoss forward launches only (csrc/prof.h; 1 = the hand<->object closest-vertex launches)
+    pmb_ms, pmb_n = _lib.prof_summary(11)
     dec_f_ms, dec_f_n = _lib.prof_summary(8)
     dec_b_ms, dec_b_n = _lib.prof_summary(9)
     _lib.prof_enable(False)
@@ -489,12 +490,17 @@ def main():
         # algorithmic bytes below are those of the whole call, so the durations of a call's launches are summed
         avg_s = (pm_ms / max(args.steps, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if pm_n else None
+        single = n_pred <= 1024 and n_gt <= 1024  # csrc/pairmin.hip S5 path: minima of both directions AND the per-sample means in one launch
         roof = {
-            "kernel": "pairmin_fwd_kernel (Chamfer fwd, both directions, %d samples/launch)" % args.batch,
+            "kernel": ("pairmin_s5_kernel (whole ChamferLoss.forward: both directions + per-sample means, %d samples, ONE launch)"
+                       if single else "pairmin_fwd_kernel (ChamferLoss forward: one launch per direction, %d samples; durations of a call's "
+                                      "launches are summed against the bytes of one call)") % args.batch,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
             "avg_launch_us": avg_s * 1e6, "launches": pm_n, "launches_per_call": pm_n / max(args.steps, 1),
             "alg_bytes_per_launch": alg_bytes,
+            "backward": {"kernel": "pairmin_bwd_kernel (Chamfer backward, both sides)", "avg_launch_us": (pmb_ms / pmb_n * 1e3) if pmb_n else None,
+                         "launches": pmb_n, "alg_bytes_per_launch": 32.0 * (n_pred + n_gt) * args.batch},
             "valu": {"achieved_tflops": alg_flop / avg_s / 1e12 if pm_n else None, "peak_tflops": VALU_PEAK_TFLOPS,
                      "frac": (alg_flop / avg_s / 1e12 / VALU_PEAK_TFLOPS) if pm_n else None,
                      "note": "binding bound: intensity N*M/(2(N+M)) = %.0f flop/B >> 20 flop/B ridge"
@@ -514,9 +520,15 @@ def main():
                        "note": "whole obman_pointgen_fwd/bwd call (all its kernels); peak = dense MFMA rate of the operand "
                                "dtype (157.3 TF fp32-in, 2500 TF bf16)"}
         traffic_file = os.path.join(REPO, "profiles", "chamfer_traffic.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file):  # PMC cannot run inside this process: the committed per-launch figure of a labelled PMC run
             with open(traffic_file) as fh:
-                roof["traffic"] = json.load(fh).get(args.config)
+                tr = json.load(fh)
+            entry = tr.get(args.config)
+            if isinstance(entry, dict):
+                roof["traffic"] = entry.get("bytes_per_launch")
+                roof["traffic_source"] = {k: v for k, v in entry.items() if k != "bytes_per_launch"}
+            else:
+                roof["traffic"] = entry
         out = {
             "metric": "train images/sec (fwd+bwd+Adam, bs=%d/GPU)" % args.batch,
             "value": args.batch * world * args.steps / dt, "unit": "images/sec", "n_gpus": world,

@@ -52,7 +52,16 @@ int obman_pairmin_bwd(const float* x, const float* y, int B, int Nx, int Ny,
  * are saved for the backward. */
 int obman_chamfer_fwd(const float* preds, const float* gts, int B, int Np, int Ng,
                       float* loss_1, float* loss_2, float* min_pred, int* idx_pred,
-                      float* min_gt, int* idx_gt, void* ws, long ws_bytes, obman_stream_t stream);
+                      float* min_gt, int* idx_gt, void* ws, long ws_bytes,
+                      void* sync, long sync_bytes, obman_stream_t stream);
+
+/* Optional single-launch mode of obman_chamfer_fwd for point sets that fit LDS (both <= 1024 points, e.g. 642 x 600): with
+ * `sync` >= this many bytes the per-sample means are produced inside the pair-min launch by the last block of each sample to
+ * finish (`sync` = 4096 arrival counters, then the published partial sums; B <= 4096).  CONTRACT: the caller zero-initialises `sync` ONCE
+ * (hipMemset at allocation); every call leaves it zero again, so one buffer per stream serves all later calls.  It must not be
+ * shared by calls that can run concurrently (different streams).  Returns 0 when the sizes take the general path (then `sync`
+ * is ignored and may be NULL); sync == NULL is always valid (the means then cost a second, tiny launch). */
+long obman_chamfer_sync_bytes(int B, int Np, int Ng);
 
 /* Backward of obman_chamfer_fwd: g_loss_1 [B], g_loss_2 [B] -> grad_preds [B,Np,3], grad_gts
  * [B,Ng,3] (either may be NULL). */

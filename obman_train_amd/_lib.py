@@ -9,7 +9,7 @@ import os
 from .build import LIB
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); 'p' pointer, 'i' int, 'l' long, 'f' float
 _SIGNATURES = {
@@ -17,7 +17,8 @@ _SIGNATURES = {
     "obman_pairmin_ws_bytes": (_c_long, "iii"),
     "obman_pairmin_fwd": (_c_int, "ppiiipppp" "plp"),
     "obman_pairmin_bwd": (_c_int, "ppiiipppppp" "p"),
-    "obman_chamfer_fwd": (_c_int, "ppiiipppppp" "plp"),
+    "obman_chamfer_fwd": (_c_int, "ppiiipppppp" "plplp"),
+    "obman_chamfer_sync_bytes": (_c_long, "iii"),
     "obman_chamfer_bwd": (_c_int, "ppiiipppppp" "p"),
     "obman_mesh_contains_fwd": (_c_int, "ppp" "iiii" "pp"),
     "obman_mesh_contains_groups_fwd": (_c_int, "ppp" "iiii" "i" "pp"),

@@ -208,6 +208,258 @@ __global__ __launch_bounds__(256) void rowmean2_kernel(const float* a, int na, f
   if (tid == 0) dst[b] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
 }
 
+
+// ---- K1 small-set path ("S5"): every reference of a sample fits LDS and the batch alone fills the chip --------------------
+// 642 x 600 x 64 samples (BASELINE configs[1]) spent 16 % of its lanes on tile padding (6 + 5 tiles of 128 query slots for
+// 642 + 600 queries), three dependent global round trips (query loads, a staging loop that waited per iteration, the query
+// re-load of the resolve pass) and two more launches for the per-sample means.  This path:
+//   * block = 512 threads = 8 waves over the SAME 320 queries (5 per lane in VGPRs), each wave sweeping an eighth of the staged
+//     references: 642 = 2 x 320 + 2 and 600 = 2 x 300, so a sample is 4 equal blocks = exactly one per CU at bs 64;
+//   * a remainder of <= S5_LEFT_MAX queries (the 2 of 642) is not padded to another tile: one short extra block per direction
+//     evaluates it TRANSPOSED (lanes over references, u64 (distance bits, index) min across the block);
+//   * arg-min bookkeeping per 16-reference chunk instead of per 4-reference group: inside a chunk only the running minimum is
+//     kept (two v_min3_f32 per 4 pairs), one compare + two selects per chunk and query; the exact index is recovered by
+//     re-evaluating the winning chunk with the same pinned instruction sequence (bit-identical, first index wins);
+//   * all staging loads are issued before the first wait, the resolve pass takes its query from registers;
+//   * the per-sample means (ChamferLoss: loss_1[b], loss_2[b]) are produced by the LAST block of the sample to finish: every
+//     block publishes the fixed-order sum of its minima with a system-scope (write-through) store, waits for the write
+//     acknowledgement, then draws a ticket from a per-sample counter with a relaxed agent-scope atomic; the block that draws
+//     the last ticket reads the partial sums back with system-scope loads and adds them in member order (deterministic for any
+//     dispatch order or XCD placement; no fence, no second launch).  It also resets the counter, so the caller's
+//     zero-initialised `sync` buffer stays zero between calls.
+constexpr int S5_THREADS = 512, S5_WAVES = 8, S5_QPT = 5, S5_TILE = 64 * S5_QPT, S5_CHUNK_GROUPS = 4;
+constexpr int S5_LEFT_MAX = 8, S5_MAX_REFS = 1024;
+
+struct S5Dir {
+  const float* q;  // queries [B,nq,3]
+  const float* r;  // references [B,nr,3]
+  float* omin;     // [B,nq] (null: direction skipped, no members)
+  int* oidx;       // [B,nq] or null
+  int nq, nr, tiles, left, slice;  // main tiles of 320 queries, leftover queries (transposed role), references per wave (multiple of 4)
+};
+struct S5Args {
+  S5Dir d[2];
+  int B, members, m0;   // blocks per sample; members of direction 0 (tiles + leftover block)
+  float* part;          // [B, members] published partial sums (null: no fused means)
+  unsigned* ticket;     // [B] arrival counters, zero on entry, zero on return
+  float* loss[2];       // [B] per direction
+};
+
+__device__ __forceinline__ float s5_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
+__global__ __launch_bounds__(S5_THREADS) void pairmin_s5_kernel(S5Args a) {
+  // XCD-aware order: the blocks of one sample take consecutive slots of ONE XCD (they read the same two point sets)
+  const int id = blockIdx.x, slot = id >> 3, member = slot % a.members;
+  const int b = (slot / a.members) * 8 + (id & 7);
+  if (b >= a.B) return;
+  const int dir = member >= a.m0 ? 1 : 0;
+  const S5Dir d = a.d[dir];
+  const int mem = member - (dir ? a.m0 : 0);
+  const bool leftover = mem >= d.tiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* __restrict__ qb = d.q + (size_t)b * d.nq * 3;
+  const float* __restrict__ rb = d.r + (size_t)b * d.nr * 3;
+  const int nmain = d.nq - d.left;  // queries covered by the main tiles
+
+  extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+  float4* sref = reinterpret_cast<float4*>(pm_smem);
+  const int padded = d.slice * S5_WAVES;
+  float(*s_val)[S5_TILE] = reinterpret_cast<float(*)[S5_TILE]>(pm_smem + (size_t)S5_MAX_REFS * sizeof(float4));
+  int(*s_grp)[S5_TILE] = reinterpret_cast<int(*)[S5_TILE]>(pm_smem + (size_t)S5_MAX_REFS * sizeof(float4) + sizeof(float) * S5_WAVES * S5_TILE);
+  u64* s_key = reinterpret_cast<u64*>(s_val);  // leftover role: one packed (distance, index) key per leftover query
+  __shared__ float s_sum[S5_WAVES];
+
+  // queries first (main role), then every staging load, one wait for all of them
+  float qx[S5_QPT], qy[S5_QPT], qz[S5_QPT];
+  if (!leftover) {
+#pragma unroll
+    for (int k = 0; k < S5_QPT; ++k) {
+      const int qi = mem * S5_TILE + k * 64 + lane;
+      const int qc = qi < nmain ? qi : nmain - 1;  // idle lanes redo the last point, never stored
+      qx[k] = qb[(size_t)qc * 3 + 0];
+      qy[k] = qb[(size_t)qc * 3 + 1];
+      qz[k] = qb[(size_t)qc * 3 + 2];
+    }
+  }
+  {
+    constexpr int PER = S5_MAX_REFS / S5_THREADS;  // 2 references per thread
+    float rx[PER], ry[PER], rz[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * S5_THREADS;
+      const int ic = i < d.nr ? i : d.nr - 1;
+      rx[u] = rb[(size_t)ic * 3 + 0];
+      ry[u] = rb[(size_t)ic * 3 + 1];
+      rz[u] = rb[(size_t)ic * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * S5_THREADS;
+      if (i < padded) sref[i] = i < d.nr ? make_float4(rx[u], ry[u], rz[u], 0.f) : make_float4(PM_BIG, PM_BIG, PM_BIG, 0.f);
+    }
+  }
+  if (leftover && tid < S5_LEFT_MAX) s_key[tid] = ~0ull;
+  __syncthreads();
+
+  float block_sum = 0.f;  // valid in thread 0 after the role's epilogue
+  if (!leftover) {
+    float best[S5_QPT], cm[S5_QPT];
+    int bestc[S5_QPT];
+#pragma unroll
+    for (int k = 0; k < S5_QPT; ++k) { best[k] = __builtin_inff(); bestc[k] = 0x7fffffff; }
+    const int jbeg = wave * d.slice, groups = d.slice >> 2;
+    // queries 0..3 as two packed pairs (v_pk_add / v_pk_mul / v_pk_fma: 1.8x the time of the scalar op for 2x the work,
+    // tools/ubench/valu_rate.hip), query 4 scalar; element-wise the same rounding as obman_dist2
+    const f2 px0 = {qx[0], qx[1]}, py0 = {qy[0], qy[1]}, pz0 = {qz[0], qz[1]};
+    const f2 px1 = {qx[2], qx[3]}, py1 = {qy[2], qy[3]}, pz1 = {qz[2], qz[3]};
+    auto sweep4 = [&](const float4 (&r)[4]) {  // four references against the lane's five queries: running chunk minima only
+      // the .w lanes are "used" HERE, at consumption: keeps the reads ds_read_b128 (b96 is 2x the LDS cycles) without forcing a
+      // wait right behind the prefetch
+      asm volatile("" ::"v"(r[0].w), "v"(r[1].w), "v"(r[2].w), "v"(r[3].w));
+      const f2 a0 = pm_dist2_pk(px0, py0, pz0, r[0].x, r[0].y, r[0].z), a1 = pm_dist2_pk(px0, py0, pz0, r[1].x, r[1].y, r[1].z);
+      const f2 a2 = pm_dist2_pk(px0, py0, pz0, r[2].x, r[2].y, r[2].z), a3 = pm_dist2_pk(px0, py0, pz0, r[3].x, r[3].y, r[3].z);
+      cm[0] = s5_min3(s5_min3(cm[0], a0[0], a1[0]), a2[0], a3[0]);
+      cm[1] = s5_min3(s5_min3(cm[1], a0[1], a1[1]), a2[1], a3[1]);
+      const f2 b0 = pm_dist2_pk(px1, py1, pz1, r[0].x, r[0].y, r[0].z), b1 = pm_dist2_pk(px1, py1, pz1, r[1].x, r[1].y, r[1].z);
+      const f2 b2 = pm_dist2_pk(px1, py1, pz1, r[2].x, r[2].y, r[2].z), b3 = pm_dist2_pk(px1, py1, pz1, r[3].x, r[3].y, r[3].z);
+      cm[2] = s5_min3(s5_min3(cm[2], b0[0], b1[0]), b2[0], b3[0]);
+      cm[3] = s5_min3(s5_min3(cm[3], b0[1], b1[1]), b2[1], b3[1]);
+      const float e0 = obman_dist2(qx[4], qy[4], qz[4], r[0].x, r[0].y, r[0].z), e1 = obman_dist2(qx[4], qy[4], qz[4], r[1].x, r[1].y, r[1].z);
+      const float e2 = obman_dist2(qx[4], qy[4], qz[4], r[2].x, r[2].y, r[2].z), e3 = obman_dist2(qx[4], qy[4], qz[4], r[3].x, r[3].y, r[3].z);
+      cm[4] = s5_min3(s5_min3(cm[4], e0, e1), e2, e3);
+    };
+    auto fetch4 = [&](float4 (&r)[4], int j) {
+      r[0] = sref[j]; r[1] = sref[j + 1]; r[2] = sref[j + 2]; r[3] = sref[j + 3];
+    };
+    auto close_chunk = [&](int first) {
+#pragma unroll
+      for (int k = 0; k < S5_QPT; ++k) {
+        const bool better = cm[k] < best[k];
+        best[k] = better ? cm[k] : best[k];
+        bestc[k] = better ? first : bestc[k];
+      }
+    };
+    // the next group's references are requested before the current group is evaluated (two register sets): the wave never sits
+    // on an LDS round trip with nothing to issue.  The last prefetch of a slice re-reads its final group (never evaluated).
+    const int jlast = jbeg + (groups - 1) * 4;
+    float4 ra[4], rb4[4];
+    fetch4(ra, jbeg);
+    int g = 0;
+    for (; g + S5_CHUNK_GROUPS <= groups; g += S5_CHUNK_GROUPS) {  // full chunks of 16 references
+#pragma unroll
+      for (int k = 0; k < S5_QPT; ++k) cm[k] = __builtin_inff();
+      const int j = jbeg + g * 4;
+      fetch4(rb4, j + 4);
+      sweep4(ra);
+      fetch4(ra, j + 8);
+      sweep4(rb4);
+      fetch4(rb4, j + 12);
+      sweep4(ra);
+      fetch4(ra, min(j + 16, jlast));
+      sweep4(rb4);
+      close_chunk(j);
+    }
+    for (; g < groups; ++g) {  // remaining groups of the slice: chunks of 4 references
+#pragma unroll
+      for (int k = 0; k < S5_QPT; ++k) cm[k] = __builtin_inff();
+      const int j = jbeg + g * 4;
+      sweep4(ra);
+      fetch4(ra, min(j + 4, jlast));
+      close_chunk(j);
+    }
+#pragma unroll
+    for (int k = 0; k < S5_QPT; ++k) {
+      s_val[wave][k * 64 + lane] = best[k];
+      s_grp[wave][k * 64 + lane] = bestc[k];
+    }
+    __syncthreads();
+    float mine = 0.f;
+    if (wave < S5_QPT) {  // thread (wave k, lane l) resolves query k*64 + l: the lane's own k-th query, already in registers
+      const int t = wave * 64 + lane, qi = mem * S5_TILE + t;
+      float x = qx[0], y = qy[0], z = qz[0];
+#pragma unroll
+      for (int k = 1; k < S5_QPT; ++k)
+        if (wave == k) { x = qx[k]; y = qy[k]; z = qz[k]; }
+      float bv = s_val[0][t];
+      int bc = s_grp[0][t];
+#pragma unroll
+      for (int w = 1; w < S5_WAVES; ++w) {
+        const float v = s_val[w][t];
+        const int c = s_grp[w][t];
+        if (v < bv || (v == bv && c < bc)) { bv = v; bc = c; }
+      }
+      if (bc == 0x7fffffff) bc = 0;  // NaN inputs: nothing ever compared smaller
+      // exact index inside the winning chunk (<= 16 references of one wave's slice), re-evaluated with the same sequence;
+      // a later chunk cannot hold an equal value at a lower index, so the first match from the chunk start is the arg-min
+      const int cend = min(min(bc + 4 * S5_CHUNK_GROUPS, (bc / d.slice + 1) * d.slice), d.nr);
+      int idx = bc;
+      for (int j = cend - 1; j >= bc; --j) {  // descending so the FIRST matching index survives
+        const float4 r = sref[j];
+        if (obman_dist2(x, y, z, r.x, r.y, r.z) == bv) idx = j;
+      }
+      if (qi < nmain) {
+        const size_t o = (size_t)b * d.nq + qi;
+        d.omin[o] = bv;
+        if (d.oidx) d.oidx[o] = idx;
+        mine = bv;
+      }
+    }
+    if (a.part) {  // fixed-order block sum of the tile's minima: wave sums by DPP, then waves 0..4 in order
+      const float ws = obman_wave_sum(mine);
+      if (lane == 0) s_sum[wave] = ws;
+      __syncthreads();
+      if (tid == 0) block_sum = (((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) + s_sum[4]);
+    }
+  } else {
+    // transposed role: each leftover query against all references, lanes over references
+    for (int lq = 0; lq < d.left; ++lq) {
+      const int qi = nmain + lq;
+      const float x = qb[(size_t)qi * 3], y = qb[(size_t)qi * 3 + 1], z = qb[(size_t)qi * 3 + 2];
+      u64 key = ~0ull;
+      for (int j = tid; j < d.nr; j += S5_THREADS) {
+        const float4 r = sref[j];
+        const float e = obman_dist2(x, y, z, r.x, r.y, r.z);
+        // e >= +0: its bit pattern orders like the value; NaN (0x7fc...) sorts above every finite distance and +inf
+        const u64 k2 = ((u64)__float_as_uint(e) << 32) | (unsigned)j;
+        key = k2 < key ? k2 : key;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_xor(key, off, 64);
+        key = o < key ? o : key;
+      }
+      if (lane == 0) atomicMin(&s_key[lq], key);  // LDS ds_min_u64: order independent
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int lq = 0; lq < d.left; ++lq) {
+        const u64 key = s_key[lq];
+        const float bv = __uint_as_float((unsigned)(key >> 32));
+        const size_t o = (size_t)b * d.nq + nmain + lq;
+        d.omin[o] = bv;
+        if (d.oidx) d.oidx[o] = (int)(unsigned)(key & 0xffffffffu);
+        block_sum += bv;
+      }
+    }
+  }
+
+  if (a.part == nullptr || tid != 0) return;
+  // publish, draw a ticket, and - for the last arriver of this sample - add the partial sums in member order
+  float* mine_slot = a.part + (size_t)b * a.members + member;
+  __hip_atomic_store(mine_slot, block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through store is acknowledged before the ticket is drawn
+  const unsigned old = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old != (unsigned)a.members - 1u) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int m = 0; m < a.members; ++m) {
+    const float v = m == member ? block_sum : __hip_atomic_load(a.part + (size_t)b * a.members + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (m < a.m0) s0 += v; else s1 += v;
+  }
+  if (a.loss[0] && a.d[0].omin) a.loss[0][b] = s0 / (float)a.d[0].nq;
+  if (a.loss[1] && a.d[1].omin) a.loss[1][b] = s1 / (float)a.d[1].nq;
+  __hip_atomic_store(a.ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-cleaning for the next call
+}
+
 struct PmBwdSide {
   const float* p;        // own points   [B,n,3]
   const float* o;        // other points [B,m,3]
@@ -221,39 +473,72 @@ struct PmBwdSide {
 
 constexpr int PB_TILE = 1024;
 
-// Block = 4 waves over the same 64 own points; each wave scans a quarter of the other side's arg-mins
-// (owner scan, ascending), partial sums are added in fixed wave order => deterministic.
+// Block = 4 waves over the same 64 own points.  Scatter side as an OWNER SCAN without float atomics: the other side's points
+// whose arg-min falls into this block's 64 own points are first compacted, in ascending index order, into LDS (ballot +
+// prefix counts: ~m*64/n entries instead of m - 60 of 600 at 642 x 600), then each wave scans a quarter of that short list
+// and the four partial sums are added in fixed wave order => deterministic.  (The r01/r02 kernel scanned all m arg-mins
+// per own point: 10 instructions x 150 iterations per wave, as much VALU work as the forward sweep.)
 __global__ __launch_bounds__(256) void pairmin_bwd_kernel(PmBwdSide s0, PmBwdSide s1) {
   const PmBwdSide s = blockIdx.z == 0 ? s0 : s1;
   if (s.grad == nullptr) return;
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (blockIdx.x * 64 >= s.n) return;
-  const int i = blockIdx.x * 64 + lane;
+  const int i0 = blockIdx.x * 64, i = i0 + lane;
   const float* __restrict__ pb = s.p + (size_t)b * s.n * 3;
   const float* __restrict__ ob = s.o + (size_t)b * s.m * 3;
   const int ic = i < s.n ? i : s.n - 1;
   const float px = pb[(size_t)ic * 3], py = pb[(size_t)ic * 3 + 1], pz = pb[(size_t)ic * 3 + 2];
+  // own term: issue its loads now, they are consumed at the very end
+  float own_w = 0.f, ox = px, oy = py, oz = pz;
+  if (s.g_own && wave == 0 && i < s.n) {
+    own_w = 2.f * (s.per_sample ? s.g_own[b] / (float)s.n : s.g_own[(size_t)b * s.n + i]);
+    const int j = s.idx_own[(size_t)b * s.n + i];
+    ox = ob[(size_t)j * 3];
+    oy = ob[(size_t)j * 3 + 1];
+    oz = ob[(size_t)j * 3 + 2];
+  }
   float gx = 0.f, gy = 0.f, gz = 0.f;
   __shared__ float4 so[PB_TILE];
   __shared__ int sidx[PB_TILE];
+  __shared__ int s_cnt[(PB_TILE / 256) * 4 + 1];
   __shared__ float s_acc[3][3][64];
   if (s.g_other) {
+    constexpr int ROUNDS = PB_TILE / 256;
     const float gs = s.per_sample ? 2.f * s.g_other[b] / (float)s.m : 0.f;
+    const int* __restrict__ idx_o = s.idx_other + (size_t)b * s.m;
     for (int base = 0; base < s.m; base += PB_TILE) {
       const int cnt = min(PB_TILE, s.m - base);
-      for (int t = tid; t < cnt; t += 256) {
-        const int j = base + t;
-        const float w = s.per_sample ? gs : 2.f * s.g_other[(size_t)b * s.m + j];
-        so[t] = make_float4(ob[(size_t)j * 3], ob[(size_t)j * 3 + 1], ob[(size_t)j * 3 + 2], w);
-        sidx[t] = s.idx_other[(size_t)b * s.m + j];
+      int rel[ROUNDS], rank[ROUNDS];
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {  // coalesced sweep over the arg-mins, round-major = ascending index
+        const int t = r * 256 + tid;
+        rel[r] = t < cnt ? idx_o[base + t] - i0 : -1;
+        const bool hit = (unsigned)rel[r] < 64u;
+        const u64 bal = __ballot(hit);
+        rank[r] = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (lane == 0) s_cnt[r * 4 + wave] = __popcll(bal);
       }
       __syncthreads();
-      const int slice = (cnt + 3) >> 2;
-      const int tend = min(cnt, (wave + 1) * slice);
-#pragma unroll 4
+      int total = 0;
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if (w == wave && (unsigned)rel[r] < 64u) {
+            const int j = base + r * 256 + tid, pos = total + rank[r];
+            const float wgt = s.per_sample ? gs : 2.f * s.g_other[(size_t)b * s.m + j];
+            so[pos] = make_float4(ob[(size_t)j * 3], ob[(size_t)j * 3 + 1], ob[(size_t)j * 3 + 2], wgt);
+            sidx[pos] = rel[r];
+          }
+          total += s_cnt[r * 4 + w];
+        }
+      }
+      __syncthreads();
+      const int slice = (total + 3) >> 2;
+      const int tend = min(total, (wave + 1) * slice);
       for (int t = wave * slice; t < tend; ++t) {
         const float4 v = so[t];
-        const float w = sidx[t] == i ? v.w : 0.f;
+        const float w = sidx[t] == lane ? v.w : 0.f;
         gx = __fmaf_rn(w, px - v.x, gx);
         gy = __fmaf_rn(w, py - v.y, gy);
         gz = __fmaf_rn(w, pz - v.z, gz);
@@ -270,12 +555,9 @@ __global__ __launch_bounds__(256) void pairmin_bwd_kernel(PmBwdSide s0, PmBwdSid
   }
   if (wave != 0 || i >= s.n) return;
   if (s.g_own) {
-    const float w = s.per_sample ? s.g_own[b] / (float)s.n : s.g_own[(size_t)b * s.n + i];
-    const int j = s.idx_own[(size_t)b * s.n + i];
-    const float w2 = 2.f * w;
-    gx = __fmaf_rn(w2, px - ob[(size_t)j * 3], gx);
-    gy = __fmaf_rn(w2, py - ob[(size_t)j * 3 + 1], gy);
-    gz = __fmaf_rn(w2, pz - ob[(size_t)j * 3 + 2], gz);
+    gx = __fmaf_rn(own_w, px - ox, gx);
+    gy = __fmaf_rn(own_w, py - oy, gy);
+    gz = __fmaf_rn(own_w, pz - oz, gz);
   }
   float* g = s.grad + ((size_t)b * s.n + i) * 3;
   g[0] = gx;
@@ -302,8 +584,8 @@ void launch_fwd_t(dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const 
   const unsigned blocks = (unsigned)(((pg.B + 7) / 8) * 8) * grid.x * grid.z;  // samples padded to a multiple of 8 (one group per XCD slot)
   pairmin_fwd_kernel<QPT><<<dim3(blocks), PM_THREADS, smem, st>>>(a, b, pg);
 }
-void launch_fwd(int qpt, dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b) {
-  ObmanProfScope prof(OBMAN_K_PAIRMIN_FWD, st);
+void launch_fwd(int qpt, dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b, int kid) {
+  ObmanProfScope prof(kid, st);
   switch (qpt) {
     case 10: launch_fwd_t<10>(grid, smem, st, a, b); break;
     case 4: launch_fwd_t<4>(grid, smem, st, a, b); break;
@@ -328,11 +610,84 @@ void plan_dir(PmDir& d, int B, int qpt, bool have_ws) {
   }
 }
 
+// ---- S5 planning (shared by the launcher and obman_chamfer_sync_bytes)
+struct S5Plan { S5Dir d0, d1; int members, m0; bool ok; };
+void s5_plan_dir(S5Dir& d) {
+  const int rem = d.nq % S5_TILE;
+  d.left = (d.nq > S5_TILE && rem > 0 && rem <= S5_LEFT_MAX) ? rem : 0;
+  d.tiles = d.left ? d.nq / S5_TILE : obman_cdiv(d.nq, S5_TILE);
+  d.slice = ((obman_cdiv(d.nr, S5_WAVES) + 3) / 4) * 4;
+}
+S5Plan s5_plan(const float* x, const float* y, int Nx, int Ny, float* min_x, int* idx_x, float* min_y, int* idx_y) {
+  static const int enabled = [] { const char* e = getenv("OBMAN_PM_S5"); return e ? atoi(e) : 1; }();  // A/B knob
+  S5Plan p{};
+  p.d0 = S5Dir{x, y, min_x, idx_x, Nx, Ny, 0, 0, 0};
+  p.d1 = S5Dir{y, x, min_y, idx_y, Ny, Nx, 0, 0, 0};
+  p.ok = enabled && (min_x || min_y) && (!min_x || Ny <= S5_MAX_REFS) && (!min_y || Nx <= S5_MAX_REFS);
+  if (!p.ok) return p;
+  s5_plan_dir(p.d0);
+  s5_plan_dir(p.d1);
+  p.m0 = min_x ? p.d0.tiles + (p.d0.left ? 1 : 0) : 0;
+  p.members = p.m0 + (min_y ? p.d1.tiles + (p.d1.left ? 1 : 0) : 0);
+  return p;
+}
+constexpr size_t S5_LDS = (size_t)S5_MAX_REFS * sizeof(float4) + (size_t)2 * S5_WAVES * S5_TILE * sizeof(float);
+// `sync` layout: [S5_MAX_TICKETS arrival counters][B x members partial sums].  The counter region has a FIXED size so that calls
+// with different batch sizes sharing one buffer never see another call's (non-zero) partial sums where they expect zero counters.
+constexpr int S5_MAX_TICKETS = 4096;
+long s5_sync_bytes(int B, int members) {
+  return B <= S5_MAX_TICKETS ? (long)sizeof(unsigned) * S5_MAX_TICKETS + (long)sizeof(float) * B * members : 0;
+}
+
+// One launch: minima + arg-mins of both directions and (with `sync` and loss pointers) the per-sample means.
+int launch_s5(const S5Plan& p, int B, float* loss_1, float* loss_2, void* sync, long sync_bytes, hipStream_t st, bool* fused, int kid) {
+  S5Args a{};
+  a.d[0] = p.d0;
+  a.d[1] = p.d1;
+  a.B = B;
+  a.members = p.members;
+  a.m0 = p.m0;
+  const bool want_mean = loss_1 || loss_2;
+  const long need = s5_sync_bytes(B, p.members);
+  *fused = want_mean && sync && need > 0 && sync_bytes >= need;
+  if (*fused) {
+    a.ticket = reinterpret_cast<unsigned*>(sync);
+    a.part = reinterpret_cast<float*>(a.ticket + S5_MAX_TICKETS);
+    a.loss[0] = loss_1;
+    a.loss[1] = loss_2;
+  }
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if (!granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)pairmin_s5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S5_LDS);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store(1, std::memory_order_relaxed);
+  }
+  const unsigned blocks = (unsigned)(((B + 7) / 8) * 8) * (unsigned)p.members;
+  {
+    ObmanProfScope prof(kid, st);
+    pairmin_s5_kernel<<<dim3(blocks), S5_THREADS, S5_LDS, st>>>(a);
+  }
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float* min_x, int* idx_x, float* min_y,
-                   int* idx_y, void* ws, long ws_bytes, hipStream_t st) {
+                   int* idx_y, void* ws, long ws_bytes, hipStream_t st, float* loss_x = nullptr, float* loss_y = nullptr,
+                   void* sync = nullptr, long sync_bytes = 0, bool* means_done = nullptr, int kid = OBMAN_K_PAIRMIN_FWD) {
   if (B < 0 || Nx < 0 || Ny < 0) return -1;
   if (B == 0) return 0;
   if (Nx == 0 || Ny == 0) return -2;  // torch.min over an empty dim raises in the reference
+  if (means_done) *means_done = false;
+  {
+    const S5Plan p = s5_plan(x, y, Nx, Ny, min_x, idx_x, min_y, idx_y);
+    if (p.ok) {
+      bool fused = false;
+      const int rc = launch_s5(p, B, loss_x, loss_y, sync, sync_bytes, st, &fused, kid);
+      if (means_done) *means_done = fused;
+      return rc;
+    }
+  }
   PmDir d0{x, y, min_x, idx_x, nullptr, Nx, Ny, 0, 1, Ny, PM_REF_TILE};
   PmDir d1{y, x, min_y, idx_y, nullptr, Ny, Nx, 0, 1, Nx, PM_REF_TILE};
   int q0 = choose_qpt(B, Nx, Ny), q1 = choose_qpt(B, Ny, Nx);
@@ -363,15 +718,15 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
     const int gx0 = d0.qtiles * d0.rsplit, gx1 = d1.qtiles * d1.rsplit;
     const int tile = tile_of(d0) > tile_of(d1) ? tile_of(d0) : tile_of(d1);
     d0.tile = d1.tile = tile;
-    launch_fwd(q0, dim3(gx0 > gx1 ? gx0 : gx1, B, 2), smem_of(tile, q0), st, d0, d1);
+    launch_fwd(q0, dim3(gx0 > gx1 ? gx0 : gx1, B, 2), smem_of(tile, q0), st, d0, d1, kid);
   } else {  // one launch per direction, each with its own query tiling
     if (min_x) {
       d0.tile = tile_of(d0);
-      launch_fwd(q0, dim3(d0.qtiles * d0.rsplit, B, 1), smem_of(d0.tile, q0), st, d0, d0);
+      launch_fwd(q0, dim3(d0.qtiles * d0.rsplit, B, 1), smem_of(d0.tile, q0), st, d0, d0, kid);
     }
     if (min_y) {
       d1.tile = tile_of(d1);
-      launch_fwd(q1, dim3(d1.qtiles * d1.rsplit, B, 1), smem_of(d1.tile, q1), st, d1, d1);
+      launch_fwd(q1, dim3(d1.qtiles * d1.rsplit, B, 1), smem_of(d1.tile, q1), st, d1, d1, kid);
     }
   }
   OBMAN_LAUNCH_CHECK();
@@ -389,7 +744,7 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
 
 int launch_pairmin_bwd(const float* x, const float* y, int B, int Nx, int Ny, const int* idx_x, const int* idx_y,
                        const float* g_x, const float* g_y, float* grad_x, float* grad_y, int per_sample,
-                       hipStream_t st) {
+                       hipStream_t st, int kid = OBMAN_K_PAIRMIN_BWD) {
   if (B < 0 || Nx <= 0 || Ny <= 0) return B == 0 ? 0 : -1;
   if (B == 0) return 0;
   if ((g_x && !idx_x) || (g_y && !idx_y)) return -3;
@@ -399,7 +754,7 @@ int launch_pairmin_bwd(const float* x, const float* y, int B, int Nx, int Ny, co
   if (!grad_x && !grad_y) return 0;
   dim3 grid(obman_cdiv(n_max, 64), B, 2);
   {
-    ObmanProfScope prof(OBMAN_K_PAIRMIN_BWD, st);
+    ObmanProfScope prof(kid, st);
     pairmin_bwd_kernel<<<grid, 256, 0, st>>>(s0, s1);
   }
   OBMAN_LAUNCH_CHECK();
@@ -425,13 +780,22 @@ int obman_pairmin_bwd(const float* x, const float* y, int B, int Nx, int Ny, con
   return launch_pairmin_bwd(x, y, B, Nx, Ny, idx_x, idx_y, g_min_x, g_min_y, grad_x, grad_y, 0, (hipStream_t)stream);
 }
 
+long obman_chamfer_sync_bytes(int B, int Np, int Ng) {
+  if (B <= 0 || Np <= 0 || Ng <= 0) return 0;
+  float dummy = 0.f;  // only the pointers' null-ness matters to the plan
+  const S5Plan p = s5_plan(nullptr, nullptr, Np, Ng, &dummy, nullptr, &dummy, nullptr);
+  return p.ok ? s5_sync_bytes(B, p.members) : 0;
+}
+
 int obman_chamfer_fwd(const float* preds, const float* gts, int B, int Np, int Ng, float* loss_1, float* loss_2,
                       float* min_pred, int* idx_pred, float* min_gt, int* idx_gt, void* ws, long ws_bytes,
-                      obman_stream_t stream) {
+                      void* sync, long sync_bytes, obman_stream_t stream) {
   if (!loss_1 || !loss_2 || !min_pred || !min_gt) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = launch_pairmin(preds, gts, B, Np, Ng, min_pred, idx_pred, min_gt, idx_gt, ws, ws_bytes, st);
-  if (rc != 0 || B == 0) return rc;
+  bool means_done = false;
+  const int rc = launch_pairmin(preds, gts, B, Np, Ng, min_pred, idx_pred, min_gt, idx_gt, ws, ws_bytes, st, loss_1, loss_2, sync,
+                                sync_bytes, &means_done, OBMAN_K_CHAMFER_FWD);
+  if (rc != 0 || B == 0 || means_done) return rc;
   rowmean2_kernel<<<dim3(B, 2), 256, 0, st>>>(min_pred, Np, loss_1, min_gt, Ng, loss_2);
   OBMAN_LAUNCH_CHECK();
   return 0;
@@ -441,7 +805,7 @@ int obman_chamfer_bwd(const float* preds, const float* gts, int B, int Np, int N
                       const int* idx_gt, const float* g_loss_1, const float* g_loss_2, float* grad_preds,
                       float* grad_gts, obman_stream_t stream) {
   return launch_pairmin_bwd(preds, gts, B, Np, Ng, idx_pred, idx_gt, g_loss_1, g_loss_2, grad_preds, grad_gts, 1,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, OBMAN_K_CHAMFER_BWD);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@ enum {
   OBMAN_K_PAIRMIN_FWD = 1, OBMAN_K_PAIRMIN_BWD = 2, OBMAN_K_CONTAINS = 3, OBMAN_K_CONTACT_FWD = 4,
   OBMAN_K_CONTACT_BWD = 5, OBMAN_K_MANO_FWD = 6, OBMAN_K_MANO_BWD = 7, OBMAN_K_DECODER_FWD = 8,
   OBMAN_K_DECODER_BWD = 9,
+  OBMAN_K_CHAMFER_FWD = 10, OBMAN_K_CHAMFER_BWD = 11,  // ChamferLoss launches only (1/2 = hand<->object closest-vertex launches)
 };
 
 struct ObmanProfScope {

@@ -90,6 +90,23 @@ def pairmin(x, y, want_x=True, want_y=True):
     return _PairMin.apply(x, y, bool(want_x), bool(want_y))
 
 
+_SYNC = {}  # (device index, stream id) -> zero-initialised arrival counters + partial sums of the single-launch Chamfer
+
+
+def _chamfer_sync(B, n_p, n_g, device):
+    """The `sync` buffer of obman_chamfer_fwd (include/obman_hip.h): zeroed ONCE here, left zero by every call, one per stream
+    (stream-ordered calls may share it, concurrent ones may not)."""
+    nbytes = _lib.lib().obman_chamfer_sync_bytes(B, n_p, n_g)
+    if nbytes <= 0:
+        return None, 0
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SYNC.get(key)
+    if buf is None or buf.numel() < nbytes:
+        # a fresh allocation rather than a resize: kernels already queued on this stream may still be using the old one
+        buf = _SYNC[key] = torch.zeros(max(nbytes, 4096), dtype=torch.uint8, device=device)
+    return buf, buf.numel()
+
+
 class _Chamfer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, preds, gts):
@@ -103,10 +120,11 @@ class _Chamfer(torch.autograd.Function):
         min_pred, min_gt = mins.view(-1)[: B * n_p], mins.view(-1)[B * n_p:]
         idx_pred, idx_gt = idx[: B * n_p], idx[B * n_p:]
         ws, ws_bytes = _workspace(B, n_p, n_g, preds.device)
+        sync, sync_bytes = _chamfer_sync(B, n_p, n_g, preds.device)
         _lib.check(_lib.lib().obman_chamfer_fwd(
             preds.data_ptr(), gts.data_ptr(), B, n_p, n_g, loss[0].data_ptr(), loss[1].data_ptr(),
             min_pred.data_ptr(), idx_pred.data_ptr(), min_gt.data_ptr(), idx_gt.data_ptr(),
-            _ptr(ws), ws_bytes, _stream()), "obman_chamfer_fwd")
+            _ptr(ws), ws_bytes, _ptr(sync), sync_bytes, _stream()), "obman_chamfer_fwd")
         ctx.save_for_backward(preds, gts, idx)
         return loss[0], loss[1]
 

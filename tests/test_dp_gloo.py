@@ -49,14 +49,18 @@ def _worker(rank, world, port, out_dir):
             for p in net.parameters():
                 p.add_(1.0)
     broadcast_parameters(net)
-    buckets = GradientBuckets(net.parameters(), bucket_bytes=256, exclude=net.unused.parameters())
+    # direct_bytes=1024: the two larger weight matrices (1536 and 2048 bytes) are all-reduced in place, the rest is packed
+    buckets = GradientBuckets(net.parameters(), bucket_bytes=256, exclude=net.unused.parameters(), direct_bytes=1024)
+    plan = buckets.describe()
+    assert plan["in_place_tensor_bytes"] == [2048, 1536] and "P" in plan["order"] and plan["order"].endswith("P"), plan
     assert len(buckets.buckets) >= 3
     # bucket targets shrink once less than one full bucket remains: the last (exposed) bucket is the smallest
     probe = GradientBuckets(nn.ModuleList([nn.Linear(8, 8) for _ in range(23)]).parameters(), bucket_bytes=1024, tail_bytes=64)
     sizes = [flat.numel() * 4 for flat, _ in probe.buckets]  # 23 x (256 + 32) bytes, walked from the last layer
     assert sizes == [1152] * 5 + [576, 288 + 46 * 4], sizes  # + one "some rank had a gradient" flag per parameter in the last one
     info = probe.describe()
-    assert info["world_size"] == 2 and info["backend"] == "gloo" and info["bucket_bytes"] == sizes and info["parameters"] == 46
+    assert info["world_size"] == 2 and info["backend"] == "gloo" and info["packed_bucket_bytes"] == sizes and info["parameters"] == 46
+    assert info["in_place_tensor_bytes"] == [] and info["order"] == "P" * 7
     x, y = _data()
     shard = slice(rank * 4, rank * 4 + 4)
     for step in range(2):  # twice: bucket state must reset between steps
@@ -68,8 +72,9 @@ def _worker(rank, world, port, out_dir):
         loss = ((net(x[shard]) - y[shard]) ** 2).mean()
         loss.backward()
         buckets.finish()
-    flat = buckets.buckets[buckets._where[net.body[0].weight]][0]
-    assert flat.data_ptr() <= net.body[0].weight.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4  # grad now lives in its bucket
+    flat = buckets.buckets[buckets._where[net.body[0].bias]][0]
+    assert flat.data_ptr() <= net.body[0].bias.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4  # a packed gradient lives in its bucket
+    assert buckets.buckets[buckets._where[net.body[0].weight]][0] is None  # a big one was reduced where autograd left it
     grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}
     torch.save(grads, os.path.join(out_dir, "grads_%d.pt" % rank))
     dist.destroy_process_group()

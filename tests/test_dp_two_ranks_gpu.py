@@ -32,6 +32,10 @@ def _build():
     from obman_train_amd.synthetic import CONFIGS
 
     warnings.simplefilter("ignore")
+    # the same convolution solutions in every process, and none that accumulate with atomics: the two workers and the
+    # reference runs below then differ by round-off of the averaging only, and the comparison can be tight
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
     torch.manual_seed(0)
     return HandNet(**CONFIGS["c3p1"]).to("cuda:0").train()
 
@@ -149,8 +153,9 @@ def test_two_ranks_real_handnet_average_per_shard_gradients(tmp_path):
                 continue
             err = (g - w).abs().max().item() / max(w.abs().max().item(), 1e-30)
             worst = max(worst, err)
-            # MIOpen's weight-gradient kernels accumulate with atomics: run-to-run differences of ~1e-6..1e-5 of the largest entry
-            assert err <= 1e-3, (r, k, err)
+            # deterministic convolution solutions on both sides (see _build): what is left is the fp32 rounding of (a + b) / 2
+            # against a / 2 + b / 2, plus at most one flipped ReLU / contact-mask element from a last-bit difference
+            assert err <= 2e-4, (r, k, err)
         for k, v in want_bn[r].items():  # BatchNorm statistics are those of the rank's own shard ...
             torch.testing.assert_close(got[r]["bn"][k], v, rtol=1e-4, atol=1e-6)
     assert got[0]["grads"]["base_net.fc.weight"] is None and got[1]["grads"]["base_net.fc.weight"] is None

@@ -194,7 +194,9 @@ def test_configs2_model_matches_oracle_at_full_size(inject):
     model.cuda()
     total, res, losses = model.forward(sample)
     total.backward()
-    tol, gtol = (1e-4, 1e-3) if inject else (1e-3, 2e-2)
+    # with the real encoder: measured total 3.3e-7, worst loss term 3.0e-4, object points 2.3e-5 of their scale (MI355X,
+    # profiles/r03_parity_measured.md) -> bounds 4e-4 (total, points) / 8e-4 (terms); with injected features north_star's 1e-4
+    tol, gtol = (1e-4, 1e-3) if inject else (4e-4, 2e-2)
     from tests.conftest import record_measurement
 
     rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)  # noqa: E731
@@ -203,7 +205,7 @@ def test_configs2_model_matches_oracle_at_full_size(inject):
         "worst_loss": max(rel(losses[k], v) for k, v in o_losses.items() if v is not None and abs(float(v)) > 1e-5),
         "objpoints3d_of_scale": float((res["objpoints3d"].detach().cpu() - o_res["objpoints3d"].detach()).abs().max()
                                       / o_res["objpoints3d"].detach().abs().max())})
-    np.testing.assert_allclose(float(total), float(o_total), rtol=tol)
+    np.testing.assert_allclose(float(total), float(o_total), rtol=tol if inject else 1e-5)
     for k, v in o_losses.items():
         if v is None:
             assert losses[k] is None

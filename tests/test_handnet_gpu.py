@@ -10,7 +10,11 @@ from tests.handnet_common import assert_matches_fixture, build_fixture_model, fi
 pytestmark = pytest.mark.gpu
 
 # real-ResNet18 whole-model bounds against the CPU oracle (see test_handnet_resnet18_matches_cpu_oracle)
-TOL_TOTAL, TOL_LOSS, TOL_POINTS, TOL_GRAD = 1e-3, 2e-3, 1e-3, 2e-2
+# Measured on MI355X (profiles/r03_parity_measured.md; bs 4, 64 x 64, three configurations): total 1.4e-6, worst loss term 7.8e-5
+# (3.0e-4 in the 25-patch model of tests/test_fullsize_gpu.py), vertices 5e-7 / object points 2.5e-5 of their scale, worst
+# sampled gradient 4.1e-3 of its largest entry (layer4 under a 16-value BatchNorm).  Bounds = 2.5-7x those, because MIOpen's
+# find picks the convolution solutions per process and its weight-gradient kernels accumulate with atomics.
+TOL_TOTAL, TOL_LOSS, TOL_POINTS, TOL_GRAD = 1e-5, 8e-4, 1e-4, 1e-2
 
 
 @pytest.mark.parametrize("tag", ["train", "eval"])
@@ -104,9 +108,12 @@ def test_handnet_resnet18_matches_cpu_oracle(contact, patches):
 
 # configs[2] in its stated precision: bounds = ~2x what MI355X produced (profiles/r03_parity_measured.md), frozen.
 FLAVOUR_BOUNDS = {
-    # flavour: (smooth loss terms rel., total rel., objpoints3d max |diff| / scale, repulsion-mask Hamming fraction, 5-step trajectory rel.)
-    "dec_bf16": dict(loss=2e-2, total=2e-2, points=1e-2, hamming=1e-2, track=2e-2),
-    "all_bf16": dict(loss=2e-2, total=2e-2, points=1e-2, hamming=1e-2, track=2e-2),
+    # smooth loss terms rel. | total rel. | objpoints3d: max |diff| and rms diff over the point scale | repulsion-mask Hamming fraction |
+    # five-Adam-step loss trajectory rel.   Measured (bs 16, 256 x 256, profiles/r03_parity_measured.md):
+    #   dec_bf16: loss 8.8e-4, total 3.7e-4, points max 7.8e-3, hamming 2.5e-3, track 4.2e-3
+    #   all_bf16: loss 1.4e-2 (final_chamfer_loss), total 5.0e-3, points max 6.8e-2, hamming 3.0e-2, track 1.3e-2
+    "dec_bf16": dict(loss=2e-3, total=1e-3, points=1.6e-2, points_rms=4e-3, hamming=6e-3, track=1e-2),
+    "all_bf16": dict(loss=3e-2, total=1.5e-2, points=0.15, points_rms=2e-2, hamming=6e-2, track=3e-2),
 }
 
 
@@ -150,6 +157,7 @@ def test_configs2_precision_flavours_track_the_fp32_model_at_size():
         got = out[flavour]
         m = {"total": abs(got["total"] - ref["total"]) / abs(ref["total"]),
              "points": (got["points"] - ref["points"]).abs().max().item() / scale,
+             "points_rms": (got["points"] - ref["points"]).square().mean().sqrt().item() / scale,
              "hamming": (got["rep"] != ref["rep"]).float().mean().item(),
              "track": max(abs(a - b) / abs(b) for a, b in zip(got["track"], ref["track"]))}
         terms = {}

@@ -25,7 +25,11 @@ def _check_dir(x, y, mn, idx, P=None):
 
 
 @pytest.mark.parametrize("B,nx,ny", [(1, 1, 1), (2, 5, 3), (3, 50, 37), (2, 642, 600), (4, 778, 642),
-                                     (1, 1030, 257), (2, 3, 2100)])
+                                     (1, 1030, 257), (2, 3, 2100),
+                                     # small-set path (whole reference set in LDS, 320-query tiles): 328 = 320 + 8 leftover queries
+                                     # (the transposed role at its maximum), 329 (a second tile instead), 1024 references (the
+                                     # largest staged set, 128 per wave), 961 = 3 tiles + 1 leftover, 17 references (one chunk of 4 per wave)
+                                     (2, 328, 40), (2, 329, 333), (3, 961, 1024), (9, 1024, 17)])
 def test_pairmin_matches_oracle(B, nx, ny):
     from obman_train_amd import ops
 
@@ -110,6 +114,37 @@ def test_pairmin_general_backward_matches_oracle():
     ((ox * wx.double()).sum() + (oy * wy.double()).sum()).backward()
     np.testing.assert_allclose(xc.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(yc.grad.cpu().numpy(), yo.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_chamfer_single_launch_means_and_self_cleaning_sync_buffer():
+    """configs[1] size (64 x 642 x 600): the per-sample means come out of the pair-min launch itself (last block of a sample to
+    finish adds the published partial sums).  Against the fp64 oracle for every sample; repeated calls on changing inputs reuse
+    one `sync` buffer, which every call must leave zero; results are run-to-run bit-identical."""
+    from obman_train_amd import _lib, ops
+
+    B, n_p, n_g = 64, 642, 600
+    assert _lib.lib().obman_chamfer_sync_bytes(B, n_p, n_g) > 0       # this size takes the single-launch path
+    assert _lib.lib().obman_chamfer_sync_bytes(B, 16050, n_g) == 0    # the 25-patch size does not
+    first = None
+    for rep in range(6):
+        p, g = _rand(B, n_p, 40 + rep, offset=10.0), _rand(B, n_g, 50 + rep, offset=12.0)
+        l1, l2 = ops.chamfer(p.cuda(), g.cuda())
+        o1, o2 = ocham.chamfer_direct(p.double(), g.double())
+        np.testing.assert_allclose(l1.cpu().numpy(), o1.numpy(), rtol=1e-5)
+        np.testing.assert_allclose(l2.cpu().numpy(), o2.numpy(), rtol=1e-5)
+        m1, m2 = ops.chamfer(p.cuda(), g.cuda())
+        assert torch.equal(l1, m1) and torch.equal(l2, m2)
+        first = first or (l1, l2)
+    torch.cuda.synchronize()
+    bufs = list(ops._SYNC.values())
+    assert bufs and all(int(b[:4 * 4096].count_nonzero()) == 0 for b in bufs)  # every arrival counter is back at zero
+    # odd batch sizes (the XCD-aware block order pads the batch to a multiple of 8)
+    for Bo in (1, 7, 13):
+        p, g = _rand(Bo, n_p, 60 + Bo), _rand(Bo, n_g, 70 + Bo)
+        l1, l2 = ops.chamfer(p.cuda(), g.cuda())
+        o1, o2 = ocham.chamfer_direct(p.double(), g.double())
+        np.testing.assert_allclose(l1.cpu().numpy(), o1.numpy(), rtol=1e-5)
+        np.testing.assert_allclose(l2.cpu().numpy(), o2.numpy(), rtol=1e-5)
 
 
 def test_chamfer_full_size_properties():

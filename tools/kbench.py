@@ -47,16 +47,27 @@ def bench_chamfer():
         sizes = ((64, 64050, 600),)
     if os.environ.get("OBMAN_KBENCH_NPRED"):  # e.g. 642: one size (PMC passes)
         sizes = ((64, int(os.environ["OBMAN_KBENCH_NPRED"]), 600),)
+    rotate = int(os.environ.get("OBMAN_KBENCH_ROTATE", "0"))  # >0: cycle through that many input sets (PMC passes: keeps the MALL from serving re-used inputs)
     for B, n_p, n_g in sizes:
         p = (torch.randn(B, n_p, 3, device="cuda") * 40).requires_grad_()
         g = torch.randn(B, n_g, 3, device="cuda") * 40
-        t_f = kernel_us(lambda: ops.chamfer(p, g), 1) * 1e-6
+        if rotate:
+            sets = [(torch.randn(B, n_p, 3, device="cuda") * 40, torch.randn(B, n_g, 3, device="cuda") * 40) for _ in range(rotate)]
+            state = {"i": 0}
+
+            def fwd():
+                a, b = sets[state["i"] % rotate]
+                state["i"] += 1
+                return ops.chamfer(a, b)
+        else:
+            fwd = lambda: ops.chamfer(p, g)  # noqa: E731
+        t_f = kernel_us(fwd, 10, iters=max(30, 2 * rotate)) * 1e-6
         l1, l2 = ops.chamfer(p, g)
         loss = (l1 + l2).mean()
-        t_b = kernel_us(lambda: torch.autograd.grad(loss, p, retain_graph=True), 2) * 1e-6
+        t_b = kernel_us(lambda: torch.autograd.grad(loss, p, retain_graph=True), 11) * 1e-6
         pairs = 2.0 * B * n_p * n_g  # both directions evaluate every pair once
         print(json.dumps(dict(
-            kernel="chamfer", qpt=os.environ.get("OBMAN_PM_QPT", "auto"), B=B, n_pred=n_p, n_gt=n_g,
+            kernel="chamfer", qpt=os.environ.get("OBMAN_PM_QPT", "auto"), s5=os.environ.get("OBMAN_PM_S5", "1"), rotate=rotate, B=B, n_pred=n_p, n_gt=n_g,
             fwd_us=round(t_f * 1e6, 2), bwd_us=round(t_b * 1e6, 2),
             fwd_alg_GBps=round(20.0 * (n_p + n_g) * B / t_f / 1e9, 1), fwd_Tpairs_per_s=round(pairs / t_f / 1e12, 3),
             fwd_valu_TFLOPs=round(pairs * 5 / t_f / 1e12, 1))), flush=True)
