@@ -215,8 +215,10 @@ __global__ __launch_bounds__(256) void rowmean2_kernel(const float* a, int na, f
 // re-load of the resolve pass) and two more launches for the per-sample means.  This path:
 //   * block = 512 threads = 8 waves over the SAME 320 queries (5 per lane in VGPRs), each wave sweeping an eighth of the staged
 //     references: 642 = 2 x 320 + 2 and 600 = 2 x 300, so a sample is 4 equal blocks = exactly one per CU at bs 64;
-//   * a remainder of <= S5_LEFT_MAX queries (the 2 of 642) is not padded to another tile: one short extra block per direction
-//     evaluates it TRANSPOSED (lanes over references, u64 (distance bits, index) min across the block);
+//   * a remainder of <= S5_LEFT_MAX queries (the 2 of 642) is not padded to another tile: the direction's last block evaluates
+//     it TRANSPOSED after its own tile (lanes over references, u64 (distance bits, index) min across the block);
+//   * the launch asks for more than half of a CU's LDS, so two blocks never share a CU: 256 equal blocks land on 256 CUs
+//     (the first version let the dispatcher double some CUs up: 21 us instead of 13 for the same work);
 //   * arg-min bookkeeping per 16-reference chunk instead of per 4-reference group: inside a chunk only the running minimum is
 //     kept (two v_min3_f32 per 4 pairs), one compare + two selects per chunk and query; the exact index is recovered by
 //     re-evaluating the winning chunk with the same pinned instruction sequence (bit-identical, first index wins);
@@ -239,7 +241,7 @@ struct S5Dir {
 };
 struct S5Args {
   S5Dir d[2];
-  int B, members, m0;   // blocks per sample; members of direction 0 (tiles + leftover block)
+  int B, members, m0;   // blocks per sample; of which direction 0's (its tiles)
   float* part;          // [B, members] published partial sums (null: no fused means)
   unsigned* ticket;     // [B] arrival counters, zero on entry, zero on return
   float* loss[2];       // [B] per direction
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(S5_THREADS) void pairmin_s5_kernel(S5Args a) {
   const int dir = member >= a.m0 ? 1 : 0;
   const S5Dir d = a.d[dir];
   const int mem = member - (dir ? a.m0 : 0);
-  const bool leftover = mem >= d.tiles;
+  const bool leftover = d.left > 0 && mem == d.tiles - 1;  // this block also evaluates the direction's remainder queries
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ qb = d.q + (size_t)b * d.nq * 3;
   const float* __restrict__ rb = d.r + (size_t)b * d.nr * 3;
@@ -266,12 +268,12 @@ __global__ __launch_bounds__(S5_THREADS) void pairmin_s5_kernel(S5Args a) {
   const int padded = d.slice * S5_WAVES;
   float(*s_val)[S5_TILE] = reinterpret_cast<float(*)[S5_TILE]>(pm_smem + (size_t)S5_MAX_REFS * sizeof(float4));
   int(*s_grp)[S5_TILE] = reinterpret_cast<int(*)[S5_TILE]>(pm_smem + (size_t)S5_MAX_REFS * sizeof(float4) + sizeof(float) * S5_WAVES * S5_TILE);
-  u64* s_key = reinterpret_cast<u64*>(s_val);  // leftover role: one packed (distance, index) key per leftover query
+  __shared__ u64 s_key[S5_LEFT_MAX];  // remainder role: one packed (distance, index) key per remainder query
   __shared__ float s_sum[S5_WAVES];
 
   // queries first (main role), then every staging load, one wait for all of them
   float qx[S5_QPT], qy[S5_QPT], qz[S5_QPT];
-  if (!leftover) {
+  {
 #pragma unroll
     for (int k = 0; k < S5_QPT; ++k) {
       const int qi = mem * S5_TILE + k * 64 + lane;
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(S5_THREADS) void pairmin_s5_kernel(S5Args a) {
   if (leftover && tid < S5_LEFT_MAX) s_key[tid] = ~0ull;
   __syncthreads();
 
-  float block_sum = 0.f;  // valid in thread 0 after the role's epilogue
-  if (!leftover) {
+  float block_sum = 0.f;  // valid in thread 0 after the epilogues
+  {
     float best[S5_QPT], cm[S5_QPT];
     int bestc[S5_QPT];
 #pragma unroll
@@ -410,8 +412,9 @@ __global__ __launch_bounds__(S5_THREADS) void pairmin_s5_kernel(S5Args a) {
       __syncthreads();
       if (tid == 0) block_sum = (((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) + s_sum[4]);
     }
-  } else {
-    // transposed role: each leftover query against all references, lanes over references
+  }
+  if (leftover) {
+    // transposed role: each remainder query against all references, lanes over references
     for (int lq = 0; lq < d.left; ++lq) {
       const int qi = nmain + lq;
       const float x = qb[(size_t)qi * 3], y = qb[(size_t)qi * 3 + 1], z = qb[(size_t)qi * 3 + 2];
@@ -627,11 +630,14 @@ S5Plan s5_plan(const float* x, const float* y, int Nx, int Ny, float* min_x, int
   if (!p.ok) return p;
   s5_plan_dir(p.d0);
   s5_plan_dir(p.d1);
-  p.m0 = min_x ? p.d0.tiles + (p.d0.left ? 1 : 0) : 0;
-  p.members = p.m0 + (min_y ? p.d1.tiles + (p.d1.left ? 1 : 0) : 0);
+  p.m0 = min_x ? p.d0.tiles : 0;
+  p.members = p.m0 + (min_y ? p.d1.tiles : 0);
   return p;
 }
-constexpr size_t S5_LDS = (size_t)S5_MAX_REFS * sizeof(float4) + (size_t)2 * S5_WAVES * S5_TILE * sizeof(float);
+// what the kernel uses (reference tile + merge buffers = 36 KB), raised to just over half of a CU's 160 KB so that the dispatcher
+// cannot put two of these blocks on one CU while another CU idles (equal blocks, one round: the slowest CU is the kernel time)
+constexpr size_t S5_LDS_USED = (size_t)S5_MAX_REFS * sizeof(float4) + (size_t)2 * S5_WAVES * S5_TILE * sizeof(float);
+constexpr size_t S5_LDS = S5_LDS_USED > 82 * 1024 ? S5_LDS_USED : 82 * 1024;
 // `sync` layout: [S5_MAX_TICKETS arrival counters][B x members partial sums].  The counter region has a FIXED size so that calls
 // with different batch sizes sharing one buffer never see another call's (non-zero) partial sums where they expect zero counters.
 constexpr int S5_MAX_TICKETS = 4096;

@@ -65,6 +65,10 @@ class GradientBuckets:
         if not self.enabled:
             return
         self.backend = dist.get_backend(group)
+        import os
+
+        # measurement aid for the 1-rank self-test only (`bench.py --force-dist`): hooks, packing and views as usual, collectives skipped
+        self._no_reduce = self.world == 1 and os.environ.get("OBMAN_DP_DEBUG") == "noreduce"
         self._avg = self.backend == "nccl"  # RCCL averages in the collective; gloo has no AVG
         # Packed-bucket targets shrink towards the end of backward: the LAST bucket's all-reduce is the only exposed one
         # (nothing is left to hide it behind), so once less than one full bucket of small gradients remains the target halves
@@ -167,7 +171,8 @@ class GradientBuckets:
                 self._missing.append(p)
             elif not (p.grad.is_contiguous() or (p.grad.dim() == 4 and p.grad.is_contiguous(memory_format=torch.channels_last))):
                 p.grad = p.grad.contiguous()
-            self._works.append((b, dist.all_reduce(p.grad, op=op, group=self.group, async_op=True)))
+            if not self._no_reduce:
+                self._works.append((b, dist.all_reduce(p.grad, op=op, group=self.group, async_op=True)))
             return
         views, grads = [], []
         for slot in slots:
@@ -193,7 +198,8 @@ class GradientBuckets:
                 grads.append(self._ones)
         if views:
             torch._foreach_copy_(views, grads)
-        self._works.append((b, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
+        if not self._no_reduce:
+            self._works.append((b, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
 
     def _drain(self, everything=False):
         while self._next < len(self.buckets) and (everything or self._pending[self._next] == 0):
