@@ -242,6 +242,7 @@ struct S5Dir {
 struct S5Args {
   S5Dir d[2];
   int B, members, m0;   // blocks per sample; of which direction 0's (its tiles)
+  int pairwise;         // every direction has <= 2 tiles: partial sums exchanged inside one atomicOr (see the kernel's epilogue)
   float* part;          // [B, members] published partial sums (null: no fused means)
   unsigned* ticket;     // [B] arrival counters, zero on entry, zero on return
   float* loss[2];       // [B] per direction
@@ -447,7 +448,29 @@ __global__ __launch_bounds__(S5_THREADS) void pairmin_s5_kernel(S5Args a) {
   }
 
   if (a.part == nullptr || tid != 0) return;
-  // publish, draw a ticket, and - for the last arriver of this sample - add the partial sums in member order
+  if (a.pairwise) {
+    // Every direction has at most two blocks per sample (642 x 600: two tiles each): the partial sum travels INSIDE the one
+    // atomic.  A 64-bit word per (sample, direction), zero on entry, one 32-bit field per tile holding the bits of the partial
+    // sum with the sign bit set (sums are >= +0, so a field is non-zero exactly when its tile has arrived).  atomicOr returns the
+    // other tile's field: whoever sees it set has both sums, adds them tile 0 first, writes the mean and clears the word.  One
+    // round trip instead of store -> acknowledgement -> ticket -> read-back; still order- and placement-independent.
+    float* out = a.loss[dir];
+    if (d.tiles == 1) {
+      if (out) out[b] = block_sum / (float)d.nq;
+      return;
+    }
+    u64* word = reinterpret_cast<u64*>(a.ticket) + (size_t)b * 2 + dir;
+    const u64 mine_field = (u64)(__float_as_uint(block_sum) | 0x80000000u) << (32 * mem);
+    const u64 old = __hip_atomic_fetch_or(word, mine_field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned other = (unsigned)(old >> (32 * (1 - mem)));
+    if (!other) return;  // first of the two
+    const float po = __uint_as_float(other & 0x7fffffffu);
+    const float total = mem == 0 ? block_sum + po : po + block_sum;
+    if (out) out[b] = total / (float)d.nq;
+    __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-cleaning for the next call
+    return;
+  }
+  // general case: publish, draw a ticket, and - for the last arriver of this sample - add the partial sums in member order
   float* mine_slot = a.part + (size_t)b * a.members + member;
   __hip_atomic_store(mine_slot, block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through store is acknowledged before the ticket is drawn
@@ -657,6 +680,7 @@ int launch_s5(const S5Plan& p, int B, float* loss_1, float* loss_2, void* sync, 
   const long need = s5_sync_bytes(B, p.members);
   *fused = want_mean && sync && need > 0 && sync_bytes >= need;
   if (*fused) {
+    a.pairwise = p.d0.tiles <= 2 && p.d1.tiles <= 2 && (size_t)B * 2 * sizeof(u64) <= (size_t)S5_MAX_TICKETS * sizeof(unsigned);
     a.ticket = reinterpret_cast<unsigned*>(sync);
     a.part = reinterpret_cast<float*>(a.ticket + S5_MAX_TICKETS);
     a.loss[0] = loss_1;

@@ -111,9 +111,11 @@ FLAVOUR_BOUNDS = {
     # smooth loss terms rel. | total rel. | objpoints3d: max |diff| and rms diff over the point scale | repulsion-mask Hamming fraction |
     # five-Adam-step loss trajectory rel.   Measured (bs 16, 256 x 256, profiles/r03_parity_measured.md):
     #   dec_bf16: loss 8.8e-4, total 3.7e-4, points max 7.8e-3, hamming 2.5e-3, track 4.2e-3
-    #   all_bf16: loss 1.4e-2 (final_chamfer_loss), total 5.0e-3, points max 6.8e-2, hamming 3.0e-2, track 1.3e-2
+    #   all_bf16 (three boxes): loss 3.8e-3 .. 1.4e-2 (final_chamfer_loss), total 1.7e-3 .. 5.0e-3, points max 6.8e-2 .. 8.0e-2 / rms 1.6e-2,
+    #             hamming 3.0e-2 .. 3.1e-2, track 1.3e-2 .. 5.4e-2 - MIOpen's bf16 weight-gradient kernels accumulate with atomics, so
+    #             the encoder's gradients (hence the Adam trajectory) differ from run to run; the decoder-only flavour is run-to-run stable
     "dec_bf16": dict(loss=2e-3, total=1e-3, points=1.6e-2, points_rms=4e-3, hamming=6e-3, track=1e-2),
-    "all_bf16": dict(loss=3e-2, total=1.5e-2, points=0.15, points_rms=2e-2, hamming=6e-2, track=3e-2),
+    "all_bf16": dict(loss=3e-2, total=1.5e-2, points=0.16, points_rms=4e-2, hamming=6e-2, track=0.12),
 }
 
 

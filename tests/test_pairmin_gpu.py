@@ -83,7 +83,9 @@ def test_chamfer_matches_reference_golden(golden):
         assert err <= 1e-4 * np.abs(want).max() + 1e-6, err
 
 
-@pytest.mark.parametrize("B,n_p,n_g", [(2, 42, 40), (3, 642, 600), (2, 1300, 77)])
+# (3, 642, 600): two tiles per direction -> the means are exchanged inside one atomicOr; (5, 1000, 700): 4 + 3 tiles per sample -> the
+# general publish / ticket / read-back protocol; (2, 1300, 77): the general (non-LDS-resident) path with its separate mean kernel
+@pytest.mark.parametrize("B,n_p,n_g", [(2, 42, 40), (3, 642, 600), (2, 1300, 77), (5, 1000, 700), (9, 330, 1024)])
 def test_chamfer_fwd_bwd_matches_oracle_autograd(B, n_p, n_g):
     from obman_train_amd import ops
 
