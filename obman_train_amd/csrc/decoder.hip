@@ -765,6 +765,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 
 
 #include "decoder_bf16.h"
+#include "decoder_rows2.h"
 
 }  // namespace dec
 
@@ -1673,8 +1674,8 @@ int launch_tn(const AOp& a, const BOp& b, int M, int Nc, long R, int, float* par
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
-int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* out, hipStream_t st) {
-  const int Kp = kpad(K);
+int launch_wcast(const float* W, int ld, int Nn, int K, int transposed, bfraw* out, hipStream_t st, int Kp_override = 0) {
+  const int Kp = Kp_override ? Kp_override : kpad(K);
   wcast_kernel<<<obman_cdiv((long)Nn * Kp / 2, 256), 256, 0, st>>>(W, ld, Nn, K, Kp, transposed, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
@@ -1740,6 +1741,53 @@ int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) 
   rows = segs;
   return 0;
 }
+// ---- second-generation rows GEMMs (decoder_rows2.h): persistent blocks, weights stationary in LDS
+int device_cus() {
+  static std::atomic<int> cus[MAX_DEVICES];
+  const int dev = current_device();
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+bool rows2_enabled() {
+  static const int on = [] { const char* e = getenv("OBMAN_DEC_ROWS2"); return e ? atoi(e) : 1; }();  // A/B knob
+  return on != 0;
+}
+R2Geo r2_geo(const Dims& d, int mode, int Nc) {
+  R2Geo g{};
+  g.R = (int)d.R; g.N = d.N; g.B = d.B; g.mode = mode;
+  g.nvt = mode == 0 ? (d.N + 63) / 64 : (d.N + 15) / 16;
+  g.nbg = mode == 0 ? (d.B + 7) / 8 : (d.B + 31) / 32;
+  g.ngroups = Nc > R2_SIDE ? (Nc - R2_SIDE + R2_COLS - 1) / R2_COLS : 1;
+  int target = device_cus() / g.ngroups;  // one block per CU (the weight slice takes most of a CU's LDS)
+  if (target < 1) target = 1;
+  g.spb = target / g.nbg;
+  if (g.spb < 1) g.spb = 1;
+  if (g.spb > g.nvt) g.spb = g.nvt;
+  g.slots = g.spb * g.nbg;
+  g.chunk = (g.nvt + g.spb - 1) / g.spb;
+  return g;
+}
+template <class AOp, class Epi>
+int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, hipStream_t st) {
+  size_t lds = (size_t)(R2_COLS + R2_SIDE) * (Kp + 8) * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
+  const size_t flush = (size_t)(R2_WAVES - 1) * (R2_NT + 1) * 32 * 2 * sizeof(double);  // the end-of-block reduction re-uses the slice
+  if (lds < flush) lds = flush;
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if ((int)lds > granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)rows2_bf16_kernel<AOp, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store((int)lds, std::memory_order_relaxed);
+  }
+  rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- bf16 flavour: layers 2-4 of the forward (after prep_kernel) and the whole backward (decoder_bf16.h)
 int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, float* out, float* ws, hipStream_t st) {
   const int tr = p->training;
@@ -1755,10 +1803,20 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     BGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
     EpiStoreB e{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
-    if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st))) return rc;
-    if ((rc = launch_rows_bf16<BGridFeat, EpiStoreB>(a, wb, d.C1, d.C2, tiled, e, st))) return rc;
     const double* mom = moments;
-    int mrows = tiled.blocks();
+    int mrows;
+    if (rows2_enabled()) {
+      const int Kp = kpad16(d.C1);
+      const R2Geo g2 = r2_geo(d, 0, d.C2);
+      EpiStoreB2 e2{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
+      if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st, Kp))) return rc;
+      if ((rc = launch_rows2<BGridFeat, EpiStoreB2>(a, wb, Kp, d.C2, g2, e2, st))) return rc;
+      mrows = g2.slots;
+    } else {
+      if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st))) return rc;
+      if ((rc = launch_rows_bf16<BGridFeat, EpiStoreB>(a, wb, d.C1, d.C2, tiled, e, st))) return rc;
+      mrows = tiled.blocks();
+    }
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C2 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(mom, mrows, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
                                                                p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
@@ -1768,10 +1826,20 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     BBnRelu a{H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
     EpiStoreB e{H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb3);
-    if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st))) return rc;
-    if ((rc = launch_rows_bf16<BBnRelu, EpiStoreB>(a, wb, d.C2, d.C3, geo, e, st))) return rc;
     const double* mom = moments;
-    int mrows = geo.blocks();
+    int mrows;
+    if (rows2_enabled()) {
+      const int Kp = kpad16(d.C2);
+      const R2Geo g2 = r2_geo(d, 0, d.C3);
+      EpiStoreB2 e2{H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
+      if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st, Kp))) return rc;
+      if ((rc = launch_rows2<BBnRelu, EpiStoreB2>(a, wb, Kp, d.C3, g2, e2, st))) return rc;
+      mrows = g2.slots;
+    } else {
+      if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st))) return rc;
+      if ((rc = launch_rows_bf16<BBnRelu, EpiStoreB>(a, wb, d.C2, d.C3, geo, e, st))) return rc;
+      mrows = geo.blocks();
+    }
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C3 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(mom, mrows, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
@@ -1821,11 +1889,20 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     BGradH3 a{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
     EpiMaskB e{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
     bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt3);
-    if ((rc = launch_wcast(p->w3, d.C2, d.C2, d.C3, 1, wt, st))) return rc;
-    if ((rc = launch_rows_bf16<BGradH3, EpiMaskB>(a, wt, d.C3, d.C2, lin, e, st))) return rc;
+    if (rows2_enabled()) {
+      const int Kp = kpad16(d.C3);
+      const R2Geo g2 = r2_geo(d, 0, d.C2);
+      EpiMaskB2 e2{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
+      if ((rc = launch_wcast(p->w3, d.C2, d.C2, d.C3, 1, wt, st, Kp))) return rc;
+      if ((rc = launch_rows2<BGradH3, EpiMaskB2>(a, wt, Kp, d.C2, g2, e2, st))) return rc;
+      srows = g2.slots;
+    } else {
+      if ((rc = launch_wcast(p->w3, d.C2, d.C2, d.C3, 1, wt, st))) return rc;
+      if ((rc = launch_rows_bf16<BGradH3, EpiMaskB>(a, wt, d.C3, d.C2, lin, e, st))) return rc;
+      srows = lin.blocks();
+    }
   }
   sp = sums;
-  srows = lin.blocks();
   if ((rc = pre_reduce<double>(sp, srows, d.C2 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);
