@@ -1756,11 +1756,11 @@ bool rows2_enabled() {
   static const int on = [] { const char* e = getenv("OBMAN_DEC_ROWS2"); return e ? atoi(e) : 1; }();  // A/B knob
   return on != 0;
 }
-R2Geo r2_geo(const Dims& d, int mode, int Nc) {
+R2Geo r2_geo(const Dims& d, int Nc) {
   R2Geo g{};
-  g.R = (int)d.R; g.N = d.N; g.B = d.B; g.mode = mode;
-  g.nvt = mode == 0 ? (d.N + 63) / 64 : (d.N + 15) / 16;
-  g.nbg = mode == 0 ? (d.B + 7) / 8 : (d.B + 31) / 32;
+  g.R = (int)d.R; g.N = d.N; g.B = d.B;
+  g.nvt = (d.N + 31) / 32;
+  g.nbg = (d.B + 7) / 8;
   g.ngroups = Nc > R2_SIDE ? (Nc - R2_SIDE + R2_COLS - 1) / R2_COLS : 1;
   int target = device_cus() / g.ngroups;  // one block per CU (the weight slice takes most of a CU's LDS)
   if (target < 1) target = 1;
@@ -1807,7 +1807,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     int mrows;
     if (rows2_enabled()) {
       const int Kp = kpad16(d.C1);
-      const R2Geo g2 = r2_geo(d, 0, d.C2);
+      const R2Geo g2 = r2_geo(d, d.C2);
       EpiStoreB2 e2{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st, Kp))) return rc;
       if ((rc = launch_rows2<BGridFeat, EpiStoreB2>(a, wb, Kp, d.C2, g2, e2, st))) return rc;
@@ -1830,7 +1830,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     int mrows;
     if (rows2_enabled()) {
       const int Kp = kpad16(d.C2);
-      const R2Geo g2 = r2_geo(d, 0, d.C3);
+      const R2Geo g2 = r2_geo(d, d.C3);
       EpiStoreB2 e2{H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
       if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st, Kp))) return rc;
       if ((rc = launch_rows2<BBnRelu, EpiStoreB2>(a, wb, Kp, d.C3, g2, e2, st))) return rc;
@@ -1891,7 +1891,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt3);
     if (rows2_enabled()) {
       const int Kp = kpad16(d.C3);
-      const R2Geo g2 = r2_geo(d, 0, d.C2);
+      const R2Geo g2 = r2_geo(d, d.C2);
       EpiMaskB2 e2{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
       if ((rc = launch_wcast(p->w3, d.C2, d.C2, d.C3, 1, wt, st, Kp))) return rc;
       if ((rc = launch_rows2<BGradH3, EpiMaskB2>(a, wt, Kp, d.C2, g2, e2, st))) return rc;

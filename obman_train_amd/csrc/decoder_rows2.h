@@ -11,16 +11,21 @@
 //   * a persistent block (one per CU) copies its 128-column slice of the bf16 weight image into LDS ONCE ([col][k], pitch
 //     Kp + 8 elements: conflict-free ds_read_b128 fragments) and then walks over row tiles; 257 = 2 x 128 + 1 and
 //     515 = 4 x 128 + 3: the last column group carries its 1 .. 3 leftover columns as VALU side products (no padding tile);
-//   * a wave owns 64 rows (two 32-row MFMA fragments) x 128 columns (4 tiles): 128 accumulator registers.  Its A fragments
-//     are GENERATED IN REGISTERS in exactly the MFMA operand layout: lane (row = lane & 31, half = lane >> 5) loads the 8
+//   * a wave owns 32 rows (one MFMA fragment) x 128 columns (4 tiles): 64 accumulator registers.  Its A fragment is
+//     GENERATED IN REGISTERS in exactly the MFMA operand layout: lane (row = lane & 31, half = lane >> 5) loads the 8
 //     consecutive k of its row with 16-byte loads (the same "one row, 8 k" unit the B* generators already work in), applies
-//     the fused BatchNorm / ReLU / BatchNorm-backward transform and packs to bf16 - no LDS write, no LDS read, no barrier;
+//     the fused BatchNorm / ReLU / BatchNorm-backward transform and packs to bf16 - no LDS write, no LDS read, no barrier.
+//     (First version: two fragments = 128 accumulators per wave.  Parity-green but SLOWER than the kernels it replaced: with
+//     the register file full the compiler spilled around every tile and, because scratch traffic shares the vmcnt counter, waited
+//     vmcnt(0) at every k-step - one or two 1 KB requests in flight per wave, 65 % of the wave cycles in s_waitcnt, 2.1 TB/s
+//     (PMC: gpurun_out/r03g_pmc_dec_rows2.txt, profiles/r03_kernels.md).  Bandwidth = bytes in flight / latency: one fragment
+//     leaves room for an 8-deep request queue and no spills.)
 //   * the k-loop has NO barrier at all: the 8 waves of a block drift freely, one wave's loads and VALU transform overlap the
 //     other wave's MFMAs on the same SIMD (2 waves per SIMD);
 //   * BatchNorm statistics are accumulated per lane across ALL row tiles a wave processes (fp32 inside a tile, fp64 across
 //     tiles) and leave the block once, at the end (one cross-wave reduction per block instead of one per 128 rows).
-// A wave tile is 1 sample x 64 consecutive template vertices (the 8 waves of a block = 8 samples over the SAME vertices, so
-// the layer-1 grid factor rows are shared through L1 / L2), or - for the dA(gy1) GEMM - 4 samples x 16 vertices.
+// A wave tile is 1 sample x 32 consecutive template vertices (the 8 waves of a block = 8 samples over the SAME vertices, so
+// the layer-1 grid factor rows are shared through L1 / L2).
 #pragma once
 
 constexpr int R2_NT = 4;               // 32-column MFMA tiles per wave
@@ -33,120 +38,26 @@ inline int kpad16(int K) { return (K + 15) / 16 * 16; }  // k extent of the weig
 
 struct R2Geo {
   int R, N, B;
-  int mode;     // 0: wave tile = 1 sample x 64 vertices (block = 8 samples); 1: 4 samples x 16 vertices (block = 32 samples)
-  int nvt, nbg; // vertex tiles, sample groups
+  int nvt, nbg; // vertex tiles (32 vertices), sample groups (8 samples)
   int ngroups;  // column groups of R2_COLS
   int slots;    // persistent blocks per column group = spb * nbg
   int spb;      // slots per sample group
   int chunk;    // vertex tiles per slot
-  // row i (0..31) of fragment f of wave `wave` in block tile (bg, vt)
-  __device__ __forceinline__ void row(int bg, int vt, int wave, int f, int i, int& b, int& n, long& r, bool& ok) const {
-    if (mode == 0) {
-      b = bg * 8 + wave;
-      n = vt * 64 + f * 32 + i;
-    } else {
-      b = bg * 32 + wave * 4 + f * 2 + (i >> 4);
-      n = vt * 16 + (i & 15);
-    }
+  // row i (0..31) of the fragment of wave `wave` in block tile (bg, vt): sample bg*8 + wave, vertex vt*32 + i
+  __device__ __forceinline__ void row(int bg, int vt, int wave, int i, int& b, int& n, long& r, bool& ok) const {
+    b = bg * 8 + wave;
+    n = vt * 32 + i;
     ok = b < B && n < N;
     if (!ok) { b = 0; n = 0; }
     r = (long)b * N + n;
   }
 };
 
-// ------------------------------------------------------------------------------------------------ operand pairs
-// Two fragments (rows r0, r1 of one lane) through an existing operand generator; BGridFeat shares the sample's Fx chunk.
-template <class AOp>
-struct R2Pair {
-  struct Raw2 { typename AOp::Raw a, b; };
-  static __device__ __forceinline__ void load(const AOp& op, Raw2& q, const typename AOp::Row& r0, const typename AOp::Row& r1, int k) {
-    op.load(q.a, r0, k);
-    op.load(q.b, r1, k);
-  }
-  static __device__ __forceinline__ void fin(const AOp& op, const typename AOp::Row& r0, const typename AOp::Row& r1, const float* kcs, int Kp,
-                                             int k, const Raw2& q, float* o0, float* o1) {
-    op.fin(r0, kcs, Kp, k, q.a, o0);
-    op.fin(r1, kcs, Kp, k, q.b, o1);
-  }
-};
-template <>
-struct R2Pair<BGridFeat> {  // mode 0: both fragments belong to ONE sample -> one Fx chunk for both
-  struct Raw2 { float4 g0, g1, h0, h1, f0, f1; };
-  static __device__ __forceinline__ void load(const BGridFeat& op, Raw2& q, const BGridFeat::Row& r0, const BGridFeat::Row& r1, int k) {
-    const int c = k <= op.ld - 8 ? k : op.ld - 8;
-    q.g0 = *reinterpret_cast<const float4*>(r0.g + c); q.g1 = *reinterpret_cast<const float4*>(r0.g + c + 4);
-    q.h0 = *reinterpret_cast<const float4*>(r1.g + c); q.h1 = *reinterpret_cast<const float4*>(r1.g + c + 4);
-    q.f0 = *reinterpret_cast<const float4*>(r0.f + c); q.f1 = *reinterpret_cast<const float4*>(r0.f + c + 4);
-  }
-  static __device__ __forceinline__ void fin(const BGridFeat&, const BGridFeat::Row&, const BGridFeat::Row&, const float* kcs, int Kp, int k,
-                                             const Raw2& q, float* o0, float* o1) {
-    const float4 ga0 = *reinterpret_cast<const float4*>(kcs + k), ga1 = *reinterpret_cast<const float4*>(kcs + k + 4);
-    const float4 be0 = *reinterpret_cast<const float4*>(kcs + Kp + k), be1 = *reinterpret_cast<const float4*>(kcs + Kp + k + 4);
-    const float ga[8] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w};
-    const float be[8] = {be0.x, be0.y, be0.z, be0.w, be1.x, be1.y, be1.z, be1.w};
-    const float fx[8] = {q.f0.x, q.f0.y, q.f0.z, q.f0.w, q.f1.x, q.f1.y, q.f1.z, q.f1.w};
-    const float x0[8] = {q.g0.x, q.g0.y, q.g0.z, q.g0.w, q.g1.x, q.g1.y, q.g1.z, q.g1.w};
-    const float x1[8] = {q.h0.x, q.h0.y, q.h0.z, q.h0.w, q.h1.x, q.h1.y, q.h1.z, q.h1.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      o0[j] = fmaxf(__fmaf_rn(ga[j], x0[j] + fx[j], be[j]), 0.f);
-      o1[j] = fmaxf(__fmaf_rn(ga[j], x1[j] + fx[j], be[j]), 0.f);
-    }
-  }
-};
-
-// the per-channel constants are the same for both fragments (same k): read them from LDS once
-template <>
-struct R2Pair<BBnRelu> {
-  struct Raw2 { u32x4 a, b; };
-  static __device__ __forceinline__ void load(const BBnRelu& op, Raw2& q, const BBnRelu::Row& r0, const BBnRelu::Row& r1, int k) {
-    const int c = k <= op.ld - 8 ? k : op.ld - 8;
-    q.a = *reinterpret_cast<const u32x4*>(r0.p + c);
-    q.b = *reinterpret_cast<const u32x4*>(r1.p + c);
-  }
-  static __device__ __forceinline__ void fin(const BBnRelu&, const BBnRelu::Row&, const BBnRelu::Row&, const float* kcs, int Kp, int k,
-                                             const Raw2& q, float* o0, float* o1) {
-    const float4 s0 = *reinterpret_cast<const float4*>(kcs + k), s1 = *reinterpret_cast<const float4*>(kcs + k + 4);
-    const float4 t0 = *reinterpret_cast<const float4*>(kcs + Kp + k), t1 = *reinterpret_cast<const float4*>(kcs + Kp + k + 4);
-    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float tc[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-    float ha[8], hb[8];
-    unpack8(q.a, ha);
-    unpack8(q.b, hb);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      o0[j] = fmaxf(__fmaf_rn(sc[j], ha[j], tc[j]), 0.f);
-      o1[j] = fmaxf(__fmaf_rn(sc[j], hb[j], tc[j]), 0.f);
-    }
-  }
-};
-template <>
-struct R2Pair<BGradH3> {
-  struct Raw2 { u32x4 a, b; };
-  static __device__ __forceinline__ void load(const BGradH3& op, Raw2& q, const BGradH3::Row& r0, const BGradH3::Row& r1, int k) {
-    const int c = k <= op.ld - 8 ? k : op.ld - 8;
-    q.a = *reinterpret_cast<const u32x4*>(r0.p + c);
-    q.b = *reinterpret_cast<const u32x4*>(r1.p + c);
-  }
-  static __device__ __forceinline__ void fin(const BGradH3&, const BGradH3::Row& r0, const BGradH3::Row& r1, const float* kcs, int, int k,
-                                             const Raw2& q, float* o0, float* o1) {
-    float ha[8], hb[8];
-    unpack8(q.a, ha);
-    unpack8(q.b, hb);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float4 c0 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8);      // s, t, kb, kc
-      const float4 c1 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8 + 4);  // ka*w0, ka*w1, ka*w2
-      // select instead of branch: the dot product is three FMAs, cheaper than a divergent skip
-      const float da = __fmaf_rn(r0.g2, c1.z, __fmaf_rn(r0.g1, c1.y, r0.g0 * c1.x));
-      const float db = __fmaf_rn(r1.g2, c1.z, __fmaf_rn(r1.g1, c1.y, r1.g0 * c1.x));
-      const float ga = __fmaf_rn(c0.x, ha[j], c0.y) > 0.f ? da : 0.f;
-      const float gb = __fmaf_rn(c0.x, hb[j], c0.y) > 0.f ? db : 0.f;
-      o0[j] = ga + __fmaf_rn(c0.z, ha[j], c0.w);
-      o1[j] = gb + __fmaf_rn(c0.z, hb[j], c0.w);
-    }
-  }
-};
+// request-queue depth per operand generator (k-steps in flight per wave): 16 registers per step for the fp32 layer-1 factors,
+// 4 / 8 for the bf16-stored activations
+template <class AOp> struct R2Depth { static constexpr int value = 8; };
+template <> struct R2Depth<BGridFeat> { static constexpr int value = 4; };
+template <> struct R2Depth<BGradH> { static constexpr int value = 6; };
 
 // ------------------------------------------------------------------------------------------------ epilogues
 struct R2Ctx {
@@ -218,7 +129,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
 #pragma unroll
     for (int t = 0; t < R2_SIDE; ++t) { s.e1[t] = 0.f; s.e2[t] = 0.f; }
   }
-  __device__ __forceinline__ void tile(State& s, const f32x16 (&acc)[2][R2_NT], const float (&side)[2][R2_SIDE], const R2Ctx& c,
+  __device__ __forceinline__ void tile(State& s, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c,
                                        const R2Geo& geo) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     const bool odd = c.lane & 1;
@@ -231,13 +142,12 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
     float s1[R2_NT], s2[R2_NT];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    {
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int i0 = acc_row(2 * p, c.lane);
         int b, n; long r0; bool ok0;
-        geo.row(c.bg, c.vt, c.wave, f, i0, b, n, r0, ok0);
+        geo.row(c.bg, c.vt, c.wave, i0, b, n, r0, ok0);
         const bool ok1 = ok0 && n + 1 < geo.N;  // row i0 + 1: the next vertex of the same sample
         bfraw* dst = C + (size_t)(odd ? r0 + 1 : r0) * ldc;
         const bool okw = odd ? ok1 : ok0;
@@ -245,7 +155,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
         for (int j = 0; j < R2_NT; ++j) {
           const int cl = c.c0 + j * 32 + li;
           const bool cok = cl < Nc;
-          const unsigned pk = pack_bf16(cok ? acc[f][j][2 * p] + bv[j] : 0.f, cok ? acc[f][j][2 * p + 1] + bv[j] : 0.f);
+          const unsigned pk = pack_bf16(cok ? acc[j][2 * p] + bv[j] : 0.f, cok ? acc[j][2 * p + 1] + bv[j] : 0.f);
           const float v0 = ok0 ? bf_lo(pk) : 0.f, v1 = ok1 ? bf_hi(pk) : 0.f;
           s1[j] += v0 + v1;
           s2[j] = __fmaf_rn(v0, v0, __fmaf_rn(v1, v1, s2[j]));
@@ -256,13 +166,13 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
       // side columns and the pitch padding behind the last real column: one row per lane (half 0 / half 1)
       if (c.last_group) {
         int b, n; long r; bool ok;
-        geo.row(c.bg, c.vt, c.wave, f, li, b, n, r, ok);
+        geo.row(c.bg, c.vt, c.wave, li, b, n, r, ok);
         if (ok && h == 0) {
 #pragma unroll
           for (int t = 0; t < R2_SIDE; ++t) {
             if (t < c.nside) {
               const int col = c.c0 + R2_COLS + t;
-              const unsigned pk = pack_bf16(side[f][t] + (bias ? bias[col] : 0.f), 0.f);
+              const unsigned pk = pack_bf16(side[t] + (bias ? bias[col] : 0.f), 0.f);
               C[(size_t)r * ldc + col] = (bfraw)(pk & 0xffffu);
               const float v = bf_lo(pk);
               s.e1[t] += v;
@@ -299,7 +209,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
 #pragma unroll
     for (int u = 0; u < R2_SIDE; ++u) { q.e1[u] = 0.f; q.e2[u] = 0.f; }
   }
-  __device__ __forceinline__ void tile(State& q, const f32x16 (&acc)[2][R2_NT], const float (&side)[2][R2_SIDE], const R2Ctx& c,
+  __device__ __forceinline__ void tile(State& q, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c,
                                        const R2Geo& geo) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     const bool odd = c.lane & 1;
@@ -314,13 +224,12 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
     float p1[R2_NT], p2[R2_NT];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { p1[j] = 0.f; p2[j] = 0.f; }
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    {
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int i0 = acc_row(2 * p, c.lane);
         int b, n; long r0; bool ok0;
-        geo.row(c.bg, c.vt, c.wave, f, i0, b, n, r0, ok0);
+        geo.row(c.bg, c.vt, c.wave, i0, b, n, r0, ok0);
         const bool ok1 = ok0 && n + 1 < geo.N;
         const size_t ro = (size_t)(odd ? r0 + 1 : r0) * ldc;
         const bool okw = odd ? ok1 : ok0;
@@ -336,8 +245,8 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
           const bool cok = cl < Nc;
           float h0, h1;
           pair_unexchange(hw[j], odd, h0, h1);
-          const float g0 = (cok && ok0 && __fmaf_rn(cs[j], h0, ct[j]) > 0.f) ? acc[f][j][2 * p] : 0.f;
-          const float g1 = (cok && ok1 && __fmaf_rn(cs[j], h1, ct[j]) > 0.f) ? acc[f][j][2 * p + 1] : 0.f;
+          const float g0 = (cok && ok0 && __fmaf_rn(cs[j], h0, ct[j]) > 0.f) ? acc[j][2 * p] : 0.f;
+          const float g1 = (cok && ok1 && __fmaf_rn(cs[j], h1, ct[j]) > 0.f) ? acc[j][2 * p + 1] : 0.f;
           const unsigned pk = pack_bf16(g0, g1);
           const float v0 = bf_lo(pk), v1 = bf_hi(pk);
           p1[j] += v0 + v1;
@@ -348,7 +257,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
       }
       if (c.last_group) {
         int b, n; long r; bool ok;
-        geo.row(c.bg, c.vt, c.wave, f, li, b, n, r, ok);
+        geo.row(c.bg, c.vt, c.wave, li, b, n, r, ok);
         if (ok && h == 0) {
 #pragma unroll
           for (int u = 0; u < R2_SIDE; ++u) {
@@ -356,7 +265,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
               const int col = c.c0 + R2_COLS + u;
               const size_t o = (size_t)r * ldc + col;
               const float hv = __uint_as_float((unsigned)H[o] << 16);
-              const float g = __fmaf_rn(s[col], hv, t[col]) > 0.f ? side[f][u] : 0.f;
+              const float g = __fmaf_rn(s[col], hv, t[col]) > 0.f ? side[u] : 0.f;
               const unsigned pk = pack_bf16(g, 0.f);
               C[o] = (bfraw)(pk & 0xffffu);
               const float v = bf_lo(pk);
@@ -385,7 +294,6 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
 template <class AOp, class Epi>
 __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, R2Geo geo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef R2Pair<AOp> P;
   const int KP2 = Kp + 8;
   bfraw* Ws = reinterpret_cast<bfraw*>(smem);
   float* kcs = reinterpret_cast<float*>(Ws + (size_t)(R2_COLS + R2_SIDE) * KP2);
@@ -417,77 +325,72 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
   ctx.bg = bg;
   for (int vt = vt_beg; vt < vt_end; ++vt) {
     ctx.vt = vt;
-    typename AOp::Row row0, row1;
-    bool ok0, ok1;
+    typename AOp::Row row;
+    bool ok;
     {
       int b, n; long r;
-      geo.row(bg, vt, wave, 0, li, b, n, r, ok0);
-      row0 = aop.row(r, b, n, ok0);
-      geo.row(bg, vt, wave, 1, li, b, n, r, ok1);
-      row1 = aop.row(r, b, n, ok1);
+      geo.row(bg, vt, wave, li, b, n, r, ok);
+      row = aop.row(r, b, n, ok);
     }
-    f32x16 acc[2][R2_NT];
+    f32x16 acc[R2_NT];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int j = 0; j < R2_NT; ++j)
 #pragma unroll
-      for (int j = 0; j < R2_NT; ++j)
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float side[R2_SIDE];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][j][r] = 0.f;
-    float side[2][R2_SIDE];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int t = 0; t < R2_SIDE; ++t) side[f][t] = 0.f;
+    for (int t = 0; t < R2_SIDE; ++t) side[t] = 0.f;
 
-    // One k-step = one 16-deep MFMA per (fragment, column tile).  The raw operand chunk of step s + 1 is requested as soon as
-    // step s has turned its own chunk into the packed fragments (single register set: 128 accumulators leave no room for a
-    // deeper queue); the 8 MFMAs of the step and the SIMD's other wave cover the round trip.  Requests past the last step are
-    // clamped re-reads that are never consumed, so the loop is branch-free.
-    typename P::Raw2 q;
-    P::load(aop, q, row0, row1, h * 8);
-    for (int s = 0; s < nks; ++s) {
-      u32x4 a0, a1;
+    // One k-step = one 16-deep MFMA per column tile.  Raw operand chunks are requested DQ k-steps ahead into a register queue
+    // with compile-time slots (the loop is unrolled by DQ); requests past the last step are clamped re-reads that are never
+    // consumed, so the loop body is branch-free and the compiler's counted vmcnt waits leave the younger requests in flight.
+    constexpr int DQ = R2Depth<AOp>::value;
+    typename AOp::Raw q[DQ];
+#pragma unroll
+    for (int u = 0; u < DQ; ++u) aop.load(q[u], row, u * 16 + h * 8);
+    auto step = [&](typename AOp::Raw& qs, int s) {
+      u32x4 a0;
       {
-        float o0[8], o1[8];
-        P::fin(aop, row0, row1, kcs, Kp, s * 16 + h * 8, q, o0, o1);
+        float o0[8];
+        aop.fin(row, kcs, Kp, s * 16 + h * 8, qs, o0);
         a0 = pack8(o0);
-        a1 = pack8(o1);
       }
-      P::load(aop, q, row0, row1, (s + 1) * 16 + h * 8);
-      if (!ok0) a0 = u32x4{0u, 0u, 0u, 0u};
-      if (!ok1) a1 = u32x4{0u, 0u, 0u, 0u};
-      const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0), fa1 = __builtin_bit_cast(bf16x8, a1);
+      aop.load(qs, row, (s + DQ) * 16 + h * 8);
+      if (!ok) a0 = u32x4{0u, 0u, 0u, 0u};
+      const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
 #pragma unroll
       for (int j = 0; j < R2_NT; ++j) {
         const bf16x8 fb = *reinterpret_cast<const bf16x8*>(wlane + (size_t)j * 32 * KP2 + s * 16);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[j], 0, 0, 0);
       }
       if (nside) {  // leftover columns of the last group on the VALU, from the SAME rounded operands the MFMAs consume
 #pragma unroll
         for (int t = 0; t < R2_SIDE; ++t) {
           if (t < nside) {
             const u32x4 wv = *reinterpret_cast<const u32x4*>(Ws + (size_t)(R2_COLS + t) * KP2 + s * 16 + h * 8);
-            float s0 = side[0][t], s1 = side[1][t];
+            float s0 = side[t];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const unsigned ww = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
               const unsigned w0 = e == 0 ? a0.x : (e == 1 ? a0.y : (e == 2 ? a0.z : a0.w));
-              const unsigned w1 = e == 0 ? a1.x : (e == 1 ? a1.y : (e == 2 ? a1.z : a1.w));
               s0 = __fmaf_rn(bf_hi(w0), bf_hi(ww), __fmaf_rn(bf_lo(w0), bf_lo(ww), s0));
-              s1 = __fmaf_rn(bf_hi(w1), bf_hi(ww), __fmaf_rn(bf_lo(w1), bf_lo(ww), s1));
             }
-            side[0][t] = s0;
-            side[1][t] = s1;
+            side[t] = s0;
           }
         }
       }
+    };
+    int s = 0;
+    for (; s + DQ <= nks; s += DQ) {
+#pragma unroll
+      for (int u = 0; u < DQ; ++u) step(q[u], s + u);
     }
+#pragma unroll
+    for (int u = 0; u < DQ; ++u)
+      if (s + u < nks) step(q[u], s + u);
     if (nside) {  // the two lane halves covered different k: combine
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int t = 0; t < R2_SIDE; ++t) side[f][t] += __shfl_xor(side[f][t], 32, 64);
+      for (int t = 0; t < R2_SIDE; ++t) side[t] += __shfl_xor(side[t], 32, 64);
     }
     epi.tile(est, acc, side, ctx, geo);
   }
