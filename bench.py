@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--dp-accumulate-in-place", action="store_true",
                     help="experiment: gradients accumulate into persistent bucket views (no pack copy, one add kernel per "
                          "parameter) instead of stolen gradients + one multi-tensor copy per bucket (the default)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a hipGraph (trainer.GraphedTrainStep): same kernels, one launch call per step; the live "
+                         "per-kernel Chamfer / decoder timings are not available in this mode (no events inside a graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget (all legs together)")
     ap.add_argument("--precondition-max", type=int, default=60,
@@ -393,7 +396,9 @@ def main():
         model.base_net.autocast_dtype = torch.bfloat16
     model.atlas_branch.decoder.mfma_dtype = args.decoder_dtype
     broadcast_parameters(model)
-    opt = make_optimizer(model, "adam", lr=1e-4)
+    if args.graph and use_dist:
+        raise SystemExit("--graph is a single-process mode (the data-parallel hooks issue collectives from Python)")
+    opt = make_optimizer(model, "adam", lr=1e-4, capturable=args.graph)
     buckets = GradientBuckets(model.parameters(), force=args.force_dist, exclude=model.unused_parameters(),
                               accumulate_in_place=args.dp_accumulate_in_place) if use_dist else None
     sample = make_batch(args.batch, dev, seed=rank, image_size=args.image_size)
@@ -401,6 +406,7 @@ def main():
     sample[TransQueries.images] = sample[TransQueries.images].contiguous(memory_format=torch.channels_last)
 
     trace = {"precondition": [], "warmup": [], "timed": []}
+    graphed = None
 
     def run_phase(name, n, sync_each=False):
         """n train steps; per step the host enqueue time and (from HIP events on the training stream) the GPU time."""
@@ -410,7 +416,7 @@ def main():
         last = None
         for i in range(n):
             h0 = time.perf_counter()
-            last = train_step(model, opt, sample, buckets)
+            last = graphed(sample) if graphed is not None else train_step(model, opt, sample, buckets)
             evs[i + 1].record()
             if sync_each:
                 evs[i + 1].synchronize()
@@ -439,10 +445,19 @@ def main():
         if settled:
             break
 
+    if args.graph:
+        from obman_train_amd.trainer import GraphedTrainStep
+
+        import gc
+
+        evs = _ = None  # noqa: F841 - nothing of the eager phase (events, the last step's outputs and their autograd nodes) stays referenced
+        gc.collect()
+        torch.cuda.synchronize()
+        graphed = GraphedTrainStep(model, opt, sample, warmup=2)
     evs, host, _ = run_phase("warmup", args.warmup)
     torch.cuda.synchronize()
     close_phase("warmup", evs, host)
-    _lib.prof_enable(True)
+    _lib.prof_enable(not args.graph)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -546,6 +561,8 @@ def main():
                        "deterministic_convs": bool(args.deterministic_convs)},
             "roofline": roof,
             "decoder_roofline": decoder,
+            "host_enqueue_ms": {"median": sorted(host)[len(host) // 2], "max": max(host), "hipgraph": bool(args.graph),
+                                "note": "host time per step inside the timed region (launch enqueue; the GPU runs asynchronously)"},
         }
         if use_dist:
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "launcher_world_size": world,

@@ -32,8 +32,20 @@ def thresh_ious(gt_dists, pred_dists, thresh):
     return torch.where(union != 0, inter / union.clamp(min=1), torch.zeros_like(union))
 
 
+_THRESH_CACHE = {}
+
+
+def _thresholds(threshs, dtype, device):
+    """The threshold vector on the device, uploaded once: a host->device copy per call would break hipGraph capture of the step."""
+    key = (tuple(threshs), dtype, str(device))
+    t = _THRESH_CACHE.get(key)
+    if t is None:
+        t = _THRESH_CACHE[key] = torch.tensor(list(threshs), dtype=dtype, device=device).view(-1, 1, 1)
+    return t
+
+
 def meshiou(gt_dists, pred_dists, threshs=(1, 2, 3, 4, 5, 6, 7, 8, 9, 10)):
-    th = torch.tensor(list(threshs), dtype=gt_dists.dtype, device=gt_dists.device).view(-1, 1, 1)
+    th = _thresholds(threshs, gt_dists.dtype, gt_dists.device)
     g, p = gt_dists.unsqueeze(0) <= th, pred_dists.unsqueeze(0) <= th
     inter, union = (g & p).sum(2).float(), (g | p).sum(2).float()
     ious = torch.where(union != 0, inter / union.clamp(min=1), torch.zeros_like(union))  # [T,B]

@@ -27,14 +27,66 @@ def read_losses(losses):
     return dict(zip(keys, flat))
 
 
-def make_optimizer(model, name="adam", lr=1e-4, momentum=0.9, weight_decay=0.0):
-    """traineval.py:104-127 (defaults nets3dopts.py:249-273)."""
+def make_optimizer(model, name="adam", lr=1e-4, momentum=0.9, weight_decay=0.0, capturable=False):
+    """traineval.py:104-127 (defaults nets3dopts.py:249-273).  ``capturable``: the step may be recorded into a hipGraph
+    (``GraphedTrainStep``): Adam keeps its step counters on the device and never reads them on the host."""
     params = [p for p in model.parameters() if p.requires_grad]
     if name == "adam":
         fused = all(p.is_cuda for p in params)  # one multi-tensor kernel instead of ~10 foreach launches per step
-        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
+        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused, capturable=bool(capturable and fused))
     if name == "rms":
         return torch.optim.RMSprop(params, lr=lr, weight_decay=weight_decay)
     if name == "sgd":
         return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
     raise ValueError(name)
+
+
+class GraphedTrainStep:
+    """One training step (forward -> zero_grad -> backward -> optimizer.step) recorded ONCE into a hipGraph and replayed.
+
+    Why: the step is ~1 000 kernel launches.  With fp32 convolutions the GPU needs 11 ms for them and the host 5 ms to enqueue
+    them, so the host is idle half of the time; with the bf16 encoder the GPU needs 5.9 ms and the same 5 ms of enqueue leave
+    no slack - and eight ranks of one node share the host's cores.  A replay is ONE launch call (~0.1 ms of host time).
+
+    What makes the step recordable: every kernel of ``csrc/`` is launched on the caller's stream through the C-ABI with no
+    hidden allocation or synchronisation; the model's forward has no device->host read (masked means, mesh IoU and the hand-side
+    split are device-side); BatchNorm counters are bumped on the device; Adam is created with ``capturable=True``
+    (``make_optimizer``).  MIOpen's solution search runs in the eager warm-up steps before the capture.
+
+    The batch SHAPE (and the non-tensor entries of the sample: sides, root) is fixed at capture; ``__call__`` copies a new
+    batch into the static input buffers and replays.  Outputs are static tensors overwritten by every replay (clone what must
+    survive).  Not for the data-parallel path: the bucket hooks issue collectives from Python.
+
+    ROCm 7.0 caveat (measured, tools/graph_probe.py): ``hipGraphInstantiate`` segfaults at the end of the capture while the
+    OUTPUTS of an earlier eager step (loss tensor, results dict - and through them their autograd nodes) are still referenced.
+    Drop them before constructing this object (``bench.py`` does); the constructor collects garbage first."""
+
+    def __init__(self, model, optimizer, sample, warmup=3):
+        import gc
+
+        gc.collect()
+        dev = next(model.parameters()).device
+        self.model, self.optimizer = model, optimizer
+        self.static = {k: (v.detach().to(dev).clone(memory_format=torch.preserve_format) if torch.is_tensor(v) else v)
+                       for k, v in sample.items()}
+        self._fixed = {k: v for k, v in sample.items() if not torch.is_tensor(v)}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # eager steps on the side stream: lazy initialisation, MIOpen find, allocator growth
+            for _ in range(max(int(warmup), 1)):
+                train_step(model, optimizer, self.static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.total, self.results, self.losses = train_step(model, optimizer, self.static)
+
+    def __call__(self, sample):
+        for k, v in sample.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+            elif self._fixed.get(k) != v:
+                raise ValueError("GraphedTrainStep: the non-tensor entry %r differs from the captured batch (%r != %r); "
+                                 "capture one graph per layout" % (k, v, self._fixed.get(k)))
+        self.graph.replay()
+        return self.total, self.results, self.losses

@@ -90,3 +90,46 @@ def test_result_dumps_and_pck_from_device_results(tmp_path):
     np.testing.assert_allclose(pck["auc"], auc, rtol=1e-4)
     np.testing.assert_allclose(pck["pck_curve"], curve, rtol=0, atol=1.0 / 84 + 1e-9)  # a joint may cross a threshold
     assert meters.average_meters["total_loss"].count == 2
+
+
+def test_graphed_train_step_replays_the_eager_step():
+    """trainer.GraphedTrainStep: the whole step (forward, zero_grad, backward, fused Adam) recorded into a hipGraph.  Replays on
+    new batches of the captured shape track the eager step on the same batches (the difference is MIOpen's run-to-run
+    round-off), the BatchNorm counters advance on the device, and a changed non-tensor entry of the sample is refused."""
+    import warnings
+
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.queries import BaseQueries
+    from obman_train_amd.synthetic import CONFIGS, make_batch
+    from obman_train_amd.trainer import GraphedTrainStep, make_optimizer, train_step
+
+    warnings.simplefilter("ignore")
+    dev = torch.device("cuda", 0)
+    batches = [make_batch(4, dev, seed=30 + i, image_size=64) for i in range(4)]
+
+    def run(graphed):
+        torch.manual_seed(0)
+        model = HandNet(**CONFIGS["c3p1"]).to(dev).train()
+        opt = make_optimizer(model, "adam", lr=1e-4, capturable=graphed)
+        if not graphed:
+            out = []
+            for _ in range(3):  # the graphed run spends 3 eager warm-up steps on batch 0 (the capture itself executes nothing)
+                train_step(model, opt, batches[0])
+            for b in batches:
+                out.append(float(train_step(model, opt, b)[0]))
+            return out, model
+        step = GraphedTrainStep(model, opt, batches[0], warmup=3)
+        out = [float(step(b)[0]) for b in batches]
+        with pytest.raises(ValueError):
+            step({**batches[0], BaseQueries.sides: ["right"] * 4})
+        return out, model
+
+    eager, m_e = run(False)
+    replay, m_g = run(True)
+    np.testing.assert_allclose(replay, eager, rtol=2e-3)
+    assert int(m_g.base_net.bn1.num_batches_tracked) == int(m_e.base_net.bn1.num_batches_tracked) == 7
+    for (k, a), (_, b) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        assert torch.isfinite(b).all(), k
+    w_e = dict(m_e.named_parameters())["mano_branch.pose_reg.weight"]
+    w_g = dict(m_g.named_parameters())["mano_branch.pose_reg.weight"]
+    assert float((w_e - w_g).abs().max()) <= 2e-2 * float(w_e.abs().max())  # seven Adam steps from the same start
