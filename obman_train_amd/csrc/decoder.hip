@@ -1587,8 +1587,11 @@ int tn_bf16_chunks(int M, int Nc, int N, int Bsz, int bn) {
 struct L1Geo { int S, tiles, groups; };
 L1Geo l1_geo(const Dims& d) {
   L1Geo g;
-  if (d.bf16) {  // EpiL1B: one partial P per group of 16 vertices, one partial Q per group of 8 samples
+  if (d.bf16) {  // EpiL1B: one partial P per group of 16 vertices, one partial Q per group of 8 samples; the rows2 dA kernel (EpiL1B2)
+    // writes one partial P per persistent block of a sample group (<= CU count, <= N / 4) and one partial Q per 64 samples
     g.S = 1; g.tiles = (d.N + 15) / 16; g.groups = (d.B + 7) / 8;
+    const int r2 = (d.N + 3) / 4 < 1024 ? (d.N + 3) / 4 : 1024;
+    if (g.tiles < r2) g.tiles = r2;
     return g;
   }
   g.groups = (d.B + L1_B - 1) / L1_B;
@@ -1756,11 +1759,11 @@ bool rows2_enabled() {
   static const int on = [] { const char* e = getenv("OBMAN_DEC_ROWS2"); return e ? atoi(e) : 1; }();  // A/B knob
   return on != 0;
 }
-R2Geo r2_geo(const Dims& d, int Nc) {
+R2Geo r2_geo(const Dims& d, int Nc, int mode = 0) {
   R2Geo g{};
-  g.R = (int)d.R; g.N = d.N; g.B = d.B;
-  g.nvt = (d.N + 31) / 32;
-  g.nbg = (d.B + 7) / 8;
+  g.R = (int)d.R; g.N = d.N; g.B = d.B; g.mode = mode;
+  g.nvt = mode == 0 ? (d.N + 31) / 32 : (d.N + 3) / 4;
+  g.nbg = mode == 0 ? (d.B + 7) / 8 : (d.B + 63) / 64;
   g.ngroups = Nc > R2_SIDE ? (Nc - R2_SIDE + R2_COLS - 1) / R2_COLS : 1;
   int target = device_cus() / g.ngroups;  // one block per CU (the weight slice takes most of a CU's LDS)
   if (target < 1) target = 1;
@@ -1773,7 +1776,7 @@ R2Geo r2_geo(const Dims& d, int Nc) {
 }
 template <class AOp, class Epi>
 int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, hipStream_t st) {
-  size_t lds = (size_t)(R2_COLS + R2_SIDE) * (Kp + 8) * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float);
+  size_t lds = (size_t)(R2_COLS + R2_SIDE) * (Kp + 8) * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float) + (size_t)Epi::LDS_FLOATS * sizeof(float);
   const size_t flush = (size_t)(R2_WAVES - 1) * (R2_NT + 1) * 32 * 2 * sizeof(double);  // the end-of-block reduction re-uses the slice
   if (lds < flush) lds = flush;
   static std::atomic<int> granted[MAX_DEVICES];
@@ -1916,19 +1919,30 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     if ((rc = launch_tn_bf16<TGridFeat, TGradH>(ta, tb, d.C1, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
   }
   const L1Geo lg = l1_geo(d);
+  int l1_prow = lg.tiles, l1_groups = lg.groups;
   {  // dA(gy1) with the (8 samples x 16 vertices) row tiling: P / Q partials straight from the accumulators
     BGradH a{GY2, H2, k1, k2, k3, d.ld2, d.C2};
     EpiL1B e{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
     const RowGeo tiled{(int)d.R, d.N, d.B, lg.tiles, 1};
     bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt2);
-    if ((rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st))) return rc;
-    if ((rc = launch_rows_bf16<BGradH, EpiL1B>(a, wt, d.C2, d.C1, tiled, e, st))) return rc;
+    if (rows2_enabled()) {
+      const int Kp = kpad16(d.C2);
+      const R2Geo g2 = r2_geo(d, d.C1, 1);
+      EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
+      if ((rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st, Kp))) return rc;
+      if ((rc = launch_rows2<BGradH, EpiL1B2>(a, wt, Kp, d.C1, g2, e2, st))) return rc;
+      l1_prow = g2.spb;
+      l1_groups = g2.nbg;
+    } else {
+      if ((rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st))) return rc;
+      if ((rc = launch_rows_bf16<BGradH, EpiL1B>(a, wt, d.C2, d.C1, tiled, e, st))) return rc;
+    }
   }
   {  // P[b,c] = sum over the vertex groups, Q[n,c] = sum over the sample groups (fixed order)
     const float* pp = ws2 + v.Pp;
-    int prow = lg.tiles;
+    int prow = l1_prow;
     if ((rc = pre_reduce<float>(pp, prow, d.B * d.ld1, ws2 + v.Ppre, st))) return rc;
-    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, lg.groups,
+    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, l1_groups,
                                                                                 ws2 + v.P, ws2 + v.Q);
     OBMAN_LAUNCH_CHECK();
   }

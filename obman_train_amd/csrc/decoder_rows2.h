@@ -38,15 +38,22 @@ inline int kpad16(int K) { return (K + 15) / 16 * 16; }  // k extent of the weig
 
 struct R2Geo {
   int R, N, B;
-  int nvt, nbg; // vertex tiles (32 vertices), sample groups (8 samples)
+  int mode;     // 0: wave = 1 sample x 32 vertices, block = 8 samples (h2, h3, gy2)
+                // 1: wave = 8 samples x 4 vertices, block = 64 samples over the SAME 4 vertices (dA: sums over samples stay in the block)
+  int nvt, nbg; // vertex tiles, sample groups
   int ngroups;  // column groups of R2_COLS
   int slots;    // persistent blocks per column group = spb * nbg
   int spb;      // slots per sample group
   int chunk;    // vertex tiles per slot
-  // row i (0..31) of the fragment of wave `wave` in block tile (bg, vt): sample bg*8 + wave, vertex vt*32 + i
+  // row i (0..31) of the fragment of wave `wave` in block tile (bg, vt)
   __device__ __forceinline__ void row(int bg, int vt, int wave, int i, int& b, int& n, long& r, bool& ok) const {
-    b = bg * 8 + wave;
-    n = vt * 32 + i;
+    if (mode == 0) {
+      b = bg * 8 + wave;
+      n = vt * 32 + i;
+    } else {
+      b = bg * 64 + wave * 8 + (i >> 2);
+      n = vt * 4 + (i & 3);
+    }
     ok = b < B && n < N;
     if (!ok) { b = 0; n = 0; }
     r = (long)b * N + n;
@@ -58,6 +65,124 @@ struct R2Geo {
 template <class AOp> struct R2Depth { static constexpr int value = 8; };
 template <> struct R2Depth<BGridFeat> { static constexpr int value = 4; };
 template <> struct R2Depth<BGradH> { static constexpr int value = 6; };
+
+// ------------------------------------------------------------------------------------------------ operand sources
+// The raw chunks of a lane's row are fetched with BUFFER loads: a wave-uniform 128-bit descriptor per source array, a 32-bit
+// per-lane byte offset fixed for the whole row tile (row start + the lane half's 8 k), and the k-step as the instruction's
+// SCALAR offset - no per-load 64-bit address arithmetic and no clamping on the VALU (the flat-load version spent ~16 of its
+// ~100 instructions per k-step on it).  Reads past the last k-step of a row land in the next row (finite values, never
+// consumed: only issued to keep the loop branch-free); reads past the end of the array return zeros (hardware bounds check).
+// The transforms are the B* generators' own fin().
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t r2_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0xfffffffcull ? 0xfffffffcull : bytes), 0x00020000);
+}
+__device__ __forceinline__ u32x4 r2_ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ float4 r2_f4(u32x4 v) { return __builtin_bit_cast(float4, v); }
+
+template <class AOp> struct R2Src;
+template <>
+struct R2Src<BGridFeat> {
+  __amdgpu_buffer_rsrc_t rg, rf;
+  struct Off { unsigned g, f; };
+  __device__ __forceinline__ void init(const BGridFeat& op, const R2Geo& geo) {
+    rg = r2_rsrc(op.Gx, (size_t)geo.N * op.ld * 4);
+    rf = r2_rsrc(op.Fx, (size_t)geo.B * op.ld * 4);
+  }
+  __device__ __forceinline__ Off off(const BGridFeat& op, long, int b, int n, int h) const {
+    return Off{(unsigned)(((size_t)n * op.ld + h * 8) * 4), (unsigned)(((size_t)b * op.ld + h * 8) * 4)};
+  }
+  __device__ __forceinline__ void load(BGridFeat::Raw& q, const Off& o, int s) const {
+    q.g0 = r2_f4(r2_ld16(rg, o.g, s * 64)); q.g1 = r2_f4(r2_ld16(rg, o.g + 16, s * 64));
+    q.f0 = r2_f4(r2_ld16(rf, o.f, s * 64)); q.f1 = r2_f4(r2_ld16(rf, o.f + 16, s * 64));
+  }
+};
+template <>
+struct R2Src<BBnRelu> {
+  __amdgpu_buffer_rsrc_t rh;
+  struct Off { unsigned h; };
+  __device__ __forceinline__ void init(const BBnRelu& op, const R2Geo& geo) { rh = r2_rsrc(op.H, (size_t)geo.R * op.ld * 2); }
+  __device__ __forceinline__ Off off(const BBnRelu& op, long r, int, int, int h) const { return Off{(unsigned)(((size_t)r * op.ld + h * 8) * 2)}; }
+  __device__ __forceinline__ void load(BBnRelu::Raw& q, const Off& o, int s) const { q.h = r2_ld16(rh, o.h, s * 32); }
+};
+template <>
+struct R2Src<BGradH3> {
+  __amdgpu_buffer_rsrc_t rh;
+  struct Off { unsigned h; };
+  __device__ __forceinline__ void init(const BGradH3& op, const R2Geo& geo) { rh = r2_rsrc(op.H, (size_t)geo.R * op.ld * 2); }
+  __device__ __forceinline__ Off off(const BGradH3& op, long r, int, int, int h) const { return Off{(unsigned)(((size_t)r * op.ld + h * 8) * 2)}; }
+  __device__ __forceinline__ void load(BGradH3::Raw& q, const Off& o, int s) const { q.h = r2_ld16(rh, o.h, s * 32); }
+};
+template <>
+struct R2Src<BGradH> {
+  __amdgpu_buffer_rsrc_t rgy, rh;
+  struct Off { unsigned o; };
+  __device__ __forceinline__ void init(const BGradH& op, const R2Geo& geo) {
+    rgy = r2_rsrc(op.GY, (size_t)geo.R * op.ld * 2);
+    rh = r2_rsrc(op.H, (size_t)geo.R * op.ld * 2);
+  }
+  __device__ __forceinline__ Off off(const BGradH& op, long r, int, int, int h) const { return Off{(unsigned)(((size_t)r * op.ld + h * 8) * 2)}; }
+  __device__ __forceinline__ void load(BGradH::Raw& q, const Off& o, int s) const {
+    q.gy = r2_ld16(rgy, o.o, s * 32);
+    q.h = r2_ld16(rh, o.o, s * 32);
+  }
+};
+
+// transforms: the generators' own fin(), with the per-channel constants read from LDS as whole 16-byte vectors up front (the
+// element-indexed form compiled to eight dependent ds_read2_b32 + wait pairs per k-step)
+template <class AOp>
+struct R2Fin {
+  static __device__ __forceinline__ void fin(const AOp& op, const typename AOp::Row& row, const float* kcs, int Kp, int k,
+                                             const typename AOp::Raw& q, float* o) {
+    op.fin(row, kcs, Kp, k, q, o);
+  }
+};
+template <>
+struct R2Fin<BBnRelu> {
+  static __device__ __forceinline__ void fin(const BBnRelu&, const BBnRelu::Row&, const float* kcs, int Kp, int k, const BBnRelu::Raw& q, float* o) {
+    const float4 s0 = *reinterpret_cast<const float4*>(kcs + k), s1 = *reinterpret_cast<const float4*>(kcs + k + 4);
+    const float4 t0 = *reinterpret_cast<const float4*>(kcs + Kp + k), t1 = *reinterpret_cast<const float4*>(kcs + Kp + k + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float tc[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    float h[8];
+    unpack8(q.h, h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fmaxf(__fmaf_rn(sc[j], h[j], tc[j]), 0.f);
+  }
+};
+template <>
+struct R2Fin<BGradH> {
+  static __device__ __forceinline__ void fin(const BGradH&, const BGradH::Row&, const float* kcs, int Kp, int k, const BGradH::Raw& q, float* o) {
+    const float4 a0 = *reinterpret_cast<const float4*>(kcs + k), a1 = *reinterpret_cast<const float4*>(kcs + k + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(kcs + Kp + k), b1 = *reinterpret_cast<const float4*>(kcs + Kp + k + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(kcs + 2 * Kp + k), c1 = *reinterpret_cast<const float4*>(kcs + 2 * Kp + k + 4);
+    const float ka[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float kb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float kc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    float gy[8], h[8];
+    unpack8(q.gy, gy);
+    unpack8(q.h, h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = __fmaf_rn(ka[j], gy[j], __fmaf_rn(kb[j], h[j], kc[j]));
+  }
+};
+template <>
+struct R2Fin<BGradH3> {
+  static __device__ __forceinline__ void fin(const BGradH3&, const BGradH3::Row& w, const float* kcs, int, int k, const BGradH3::Raw& q, float* o) {
+    float h[8];
+    unpack8(q.h, h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 c0 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8);      // s, t, kb, kc
+      const float4 c1 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8 + 4);  // ka*w0, ka*w1, ka*w2
+      // select instead of a divergent skip: the dot product is three FMAs
+      const float d = __fmaf_rn(w.g2, c1.z, __fmaf_rn(w.g1, c1.y, w.g0 * c1.x));
+      const float gy = __fmaf_rn(c0.x, h[j], c0.y) > 0.f ? d : 0.f;
+      o[j] = gy + __fmaf_rn(c0.z, h[j], c0.w);
+    }
+  }
+};
 
 // ------------------------------------------------------------------------------------------------ epilogues
 struct R2Ctx {
@@ -115,6 +240,7 @@ __device__ __forceinline__ void r2_flush_cols(double (&d1)[R2_NT], double (&d2)[
 }
 
 struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, sum of squares of the STORED values) per slot
+  static constexpr int LDS_FLOATS = 0;
   bfraw* C;
   const float* bias;
   double* moments;  // [slots][Nc][2] or null
@@ -130,7 +256,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
     for (int t = 0; t < R2_SIDE; ++t) { s.e1[t] = 0.f; s.e2[t] = 0.f; }
   }
   __device__ __forceinline__ void tile(State& s, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c,
-                                       const R2Geo& geo) const {
+                                       const R2Geo& geo, float*) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     const bool odd = c.lane & 1;
     float bv[R2_NT];
@@ -194,6 +320,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
 };
 
 struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum C, S2 = sum C * xhat, xhat = (H - mean) * rstd
+  static constexpr int LDS_FLOATS = 0;
   bfraw* C;
   const bfraw* H;  // same pitch as C
   double* sums;    // [slots][Nc][2]
@@ -210,7 +337,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
     for (int u = 0; u < R2_SIDE; ++u) { q.e1[u] = 0.f; q.e2[u] = 0.f; }
   }
   __device__ __forceinline__ void tile(State& q, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c,
-                                       const R2Geo& geo) const {
+                                       const R2Geo& geo, float*) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     const bool odd = c.lane & 1;
     float cs[R2_NT], ct[R2_NT], cm[R2_NT], cr[R2_NT];
@@ -287,6 +414,128 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
   }
 };
 
+// dA(gy1) without gy1 (geometry mode 1).  gy1 = acc * (y1 > 0), y1 = gamma * (Gx[n] + Fx[b]) + beta; layer 1 only needs
+//   P[b,c] = sum_n gy1   and   Q[n,c] = sum_b gy1.
+// Accumulator register r of lane (li, h): vertex v = r & 3, sample h + 2 (r >> 2) of the wave's eight.
+//   P: the sum over a tile's 4 vertices is in-lane (r & 3); it keeps accumulating IN REGISTERS over all vertex tiles of the
+//      block's range and leaves once per block:  Pp[slot of the sample group][b][c].
+//   Q: the sum over the wave's 8 samples is in-lane (r >> 2) plus one exchange with the other lane half; the 8 waves of the
+//      block (= all 64 samples of the group) meet in a double-buffered LDS array, one barrier per tile, and 512 threads add the
+//      eight partials in wave order:  Qp[sample group][n][c].
+// Leftover (side) columns of the last column group: one row per lane; their vertex / sample sums go through lane exchanges.
+struct EpiL1B2 {
+  float *Pp, *Qp;  // [spb][B][ld], [nbg][N][ld]
+  const float *Gx, *Fx, *gamma, *beta;
+  int ld, Nc;
+  static constexpr int LDS_FLOATS = 2 * R2_WAVES * (R2_NT * 4 * 32 + R2_SIDE * 4);  // two buffers of per-wave Q partials
+  struct State {
+    float p[4][R2_NT];   // samples h, h+2, h+4, h+6 of the wave x column tiles
+    float ps[R2_SIDE];   // side columns: lanes (li % 4 == 0, h == 0) hold sample li >> 2
+    int parity;
+  };
+  __device__ __forceinline__ void init(State& s, const R2Ctx&) const {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j) s.p[m][j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < R2_SIDE; ++t) s.ps[t] = 0.f;
+    s.parity = 0;
+  }
+  __device__ __forceinline__ void tile(State& s, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c, const R2Geo& geo,
+                                       float* red) const {
+    const int li = c.lane & 31, h = c.lane >> 5;
+    float* buf = red + (size_t)s.parity * (LDS_FLOATS / 2);
+    const int b0 = c.bg * 64 + c.wave * 8, n0 = c.vt * 4;
+    float q[R2_NT][4];
+#pragma unroll
+    for (int j = 0; j < R2_NT; ++j) {
+      const int cl = c.c0 + j * 32 + li;
+      const bool cok = cl < Nc;
+      const int cc = cok ? cl : 0;
+      const float ga = cok ? gamma[cc] : 0.f, be = cok ? beta[cc] : 0.f;
+      float gx[4], fx[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gx[v] = (cok && n0 + v < geo.N) ? Gx[(size_t)(n0 + v) * ld + cc] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fx[m] = (cok && b0 + h + 2 * m < geo.B) ? Fx[(size_t)(b0 + h + 2 * m) * ld + cc] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) q[j][v] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int v = r & 3, m = r >> 2;
+        const bool live = cok && n0 + v < geo.N && b0 + h + 2 * m < geo.B;
+        const float g = (live && __fmaf_rn(ga, gx[v] + fx[m], be) > 0.f) ? acc[j][r] : 0.f;
+        q[j][v] += g;
+        s.p[m][j] += g;
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) q[j][v] += __shfl_xor(q[j][v], 32, 64);  // the other four samples of the wave
+      if (h == 0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) buf[((c.wave * R2_NT + j) * 4 + v) * 32 + li] = q[j][v];
+      }
+    }
+    float* sbuf = buf + R2_WAVES * R2_NT * 4 * 32;  // [wave][side column][vertex]
+    if (c.nside) {
+      const int v = li & 3, sm = li >> 2;  // this lane's row: vertex v of sample b0 + sm
+#pragma unroll
+      for (int t = 0; t < R2_SIDE; ++t) {
+        if (t < c.nside) {
+          const int col = c.c0 + R2_COLS + t;
+          const bool live = n0 + v < geo.N && b0 + sm < geo.B;
+          const float y = live ? __fmaf_rn(gamma[col], Gx[(size_t)(n0 + v) * ld + col] + Fx[(size_t)(b0 + sm) * ld + col], beta[col]) : 0.f;
+          const float g = (live && y > 0.f) ? side[t] : 0.f;
+          float pv = g + __shfl_xor(g, 1, 64);  // over the sample's 4 vertices
+          pv += __shfl_xor(pv, 2, 64);
+          s.ps[t] += pv;
+          float qs = g + __shfl_xor(g, 4, 64);  // over the wave's 8 samples
+          qs += __shfl_xor(qs, 8, 64);
+          qs += __shfl_xor(qs, 16, 64);
+          if (c.lane < 4) sbuf[(c.wave * R2_SIDE + t) * 4 + c.lane] = qs;
+        }
+      }
+    }
+    __syncthreads();  // one barrier per tile: the buffer written two tiles ago was consumed before the previous barrier
+    {
+      const int o = c.wave * 64 + c.lane;  // 512 outputs: (column tile, vertex, lane)
+      const int j = o >> 7, v = (o >> 5) & 3, l = o & 31;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < R2_WAVES; ++w) a += buf[((w * R2_NT + j) * 4 + v) * 32 + l];
+      const int col = c.c0 + j * 32 + l, n = n0 + v;
+      if (col < Nc && col < c.c0 + R2_COLS && n < geo.N) Qp[((size_t)c.bg * geo.N + n) * ld + col] = a;
+      if (o < c.nside * 4) {
+        const int t = o >> 2, vv = o & 3;
+        float e = 0.f;
+#pragma unroll
+        for (int w = 0; w < R2_WAVES; ++w) e += sbuf[(w * R2_SIDE + t) * 4 + vv];
+        if (n0 + vv < geo.N) Qp[((size_t)c.bg * geo.N + n0 + vv) * ld + c.c0 + R2_COLS + t] = e;
+      }
+    }
+    s.parity ^= 1;
+  }
+  __device__ __forceinline__ void flush(State& s, const R2Ctx& c, const R2Geo& geo, char*) const {
+    const int li = c.lane & 31, h = c.lane >> 5;
+    const int sq = c.slot % geo.spb;  // the block's slot inside its sample group = its partial's index
+    const int b0 = c.bg * 64 + c.wave * 8;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int b = b0 + h + 2 * m;
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j) {
+        const int col = c.c0 + j * 32 + li;
+        if (b < geo.B && col < Nc) Pp[((size_t)sq * geo.B + b) * ld + col] = s.p[m][j];
+      }
+    }
+    if (c.nside && h == 0 && (li & 3) == 0 && b0 + (li >> 2) < geo.B) {
+#pragma unroll
+      for (int t = 0; t < R2_SIDE; ++t)
+        if (t < c.nside) Pp[((size_t)sq * geo.B + b0 + (li >> 2)) * ld + c.c0 + R2_COLS + t] = s.ps[t];
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ the kernel
 // grid = ngroups * slots blocks (1-D, XCD-aware virtual ids: the column groups of one slot are neighbours on one XCD - they
 // stream the same activation rows).  Dynamic LDS: weight slice [(R2_COLS + R2_SIDE)][Kp + 8] bf16, then the generator's
@@ -297,6 +546,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
   const int KP2 = Kp + 8;
   bfraw* Ws = reinterpret_cast<bfraw*>(smem);
   float* kcs = reinterpret_cast<float*>(Ws + (size_t)(R2_COLS + R2_SIDE) * KP2);
+  float* red = kcs + (size_t)AOp::NC * Kp;  // Epi::LDS_FLOATS floats of epilogue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   const int vid = xcd_virtual_id(blockIdx.x, gridDim.x), cg = vid % geo.ngroups, slot = vid / geo.ngroups;
   const int c0 = cg * R2_COLS;
@@ -315,6 +565,8 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
   aop.stage(kcs, Kp, tid);
   __syncthreads();
 
+  R2Src<AOp> src;
+  src.init(aop, geo);
   R2Ctx ctx{lane, wave, c0, nside, last_group, slot, 0, 0};
   typename Epi::State est;
   epi.init(est, ctx);
@@ -326,11 +578,13 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
   for (int vt = vt_beg; vt < vt_end; ++vt) {
     ctx.vt = vt;
     typename AOp::Row row;
+    typename R2Src<AOp>::Off roff;
     bool ok;
     {
       int b, n; long r;
       geo.row(bg, vt, wave, li, b, n, r, ok);
       row = aop.row(r, b, n, ok);
+      roff = src.off(aop, r, b, n, h);
     }
     f32x16 acc[R2_NT];
 #pragma unroll
@@ -342,27 +596,33 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
     for (int t = 0; t < R2_SIDE; ++t) side[t] = 0.f;
 
     // One k-step = one 16-deep MFMA per column tile.  Raw operand chunks are requested DQ k-steps ahead into a register queue
-    // with compile-time slots (the loop is unrolled by DQ); requests past the last step are clamped re-reads that are never
-    // consumed, so the loop body is branch-free and the compiler's counted vmcnt waits leave the younger requests in flight.
+    // with compile-time slots (the loop is unrolled by DQ); requests past the last step are re-reads that are never consumed, so
+    // the loop body is branch-free and the compiler's counted vmcnt waits leave the younger requests in flight.
+    // (Measured and dropped: software-pipelining the loop inside the wave - next step's fragment reads and transform between
+    // this step's MFMAs via sched_group_barrier - was 4 .. 10 % SLOWER: the SIMD's other wave already fills those slots, and
+    // the second fragment set costs registers the request queue needs.)
     constexpr int DQ = R2Depth<AOp>::value;
     typename AOp::Raw q[DQ];
 #pragma unroll
-    for (int u = 0; u < DQ; ++u) aop.load(q[u], row, u * 16 + h * 8);
+    for (int u = 0; u < DQ; ++u) src.load(q[u], roff, u);
     auto step = [&](typename AOp::Raw& qs, int s) {
+      // the four weight fragments of this k-step first: the transform below covers their LDS latency (left to itself the
+      // compiler sank each read next to its MFMA: read -> wait -> MFMA, four exposed LDS round trips per k-step)
+      bf16x8 fb[R2_NT];
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)j * 32 * KP2 + s * 16);
+      __builtin_amdgcn_sched_barrier(0);
       u32x4 a0;
       {
         float o0[8];
-        aop.fin(row, kcs, Kp, s * 16 + h * 8, qs, o0);
+        R2Fin<AOp>::fin(aop, row, kcs, Kp, s * 16 + h * 8, qs, o0);
         a0 = pack8(o0);
       }
-      aop.load(qs, row, (s + DQ) * 16 + h * 8);
+      src.load(qs, roff, s + DQ);
       if (!ok) a0 = u32x4{0u, 0u, 0u, 0u};
       const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
 #pragma unroll
-      for (int j = 0; j < R2_NT; ++j) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(wlane + (size_t)j * 32 * KP2 + s * 16);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < R2_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[j], acc[j], 0, 0, 0);
       if (nside) {  // leftover columns of the last group on the VALU, from the SAME rounded operands the MFMAs consume
 #pragma unroll
         for (int t = 0; t < R2_SIDE; ++t) {
@@ -392,7 +652,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
 #pragma unroll
       for (int t = 0; t < R2_SIDE; ++t) side[t] += __shfl_xor(side[t], 32, 64);
     }
-    epi.tile(est, acc, side, ctx, geo);
+    epi.tile(est, acc, side, ctx, geo, red);
   }
   epi.flush(est, ctx, geo, smem);
 }
