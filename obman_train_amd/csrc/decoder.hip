@@ -1544,7 +1544,7 @@ constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gra
 
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
-  long Gx, Fx, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
+  long Gx, Fx, Gy, Fy, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
 };
 FwdWs fwd_ws(const Dims& d) {
   FwdWs w; long o = 0;
@@ -1557,6 +1557,8 @@ FwdWs fwd_ws(const Dims& d) {
   w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS_NARROW * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
   w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
   w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
+  w.Gy = take(d.bf16 ? (long)d.N * d.ld1 : 0);  // pre-scaled layer-1 factors of the bf16 forward (prescale_l1_kernel)
+  w.Fy = take(d.bf16 ? (long)d.B * d.ld1 : 0);
   w.total = o;
   return w;
 }
@@ -1744,6 +1746,19 @@ int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) 
   rows = segs;
   return 0;
 }
+// Gy[n,c] = gamma[c] * Gx[n,c],  Fy[b,c] = gamma[c] * Fx[b,c] + beta[c]  (pitch columns stay zero): relu(Gy + Fy) = a1
+__global__ __launch_bounds__(256) void prescale_l1_kernel(const float* __restrict__ Gx, const float* __restrict__ Fx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int N, int B, int ld, int C, float* __restrict__ Gy,
+                                                          float* __restrict__ Fy) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x, total = (long)(N + B) * ld;
+  if (i >= total) return;
+  const long row = i / ld;
+  const int c = (int)(i - row * ld);
+  const bool ok = c < C;
+  if (row < N) Gy[i] = ok ? gamma[c] * Gx[i] : 0.f;
+  else { const long j = i - (long)N * ld; Fy[j] = ok ? __fmaf_rn(gamma[c], Fx[j], beta[c]) : 0.f; }
+}
+
 // ---- second-generation rows GEMMs (decoder_rows2.h): persistent blocks, weights stationary in LDS
 int device_cus() {
   static std::atomic<int> cus[MAX_DEVICES];
@@ -1762,8 +1777,8 @@ bool rows2_enabled() {
 R2Geo r2_geo(const Dims& d, int Nc, int mode = 0) {
   R2Geo g{};
   g.R = (int)d.R; g.N = d.N; g.B = d.B; g.mode = mode;
-  g.nvt = mode == 0 ? (d.N + 31) / 32 : (d.N + 3) / 4;
-  g.nbg = mode == 0 ? (d.B + 7) / 8 : (d.B + 63) / 64;
+  g.nvt = mode == 1 ? (d.N + 3) / 4 : (d.N + 31) / 32;
+  g.nbg = mode == 1 ? (d.B + 63) / 64 : (d.B + 7) / 8;
   g.ngroups = Nc > R2_SIDE ? (Nc - R2_SIDE + R2_COLS - 1) / R2_COLS : 1;
   int target = device_cus() / g.ngroups;  // one block per CU (the weight slice takes most of a CU's LDS)
   if (target < 1) target = 1;
@@ -1776,7 +1791,8 @@ R2Geo r2_geo(const Dims& d, int Nc, int mode = 0) {
 }
 template <class AOp, class Epi>
 int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, hipStream_t st) {
-  size_t lds = (size_t)(R2_COLS + R2_SIDE) * (Kp + 8) * sizeof(bfraw) + (size_t)AOp::NC * Kp * sizeof(float) + (size_t)Epi::LDS_FLOATS * sizeof(float);
+  const int aop_floats = R2Lds<AOp>::floats(Kp);
+  size_t lds = (size_t)(R2_COLS + R2_SIDE) * (Kp + 8) * sizeof(bfraw) + (size_t)aop_floats * sizeof(float) + (size_t)Epi::LDS_FLOATS * sizeof(float);
   const size_t flush = (size_t)(R2_WAVES - 1) * (R2_NT + 1) * 32 * 2 * sizeof(double);  // the end-of-block reduction re-uses the slice
   if (lds < flush) lds = flush;
   static std::atomic<int> granted[MAX_DEVICES];
@@ -1786,7 +1802,7 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
     if (err != hipSuccess) return (int)err;
     granted[dev].store((int)lds, std::memory_order_relaxed);
   }
-  rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo);
+  rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, aop_floats);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -1810,10 +1826,17 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     int mrows;
     if (rows2_enabled()) {
       const int Kp = kpad16(d.C1);
-      const R2Geo g2 = r2_geo(d, d.C2);
+      // rows as (8 samples x 4 vertices) per wave: a load instruction touches 4 rows of the layer-1 grid factor and 8 of the
+      // feature factor instead of 32 + 1 (the fp32 factors go through the texture path 64 B per clock and CU),
+      // and the feature factor's 8 rows of the block live in LDS.  Factors pre-scaled by BatchNorm-1's gamma / beta: add + max per element
+      const R2Geo g2 = r2_geo(d, d.C2, 2);
       EpiStoreB2 e2{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
+      prescale_l1_kernel<<<obman_cdiv((long)(d.N + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
+                                                                                        d.C1, ws + w.Gy, ws + w.Fy);
+      OBMAN_LAUNCH_CHECK();
+      BGridFeatPre ap{ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st, Kp))) return rc;
-      if ((rc = launch_rows2<BGridFeat, EpiStoreB2>(a, wb, Kp, d.C2, g2, e2, st))) return rc;
+      if ((rc = launch_rows2<BGridFeatPre, EpiStoreB2>(ap, wb, Kp, d.C2, g2, e2, st))) return rc;
       mrows = g2.slots;
     } else {
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st))) return rc;

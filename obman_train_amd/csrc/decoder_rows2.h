@@ -40,6 +40,7 @@ struct R2Geo {
   int R, N, B;
   int mode;     // 0: wave = 1 sample x 32 vertices, block = 8 samples (h2, h3, gy2)
                 // 1: wave = 8 samples x 4 vertices, block = 64 samples over the SAME 4 vertices (dA: sums over samples stay in the block)
+                // 2: wave = 8 samples x 4 vertices, block = the SAME 8 samples over 32 vertices (h2: the block's 8 feature-factor rows sit in LDS)
   int nvt, nbg; // vertex tiles, sample groups
   int ngroups;  // column groups of R2_COLS
   int slots;    // persistent blocks per column group = spb * nbg
@@ -50,9 +51,12 @@ struct R2Geo {
     if (mode == 0) {
       b = bg * 8 + wave;
       n = vt * 32 + i;
-    } else {
+    } else if (mode == 1) {
       b = bg * 64 + wave * 8 + (i >> 2);
       n = vt * 4 + (i & 3);
+    } else {
+      b = bg * 8 + (i >> 2);
+      n = vt * 32 + wave * 4 + (i & 3);
     }
     ok = b < B && n < N;
     if (!ok) { b = 0; n = 0; }
@@ -60,11 +64,43 @@ struct R2Geo {
   }
 };
 
+// Layer-1 activation from PRE-SCALED factors (h2 only):  a1 = relu(Gy[n,k] + Fy[b,k]),  Gy = gamma * Gx,  Fy = gamma * Fx + beta
+// (prescale_l1_kernel).  Two VALU operations per element instead of three and no per-channel constants; with geometry mode 2 the
+// block's 8 rows of Fy sit in LDS for the block's whole life, so a k-step fetches 32 bytes per lane instead of 64.
+struct BGridFeatPre {
+  const float *Gy, *Fy;
+  int ld, K;
+  static constexpr int NC = 0;
+  static constexpr int FPITCH_PAD = 4;  // row pitch Kp + 4 floats: the 8 sample rows start 20 banks apart (conflict-free 16-byte reads)
+  struct Row { int sl; bool ok; };      // sample slot 0..7 inside the block
+  struct Raw { u32x4 g0, g1; };
+  __device__ Row row(long, int b, int, bool ok) const { return Row{b & 7, ok}; }
+};
+
 // request-queue depth per operand generator (k-steps in flight per wave): 16 registers per step for the fp32 layer-1 factors,
 // 4 / 8 for the bf16-stored activations
 template <class AOp> struct R2Depth { static constexpr int value = 8; };
 template <> struct R2Depth<BGridFeat> { static constexpr int value = 4; };
 template <> struct R2Depth<BGradH> { static constexpr int value = 6; };
+template <> struct R2Depth<BGridFeatPre> { static constexpr int value = 4; };
+
+// LDS floats an operand generator needs besides the weight slice (per-channel constants; the 8 Fy rows), and how it fills them
+template <class AOp> struct R2Lds {
+  static int floats(int Kp) { return AOp::NC * Kp; }
+  static __device__ __forceinline__ void stage(const AOp& op, float* kcs, int Kp, int tid, int, const R2Geo&) { op.stage(kcs, Kp, tid); }
+};
+template <> struct R2Lds<BGridFeatPre> {
+  static int floats(int Kp) { return 8 * (Kp + BGridFeatPre::FPITCH_PAD); }
+  static __device__ __forceinline__ void stage(const BGridFeatPre& op, float* kcs, int Kp, int tid, int bg, const R2Geo& geo) {
+    const int pitch = Kp + BGridFeatPre::FPITCH_PAD, chunks = Kp >> 2;
+    for (int i = tid; i < 8 * chunks; i += R2_THREADS) {
+      const int sl = i / chunks, c = (i - sl * chunks) * 4, b = bg * 8 + sl;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < geo.B && c + 4 <= op.ld) v = *reinterpret_cast<const float4*>(op.Fy + (size_t)b * op.ld + c);
+      *reinterpret_cast<float4*>(kcs + (size_t)sl * pitch + c) = v;
+    }
+  }
+};
 
 // ------------------------------------------------------------------------------------------------ operand sources
 // The raw chunks of a lane's row are fetched with BUFFER loads: a wave-uniform 128-bit descriptor per source array, a 32-bit
@@ -74,7 +110,12 @@ template <> struct R2Depth<BGradH> { static constexpr int value = 6; };
 // consumed: only issued to keep the loop branch-free); reads past the end of the array return zeros (hardware bounds check).
 // The transforms are the B* generators' own fin().
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t r2_rsrc(const void* p, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0xfffffffcull ? 0xfffffffcull : bytes), 0x00020000);
+  // uniformity made PROVABLE (readfirstlane on the inputs): under SGPR pressure hipcc parks the descriptor in VGPRs and then
+  // wraps every buffer load in a waterfall loop (~12 instructions and a serialisation point per load)
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xfffffffcull ? 0xfffffffcull : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)n, 0x00020000);
 }
 __device__ __forceinline__ u32x4 r2_ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
@@ -96,6 +137,17 @@ struct R2Src<BGridFeat> {
   __device__ __forceinline__ void load(BGridFeat::Raw& q, const Off& o, int s) const {
     q.g0 = r2_f4(r2_ld16(rg, o.g, s * 64)); q.g1 = r2_f4(r2_ld16(rg, o.g + 16, s * 64));
     q.f0 = r2_f4(r2_ld16(rf, o.f, s * 64)); q.f1 = r2_f4(r2_ld16(rf, o.f + 16, s * 64));
+  }
+};
+template <>
+struct R2Src<BGridFeatPre> {
+  __amdgpu_buffer_rsrc_t rg;
+  struct Off { unsigned g; };
+  __device__ __forceinline__ void init(const BGridFeatPre& op, const R2Geo& geo) { rg = r2_rsrc(op.Gy, (size_t)geo.N * op.ld * 4); }
+  __device__ __forceinline__ Off off(const BGridFeatPre& op, long, int, int n, int h) const { return Off{(unsigned)(((size_t)n * op.ld + h * 8) * 4)}; }
+  __device__ __forceinline__ void load(BGridFeatPre::Raw& q, const Off& o, int s) const {
+    q.g0 = r2_ld16(rg, o.g, s * 64);
+    q.g1 = r2_ld16(rg, o.g + 16, s * 64);
   }
 };
 template <>
@@ -136,6 +188,17 @@ struct R2Fin {
   static __device__ __forceinline__ void fin(const AOp& op, const typename AOp::Row& row, const float* kcs, int Kp, int k,
                                              const typename AOp::Raw& q, float* o) {
     op.fin(row, kcs, Kp, k, q, o);
+  }
+};
+template <>
+struct R2Fin<BGridFeatPre> {
+  static __device__ __forceinline__ void fin(const BGridFeatPre&, const BGridFeatPre::Row& w, const float* fy, int Kp, int k, const BGridFeatPre::Raw& q,
+                                             float* o) {
+    const float* f = fy + (size_t)w.sl * (Kp + BGridFeatPre::FPITCH_PAD) + k;
+    const float4 f0 = *reinterpret_cast<const float4*>(f), f1 = *reinterpret_cast<const float4*>(f + 4);
+    const float4 g0 = r2_f4(q.g0), g1 = r2_f4(q.g1);
+    o[0] = fmaxf(g0.x + f0.x, 0.f); o[1] = fmaxf(g0.y + f0.y, 0.f); o[2] = fmaxf(g0.z + f0.z, 0.f); o[3] = fmaxf(g0.w + f0.w, 0.f);
+    o[4] = fmaxf(g1.x + f1.x, 0.f); o[5] = fmaxf(g1.y + f1.y, 0.f); o[6] = fmaxf(g1.z + f1.z, 0.f); o[7] = fmaxf(g1.w + f1.w, 0.f);
   }
 };
 template <>
@@ -541,12 +604,13 @@ struct EpiL1B2 {
 // stream the same activation rows).  Dynamic LDS: weight slice [(R2_COLS + R2_SIDE)][Kp + 8] bf16, then the generator's
 // per-channel constants [AOp::NC][Kp] fp32.
 template <class AOp, class Epi>
-__global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, R2Geo geo) {
+__global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, R2Geo geo,
+                                                                 int lds_aop_floats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int KP2 = Kp + 8;
   bfraw* Ws = reinterpret_cast<bfraw*>(smem);
   float* kcs = reinterpret_cast<float*>(Ws + (size_t)(R2_COLS + R2_SIDE) * KP2);
-  float* red = kcs + (size_t)AOp::NC * Kp;  // Epi::LDS_FLOATS floats of epilogue scratch
+  float* red = kcs + lds_aop_floats;        // Epi::LDS_FLOATS floats of epilogue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   const int vid = xcd_virtual_id(blockIdx.x, gridDim.x), cg = vid % geo.ngroups, slot = vid / geo.ngroups;
   const int c0 = cg * R2_COLS;
@@ -562,7 +626,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
       *reinterpret_cast<u32x4*>(Ws + (size_t)cc * KP2 + q * 8) = v;
     }
   }
-  aop.stage(kcs, Kp, tid);
+  R2Lds<AOp>::stage(aop, kcs, Kp, tid, (vid / geo.ngroups) / geo.spb, geo);
   __syncthreads();
 
   R2Src<AOp> src;
@@ -628,13 +692,14 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
         for (int t = 0; t < R2_SIDE; ++t) {
           if (t < nside) {
             const u32x4 wv = *reinterpret_cast<const u32x4*>(Ws + (size_t)(R2_COLS + t) * KP2 + s * 16 + h * 8);
+            // v_dot2c_f32_bf16: two bf16 products accumulated in fp32 per instruction (4 per side column and k-step instead of
+            // 8 unpacks + 8 FMAs).  Inline asm: with __builtin_amdgcn_fdot2_f32_bf16 on components of the two u32x4 values this
+            // compiler (ROCm 7.2 clang) emitted all four instructions with the FIRST component's registers.
             float s0 = side[t];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const unsigned ww = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
-              const unsigned w0 = e == 0 ? a0.x : (e == 1 ? a0.y : (e == 2 ? a0.z : a0.w));
-              s0 = __fmaf_rn(bf_hi(w0), bf_hi(ww), __fmaf_rn(bf_lo(w0), bf_lo(ww), s0));
-            }
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.x), "v"(wv.x));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.y), "v"(wv.y));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.z), "v"(wv.z));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.w), "v"(wv.w));
             side[t] = s0;
           }
         }
