@@ -1557,7 +1557,7 @@ FwdWs fwd_ws(const Dims& d) {
   w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS_NARROW * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
   w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
   w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
-  w.Gy = take(d.bf16 ? (long)d.N * d.ld1 : 0);  // pre-scaled layer-1 factors of the bf16 forward (prescale_l1_kernel)
+  w.Gy = take(d.bf16 ? (long)(d.N + 1) * d.ld1 : 0);  // pre-scaled layer-1 factors of the bf16 forward (prescale_l1_kernel)
   w.Fy = take(d.bf16 ? (long)d.B * d.ld1 : 0);
   w.total = o;
   return w;
@@ -1750,13 +1750,14 @@ int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) 
 __global__ __launch_bounds__(256) void prescale_l1_kernel(const float* __restrict__ Gx, const float* __restrict__ Fx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int N, int B, int ld, int C, float* __restrict__ Gy,
                                                           float* __restrict__ Fy) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x, total = (long)(N + B) * ld;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x, total = (long)(N + 1 + B) * ld;
   if (i >= total) return;
   const long row = i / ld;
   const int c = (int)(i - row * ld);
   const bool ok = c < C;
   if (row < N) Gy[i] = ok ? gamma[c] * Gx[i] : 0.f;
-  else { const long j = i - (long)N * ld; Fy[j] = ok ? __fmaf_rn(gamma[c], Fx[j], beta[c]) : 0.f; }
+  else if (row == N) Gy[i] = -3.0e38f;  // the row that rows outside the problem read: relu(-3e38 + Fy) = 0 exactly
+  else { const long j = i - (long)(N + 1) * ld; Fy[j] = ok ? __fmaf_rn(gamma[c], Fx[j], beta[c]) : 0.f; }
 }
 
 // ---- second-generation rows GEMMs (decoder_rows2.h): persistent blocks, weights stationary in LDS
@@ -1802,6 +1803,26 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
     if (err != hipSuccess) return (int)err;
     granted[dev].store((int)lds, std::memory_order_relaxed);
   }
+  if constexpr (std::is_same<AOp, BGridFeatPre>::value) {
+    // measurement-only ablations of the k loop (wrong results; tools/r03_abl.sh): where does a k-step's time go?
+    static const int abl = [] { const char* v = getenv("OBMAN_R2_ABL"); return v ? atoi(v) : 0; }();
+    if (abl) {
+      const unsigned g = (unsigned)(geo.ngroups * geo.slots);
+      auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kern<<<g, R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, aop_floats);
+      };
+      switch (abl) {
+        case 1: go(rows2_bf16_kernel<AOp, Epi, 1>); break;
+        case 2: go(rows2_bf16_kernel<AOp, Epi, 2>); break;
+        case 3: go(rows2_bf16_kernel<AOp, Epi, 3>); break;
+        case 4: go(rows2_bf16_kernel<AOp, Epi, 4>); break;
+        default: go(rows2_bf16_kernel<AOp, Epi, 5>); break;
+      }
+      OBMAN_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, aop_floats);
   OBMAN_LAUNCH_CHECK();
   return 0;
@@ -1831,7 +1852,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
       // and the feature factor's 8 rows of the block live in LDS.  Factors pre-scaled by BatchNorm-1's gamma / beta: add + max per element
       const R2Geo g2 = r2_geo(d, d.C2, 2);
       EpiStoreB2 e2{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
-      prescale_l1_kernel<<<obman_cdiv((long)(d.N + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
+      prescale_l1_kernel<<<obman_cdiv((long)(d.N + 1 + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
                                                                                         d.C1, ws + w.Gy, ws + w.Fy);
       OBMAN_LAUNCH_CHECK();
       BGridFeatPre ap{ws + w.Gy, ws + w.Fy, d.ld1, d.C1};

@@ -71,6 +71,7 @@ struct BGridFeatPre {
   const float *Gy, *Fy;
   int ld, K;
   static constexpr int NC = 0;
+  static constexpr bool SENTINEL = true;  // rows outside the problem read Gy's row N (-3e38 everywhere): relu gives exact zeros, no select
   static constexpr int FPITCH_PAD = 4;  // row pitch Kp + 4 floats: the 8 sample rows start 20 banks apart (conflict-free 16-byte reads)
   struct Row { int sl; bool ok; };      // sample slot 0..7 inside the block
   struct Raw { u32x4 g0, g1; };
@@ -143,7 +144,7 @@ template <>
 struct R2Src<BGridFeatPre> {
   __amdgpu_buffer_rsrc_t rg;
   struct Off { unsigned g; };
-  __device__ __forceinline__ void init(const BGridFeatPre& op, const R2Geo& geo) { rg = r2_rsrc(op.Gy, (size_t)geo.N * op.ld * 4); }
+  __device__ __forceinline__ void init(const BGridFeatPre& op, const R2Geo& geo) { rg = r2_rsrc(op.Gy, (size_t)(geo.N + 1) * op.ld * 4); }
   __device__ __forceinline__ Off off(const BGridFeatPre& op, long, int, int n, int h) const { return Off{(unsigned)(((size_t)n * op.ld + h * 8) * 4)}; }
   __device__ __forceinline__ void load(BGridFeatPre::Raw& q, const Off& o, int s) const {
     q.g0 = r2_ld16(rg, o.g, s * 64);
@@ -190,8 +191,36 @@ struct R2Fin {
     op.fin(row, kcs, Kp, k, q, o);
   }
 };
+// does the generator produce the packed bf16 fragment itself (finp) / zero the rows outside the problem itself?
+template <class F, class = void> struct R2Packed { static constexpr bool value = false; };
+template <class F> struct R2Packed<F, std::enable_if_t<F::PACKED>> { static constexpr bool value = true; };
+template <class AOp, class = void> struct R2Sentinel { static constexpr bool value = false; };
+template <class AOp> struct R2Sentinel<AOp, std::enable_if_t<AOp::SENTINEL>> { static constexpr bool value = true; };
+typedef short s16x2v __attribute__((ext_vector_type(2)));
+// relu on a PACKED bf16 pair: as signed 16-bit integers every negative value (sign bit) is < 0 and every non-negative one is
+// >= 0 and unchanged by max(., 0) - one v_pk_max_i16 per two elements; rounding first and clamping second gives the same
+// bits as the other order (round-to-nearest keeps the sign)
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned w) {
+  const s16x2v z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2v, w), z));
+}
 template <>
 struct R2Fin<BGridFeatPre> {
+  // 4 v_pk_add_f32 + 4 v_cvt_pk_bf16_f32 + 4 v_pk_max_i16 per 8 elements (scalar form: 8 adds, 8 max, 4 converts)
+  static constexpr bool PACKED = true;
+  static __device__ __forceinline__ u32x4 finp(const BGridFeatPre&, const BGridFeatPre::Row& w, const float* fy, int Kp, int k, const BGridFeatPre::Raw& q) {
+    const float* f = fy + (size_t)w.sl * (Kp + BGridFeatPre::FPITCH_PAD) + k;
+    const float4 f0 = *reinterpret_cast<const float4*>(f), f1 = *reinterpret_cast<const float4*>(f + 4);
+    const float4 g0 = r2_f4(q.g0), g1 = r2_f4(q.g1);
+    const f32x2v s0 = f32x2v{g0.x, g0.y} + f32x2v{f0.x, f0.y}, s1 = f32x2v{g0.z, g0.w} + f32x2v{f0.z, f0.w};
+    const f32x2v s2 = f32x2v{g1.x, g1.y} + f32x2v{f1.x, f1.y}, s3 = f32x2v{g1.z, g1.w} + f32x2v{f1.z, f1.w};
+    u32x4 o;
+    o.x = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s0, bf16x2)));
+    o.y = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s1, bf16x2)));
+    o.z = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s2, bf16x2)));
+    o.w = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s3, bf16x2)));
+    return o;
+  }
   static __device__ __forceinline__ void fin(const BGridFeatPre&, const BGridFeatPre::Row& w, const float* fy, int Kp, int k, const BGridFeatPre::Raw& q,
                                              float* o) {
     const float* f = fy + (size_t)w.sl * (Kp + BGridFeatPre::FPITCH_PAD) + k;
@@ -213,6 +242,24 @@ struct R2Fin<BBnRelu> {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = fmaxf(__fmaf_rn(sc[j], h[j], tc[j]), 0.f);
   }
+  // packed: 4 v_pk_fma_f32 + 4 converts + 4 v_pk_max_i16 after the 8 unpacks (scalar: 8 FMAs, 8 max, 4 converts)
+  static constexpr bool PACKED = true;
+  static __device__ __forceinline__ u32x4 finp(const BBnRelu&, const BBnRelu::Row&, const float* kcs, int Kp, int k, const BBnRelu::Raw& q) {
+    const float4 s0 = *reinterpret_cast<const float4*>(kcs + k), s1 = *reinterpret_cast<const float4*>(kcs + k + 4);
+    const float4 t0 = *reinterpret_cast<const float4*>(kcs + Kp + k), t1 = *reinterpret_cast<const float4*>(kcs + Kp + k + 4);
+    float h[8];
+    unpack8(q.h, h);
+    const f32x2v y0 = __builtin_elementwise_fma(f32x2v{s0.x, s0.y}, f32x2v{h[0], h[1]}, f32x2v{t0.x, t0.y});
+    const f32x2v y1 = __builtin_elementwise_fma(f32x2v{s0.z, s0.w}, f32x2v{h[2], h[3]}, f32x2v{t0.z, t0.w});
+    const f32x2v y2 = __builtin_elementwise_fma(f32x2v{s1.x, s1.y}, f32x2v{h[4], h[5]}, f32x2v{t1.x, t1.y});
+    const f32x2v y3 = __builtin_elementwise_fma(f32x2v{s1.z, s1.w}, f32x2v{h[6], h[7]}, f32x2v{t1.z, t1.w});
+    u32x4 o;
+    o.x = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(y0, bf16x2)));
+    o.y = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(y1, bf16x2)));
+    o.z = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(y2, bf16x2)));
+    o.w = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(y3, bf16x2)));
+    return o;
+  }
 };
 template <>
 struct R2Fin<BGradH> {
@@ -228,6 +275,26 @@ struct R2Fin<BGradH> {
     unpack8(q.h, h);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = __fmaf_rn(ka[j], gy[j], __fmaf_rn(kb[j], h[j], kc[j]));
+  }
+  static constexpr bool PACKED = true;  // 8 v_pk_fma_f32 instead of 16 FMAs
+  static __device__ __forceinline__ u32x4 finp(const BGradH&, const BGradH::Row&, const float* kcs, int Kp, int k, const BGradH::Raw& q) {
+    const float4 a0 = *reinterpret_cast<const float4*>(kcs + k), a1 = *reinterpret_cast<const float4*>(kcs + k + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(kcs + Kp + k), b1 = *reinterpret_cast<const float4*>(kcs + Kp + k + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(kcs + 2 * Kp + k), c1 = *reinterpret_cast<const float4*>(kcs + 2 * Kp + k + 4);
+    float gy[8], h[8];
+    unpack8(q.gy, gy);
+    unpack8(q.h, h);
+    auto one = [](float ax, float ay, float gx, float gy_, float bx, float by, float hx, float hy, float cx, float cy) {
+      const f32x2v t = __builtin_elementwise_fma(f32x2v{bx, by}, f32x2v{hx, hy}, f32x2v{cx, cy});
+      const f32x2v y = __builtin_elementwise_fma(f32x2v{ax, ay}, f32x2v{gx, gy_}, t);
+      return __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2));
+    };
+    u32x4 o;
+    o.x = one(a0.x, a0.y, gy[0], gy[1], b0.x, b0.y, h[0], h[1], c0.x, c0.y);
+    o.y = one(a0.z, a0.w, gy[2], gy[3], b0.z, b0.w, h[2], h[3], c0.z, c0.w);
+    o.z = one(a1.x, a1.y, gy[4], gy[5], b1.x, b1.y, h[4], h[5], c1.x, c1.y);
+    o.w = one(a1.z, a1.w, gy[6], gy[7], b1.z, b1.w, h[6], h[7], c1.z, c1.w);
+    return o;
   }
 };
 template <>
@@ -603,7 +670,9 @@ struct EpiL1B2 {
 // grid = ngroups * slots blocks (1-D, XCD-aware virtual ids: the column groups of one slot are neighbours on one XCD - they
 // stream the same activation rows).  Dynamic LDS: weight slice [(R2_COLS + R2_SIDE)][Kp + 8] bf16, then the generator's
 // per-channel constants [AOp::NC][Kp] fp32.
-template <class AOp, class Epi>
+// ABL != 0: measurement-only variants (tools/r03_abl.sh, OBMAN_R2_ABL; wrong results): 1 no operand requests inside the k loop,
+// 2 weight fragments read once, 3 no epilogue, 4 no MFMAs, 5 = 2 + the generator's LDS constants read once
+template <class AOp, class Epi, int ABL = 0>
 __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, R2Geo geo,
                                                                  int lds_aop_floats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -647,6 +716,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
     {
       int b, n; long r;
       geo.row(bg, vt, wave, li, b, n, r, ok);
+      if constexpr (R2Sentinel<AOp>::value) { if (!ok) n = geo.N; }
       row = aop.row(r, b, n, ok);
       roff = src.off(aop, r, b, n, h);
     }
@@ -674,19 +744,31 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
       // compiler sank each read next to its MFMA: read -> wait -> MFMA, four exposed LDS round trips per k-step)
       bf16x8 fb[R2_NT];
 #pragma unroll
-      for (int j = 0; j < R2_NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)j * 32 * KP2 + s * 16);
+      for (int j = 0; j < R2_NT; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)j * 32 * KP2 + ((ABL == 2 || ABL == 5) ? 0 : s * 16));
       __builtin_amdgcn_sched_barrier(0);
       u32x4 a0;
-      {
+      const int kf = (ABL == 5 ? 0 : s * 16) + h * 8;
+      if constexpr (R2Packed<R2Fin<AOp>>::value) {
+        a0 = R2Fin<AOp>::finp(aop, row, kcs, Kp, kf, qs);
+      } else {
         float o0[8];
-        R2Fin<AOp>::fin(aop, row, kcs, Kp, s * 16 + h * 8, qs, o0);
+        R2Fin<AOp>::fin(aop, row, kcs, Kp, kf, qs, o0);
         a0 = pack8(o0);
       }
-      src.load(qs, roff, s + DQ);
-      if (!ok) a0 = u32x4{0u, 0u, 0u, 0u};
+      if constexpr (ABL != 1) src.load(qs, roff, s + DQ);
+      if constexpr (!R2Sentinel<AOp>::value) { if (!ok) a0 = u32x4{0u, 0u, 0u, 0u}; }
       const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
+      if constexpr (ABL == 4) {
 #pragma unroll
-      for (int j = 0; j < R2_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < R2_NT; ++j) {
+          const u32x4 fw = __builtin_bit_cast(u32x4, fb[j]);
+          asm volatile("" ::"v"(fw.x), "v"(fw.y), "v"(fw.z), "v"(fw.w), "v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < R2_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[j], acc[j], 0, 0, 0);
+      }
       if (nside) {  // leftover columns of the last group on the VALU, from the SAME rounded operands the MFMAs consume
 #pragma unroll
         for (int t = 0; t < R2_SIDE; ++t) {
@@ -717,7 +799,14 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
 #pragma unroll
       for (int t = 0; t < R2_SIDE; ++t) side[t] += __shfl_xor(side[t], 32, 64);
     }
-    epi.tile(est, acc, side, ctx, geo, red);
+    if constexpr (ABL == 3) {
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r]));
+    } else {
+      epi.tile(est, acc, side, ctx, geo, red);
+    }
   }
   epi.flush(est, ctx, geo, smem);
 }
