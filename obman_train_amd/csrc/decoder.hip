@@ -16,6 +16,7 @@
 // fp32 in / fp32 accumulate MFMA (exact fp32 fma chains): 157 TF peak = the fp32 vector rate, but it
 // leaves the VALU free for the fused loaders/epilogues.  Tile: 128 x 64 x 32, 4 waves (2x2), each wave
 // 64 x 32 = two 32x32 accumulators; LDS tiles k-major with +1 padding (conflict-free b32 reads/writes).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1781,6 +1782,7 @@ R2Geo r2_geo(const Dims& d, int Nc, int mode = 0) {
   g.nvt = mode == 1 ? (d.N + 3) / 4 : (d.N + 31) / 32;
   g.nbg = mode == 1 ? (d.B + 63) / 64 : (d.B + 7) / 8;
   g.ngroups = Nc > R2_SIDE ? (Nc - R2_SIDE + R2_COLS - 1) / R2_COLS : 1;
+  { const int last = Nc - (g.ngroups - 1) * R2_COLS; g.wside = last > R2_COLS ? last - R2_COLS : 0; }
   int target = device_cus() / g.ngroups;  // one block per CU (the weight slice takes most of a CU's LDS)
   if (target < 1) target = 1;
   g.spb = target / g.nbg;
@@ -1791,11 +1793,16 @@ R2Geo r2_geo(const Dims& d, int Nc, int mode = 0) {
   return g;
 }
 template <class AOp, class Epi>
+size_t r2_lds_bytes(int Kp, const R2Geo& geo) {
+  size_t lds = (size_t)(R2_COLS + geo.wside) * (Kp + 8) * sizeof(bfraw) + (size_t)R2Lds<AOp>::floats(Kp) * sizeof(float) + (size_t)Epi::LDS_FLOATS * sizeof(float);
+  const size_t flush = (size_t)(R2_WAVES - 1) * (R2_NT + 1) * 32 * 2 * sizeof(double);  // the end-of-block reduction re-uses the slice
+  return lds < flush ? flush : lds;
+}
+constexpr size_t R2_LDS_LIMIT = 160 * 1024;  // per workgroup on gfx950; wider layers than that fits take the first-generation kernels
+template <class AOp, class Epi>
 int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, hipStream_t st) {
   const int aop_floats = R2Lds<AOp>::floats(Kp);
-  size_t lds = (size_t)(R2_COLS + R2_SIDE) * (Kp + 8) * sizeof(bfraw) + (size_t)aop_floats * sizeof(float) + (size_t)Epi::LDS_FLOATS * sizeof(float);
-  const size_t flush = (size_t)(R2_WAVES - 1) * (R2_NT + 1) * 32 * 2 * sizeof(double);  // the end-of-block reduction re-uses the slice
-  if (lds < flush) lds = flush;
+  const size_t lds = r2_lds_bytes<AOp, Epi>(Kp, geo);
   static std::atomic<int> granted[MAX_DEVICES];
   const int dev = current_device();
   if ((int)lds > granted[dev].load(std::memory_order_relaxed)) {
@@ -1817,6 +1824,23 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
         case 2: go(rows2_bf16_kernel<AOp, Epi, 2>); break;
         case 3: go(rows2_bf16_kernel<AOp, Epi, 3>); break;
         case 4: go(rows2_bf16_kernel<AOp, Epi, 4>); break;
+        case 6: go(rows2_bf16_kernel<AOp, Epi, 6>); break;
+        case 8: {
+          go(rows2_bf16_kernel<AOp, Epi, 8>);
+          (void)hipStreamSynchronize(st);
+          static int calls = 0;
+          if (++calls == 5) {
+            static unsigned long long host[1024 * R2_WAVES * 8];
+            (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(r2_dbg), sizeof(host));
+            double sum[8] = {0};
+            const int nw = (int)(g < 1024 ? g : 1024) * R2_WAVES;
+            for (int i = 0; i < nw; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)host[(size_t)i * 8 + k];
+            const double st_ = sum[5] > 0 ? sum[5] : 1, tl = sum[7] > 0 ? sum[7] : 1;
+            fprintf(stderr, "R2DBG waves %d steps/wave %.0f tiles/wave %.1f | per k-step ticks: lds %.1f transform+vmwait %.1f mfma %.1f rest %.1f | per tile: epilogue %.0f | per wave total %.0f\n",
+                    nw, st_ / nw, tl / nw, sum[0] / st_, sum[1] / st_, sum[2] / st_, sum[3] / st_, sum[4] / tl, sum[6] / nw);
+          }
+          break;
+        }
         default: go(rows2_bf16_kernel<AOp, Epi, 5>); break;
       }
       OBMAN_LAUNCH_CHECK();
@@ -1845,7 +1869,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
     const double* mom = moments;
     int mrows;
-    if (rows2_enabled()) {
+    if (rows2_enabled() && r2_lds_bytes<BGridFeatPre, EpiStoreB2>(kpad16(d.C1), r2_geo(d, d.C2, 2)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C1);
       // rows as (8 samples x 4 vertices) per wave: a load instruction touches 4 rows of the layer-1 grid factor and 8 of the
       // feature factor instead of 32 + 1 (the fp32 factors go through the texture path 64 B per clock and CU),
@@ -1875,7 +1899,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb3);
     const double* mom = moments;
     int mrows;
-    if (rows2_enabled()) {
+    if (rows2_enabled() && r2_lds_bytes<BBnRelu, EpiStoreB2>(kpad16(d.C2), r2_geo(d, d.C3)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C2);
       const R2Geo g2 = r2_geo(d, d.C3);
       EpiStoreB2 e2{H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
@@ -1936,7 +1960,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     BGradH3 a{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
     EpiMaskB e{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
     bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt3);
-    if (rows2_enabled()) {
+    if (rows2_enabled() && r2_lds_bytes<BGradH3, EpiMaskB2>(kpad16(d.C3), r2_geo(d, d.C2)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C3);
       const R2Geo g2 = r2_geo(d, d.C2);
       EpiMaskB2 e2{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
@@ -1969,7 +1993,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     EpiL1B e{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
     const RowGeo tiled{(int)d.R, d.N, d.B, lg.tiles, 1};
     bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt2);
-    if (rows2_enabled()) {
+    if (rows2_enabled() && r2_lds_bytes<BGradH, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C2);
       const R2Geo g2 = r2_geo(d, d.C1, 1);
       EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};

@@ -28,6 +28,9 @@
 // the layer-1 grid factor rows are shared through L1 / L2).
 #pragma once
 
+#ifndef R2_EPI_ABL
+#define R2_EPI_ABL 0  // measurement-only epilogue ablations (wrong results): 1 no global stores, 2 no transposition and no stores, 3 no moments
+#endif
 constexpr int R2_NT = 4;               // 32-column MFMA tiles per wave
 constexpr int R2_COLS = 32 * R2_NT;    // columns per block (+ up to R2_SIDE side columns in the last group)
 constexpr int R2_SIDE = 3;
@@ -45,6 +48,7 @@ struct R2Geo {
   int ngroups;  // column groups of R2_COLS
   int slots;    // persistent blocks per column group = spb * nbg
   int spb;      // slots per sample group
+  int wside;    // side-column rows of the weight slice actually present (0 .. R2_SIDE): LDS rows = R2_COLS + wside
   int chunk;    // vertex tiles per slot
   // row i (0..31) of the fragment of wave `wave` in block tile (bg, vt)
   __device__ __forceinline__ void row(int bg, int vt, int wave, int i, int& b, int& n, long& r, bool& ok) const {
@@ -208,9 +212,16 @@ template <>
 struct R2Fin<BGridFeatPre> {
   // 4 v_pk_add_f32 + 4 v_cvt_pk_bf16_f32 + 4 v_pk_max_i16 per 8 elements (scalar form: 8 adds, 8 max, 4 converts)
   static constexpr bool PACKED = true;
-  static __device__ __forceinline__ u32x4 finp(const BGridFeatPre&, const BGridFeatPre::Row& w, const float* fy, int Kp, int k, const BGridFeatPre::Raw& q) {
+  struct Pref { float4 f0, f1; };  // the k-step's LDS constants, requested one k-step ahead by the pipelined loop
+  static __device__ __forceinline__ Pref pre(const BGridFeatPre&, const BGridFeatPre::Row& w, const float* fy, int Kp, int k) {
     const float* f = fy + (size_t)w.sl * (Kp + BGridFeatPre::FPITCH_PAD) + k;
-    const float4 f0 = *reinterpret_cast<const float4*>(f), f1 = *reinterpret_cast<const float4*>(f + 4);
+    return Pref{*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4)};
+  }
+  static __device__ __forceinline__ u32x4 finp(const BGridFeatPre& op, const BGridFeatPre::Row& w, const float* fy, int Kp, int k, const BGridFeatPre::Raw& q) {
+    return finq(pre(op, w, fy, Kp, k), q);
+  }
+  static __device__ __forceinline__ u32x4 finq(const Pref& c, const BGridFeatPre::Raw& q) {
+    const float4 f0 = c.f0, f1 = c.f1;
     const float4 g0 = r2_f4(q.g0), g1 = r2_f4(q.g1);
     const f32x2v s0 = f32x2v{g0.x, g0.y} + f32x2v{f0.x, f0.y}, s1 = f32x2v{g0.z, g0.w} + f32x2v{f0.z, f0.w};
     const f32x2v s2 = f32x2v{g1.x, g1.y} + f32x2v{f1.x, f1.y}, s3 = f32x2v{g1.z, g1.w} + f32x2v{f1.z, f1.w};
@@ -370,7 +381,11 @@ __device__ __forceinline__ void r2_flush_cols(double (&d1)[R2_NT], double (&d2)[
 }
 
 struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, sum of squares of the STORED values) per slot
-  static constexpr int LDS_FLOATS = 0;
+  // Stores are ISSUE-bound on this chip (a wave's store instruction costs the same whether it carries 4 or 16 bytes per lane;
+  // the 32 dword stores per tile of the first version were 30 % of the h2 kernel, tools/r03_abl.sh): every 16 x 32 piece of
+  // the tile is transposed through 1 KB of LDS per wave (4 ds_write_b32 + 1 ds_read_b128 per lane) and leaves as ONE
+  // 16-byte store per lane - 8 store instructions per tile instead of 32.
+  static constexpr int LDS_FLOATS = R2_WAVES * 256;
   bfraw* C;
   const float* bias;
   double* moments;  // [slots][Nc][2] or null
@@ -386,7 +401,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
     for (int t = 0; t < R2_SIDE; ++t) { s.e1[t] = 0.f; s.e2[t] = 0.f; }
   }
   __device__ __forceinline__ void tile(State& s, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c,
-                                       const R2Geo& geo, float*) const {
+                                       const R2Geo& geo, float* red) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     const bool odd = c.lane & 1;
     float bv[R2_NT];
@@ -399,24 +414,52 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     {
+      unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
+      // which rows of the tile this lane's registers hold (validity for the moments) ...
+      bool ok0[8], ok1[8];
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const int i0 = acc_row(2 * p, c.lane);
-        int b, n; long r0; bool ok0;
-        geo.row(c.bg, c.vt, c.wave, i0, b, n, r0, ok0);
-        const bool ok1 = ok0 && n + 1 < geo.N;  // row i0 + 1: the next vertex of the same sample
-        bfraw* dst = C + (size_t)(odd ? r0 + 1 : r0) * ldc;
-        const bool okw = odd ? ok1 : ok0;
+        int b, n; long r0;
+        geo.row(c.bg, c.vt, c.wave, acc_row(2 * p, c.lane), b, n, r0, ok0[p]);
+        ok1[p] = ok0[p] && n + 1 < geo.N;  // row i0 + 1: the next vertex of the same sample
+      }
+      // ... and which rows it stores: row 16 G + (lane >> 2) of the tile, columns 8 (lane & 3) .. + 7 of each 32-column piece
+      bfraw* dstg[2];
+      bool okg[2];
 #pragma unroll
-        for (int j = 0; j < R2_NT; ++j) {
-          const int cl = c.c0 + j * 32 + li;
-          const bool cok = cl < Nc;
-          const unsigned pk = pack_bf16(cok ? acc[j][2 * p] + bv[j] : 0.f, cok ? acc[j][2 * p + 1] + bv[j] : 0.f);
-          const float v0 = ok0 ? bf_lo(pk) : 0.f, v1 = ok1 ? bf_hi(pk) : 0.f;
-          s1[j] += v0 + v1;
-          s2[j] = __fmaf_rn(v0, v0, __fmaf_rn(v1, v1, s2[j]));
-          const unsigned w = pair_exchange(pk, odd);
-          if (okw && (cl & ~1) < ldc) *reinterpret_cast<unsigned*>(dst + (cl & ~1)) = w;
+      for (int G = 0; G < 2; ++G) {
+        int b, n; long r;
+        geo.row(c.bg, c.vt, c.wave, 16 * G + (c.lane >> 2), b, n, r, okg[G]);
+        dstg[G] = C + (size_t)r * ldc + c.c0 + (c.lane & 3) * 8;
+      }
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j) {
+        const bool cok = c.c0 + j * 32 + (c.lane & 3) * 8 < ldc;  // columns >= Nc inside the pitch hold zeros (zero weights, no bias)
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int p = 4 * G + q;
+            const unsigned pk = pack_bf16(acc[j][2 * p] + bv[j], acc[j][2 * p + 1] + bv[j]);
+            const float v0 = ok0[p] ? bf_lo(pk) : 0.f, v1 = ok1[p] ? bf_hi(pk) : 0.f;
+#if R2_EPI_ABL != 3
+            s1[j] += v0 + v1;
+            s2[j] = __fmaf_rn(v0, v0, __fmaf_rn(v1, v1, s2[j]));
+#endif
+            // even lane: row 2p, columns (li, li + 1); odd lane: row 2p + 1, columns (li - 1, li)
+            const int rr = ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * h + (odd ? 1 : 0);
+#if R2_EPI_ABL != 2
+            tb[rr * 16 + (li >> 1)] = pair_exchange(pk, odd);
+#endif
+          }
+#if R2_EPI_ABL != 2
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tb + (c.lane >> 2) * 16 + (c.lane & 3) * 4);
+#if R2_EPI_ABL == 1
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
+          if (okg[G] && cok) *reinterpret_cast<u32x4*>(dstg[G] + j * 32) = v;
+#endif
+#endif
         }
       }
       // side columns and the pitch padding behind the last real column: one row per lane (half 0 / half 1)
@@ -668,17 +711,20 @@ struct EpiL1B2 {
 
 // ------------------------------------------------------------------------------------------------ the kernel
 // grid = ngroups * slots blocks (1-D, XCD-aware virtual ids: the column groups of one slot are neighbours on one XCD - they
-// stream the same activation rows).  Dynamic LDS: weight slice [(R2_COLS + R2_SIDE)][Kp + 8] bf16, then the generator's
+// stream the same activation rows).  Dynamic LDS: weight slice [(R2_COLS + geo.wside)][Kp + 8] bf16, then the generator's
 // per-channel constants [AOp::NC][Kp] fp32.
 // ABL != 0: measurement-only variants (tools/r03_abl.sh, OBMAN_R2_ABL; wrong results): 1 no operand requests inside the k loop,
 // 2 weight fragments read once, 3 no epilogue, 4 no MFMAs, 5 = 2 + the generator's LDS constants read once
+// ABL == 8: s_memtime stamps inside the k-step of every wave (LDS phase / transform + operand wait / MFMA issue / rest / epilogue),
+// summed per wave into r2_dbg[block][wave][8] - printed by launch_rows2 (measurement only; the stamps serialise the phases)
+__device__ unsigned long long r2_dbg[1024 * R2_WAVES * 8];
 template <class AOp, class Epi, int ABL = 0>
 __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, R2Geo geo,
                                                                  int lds_aop_floats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int KP2 = Kp + 8;
   bfraw* Ws = reinterpret_cast<bfraw*>(smem);
-  float* kcs = reinterpret_cast<float*>(Ws + (size_t)(R2_COLS + R2_SIDE) * KP2);
+  float* kcs = reinterpret_cast<float*>(Ws + (size_t)(R2_COLS + geo.wside) * KP2);
   float* red = kcs + lds_aop_floats;        // Epi::LDS_FLOATS floats of epilogue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   const int vid = xcd_virtual_id(blockIdx.x, gridDim.x), cg = vid % geo.ngroups, slot = vid / geo.ngroups;
@@ -687,7 +733,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
   const int gcols = last_group ? Nc - c0 : R2_COLS;  // the last group holds the remainder: up to R2_COLS + R2_SIDE columns
   const int nside = gcols > R2_COLS ? gcols - R2_COLS : 0;
   {
-    const int chunks = Kp >> 3, total = (R2_COLS + R2_SIDE) * chunks;
+    const int chunks = Kp >> 3, total = (R2_COLS + geo.wside) * chunks;
     for (int i = tid; i < total; i += R2_THREADS) {
       const int cc = i / chunks, q = i - cc * chunks;
       u32x4 v = {0u, 0u, 0u, 0u};
@@ -708,6 +754,8 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
   const int nks = Kp >> 4;
   const bfraw* wlane = Ws + (size_t)li * KP2 + h * 8;
   ctx.bg = bg;
+  unsigned long long dbg_l = 0, dbg_v = 0, dbg_m = 0, dbg_g = 0, dbg_e = 0, dbg_steps = 0, dbg_last = 0;
+  const unsigned long long dbg_t0 = ABL == 8 ? __builtin_readcyclecounter() : 0;
   for (int vt = vt_beg; vt < vt_end; ++vt) {
     ctx.vt = vt;
     typename AOp::Row row;
@@ -788,6 +836,88 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
       }
     };
     int s = 0;
+    if constexpr (ABL == 8) {
+      typedef typename R2Fin<AOp>::Pref Pref;
+      for (; s < nks; ++s) {
+        const unsigned long long T0 = __builtin_readcyclecounter();
+        bf16x8 fb[R2_NT];
+#pragma unroll
+        for (int j = 0; j < R2_NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)j * 32 * KP2 + s * 16);
+        const Pref pc = R2Fin<AOp>::pre(aop, row, kcs, Kp, s * 16 + h * 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long T1 = __builtin_readcyclecounter();
+        typename AOp::Raw& qs = q[0];
+        u32x4 a0 = R2Fin<AOp>::finq(pc, qs);
+        asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w));
+        const unsigned long long T2 = __builtin_readcyclecounter();
+        // rotate the queue by hand (runtime s): q[0] <- q[1] ... and request step s + DQ into the last slot
+#pragma unroll
+        for (int u = 0; u + 1 < DQ; ++u) q[u] = q[u + 1];
+        src.load(q[DQ - 1], roff, s + DQ);
+        const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
+#pragma unroll
+        for (int j = 0; j < R2_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[j], acc[j], 0, 0, 0);
+        const unsigned long long T3 = __builtin_readcyclecounter();
+        dbg_l += T1 - T0; dbg_v += T2 - T1; dbg_m += T3 - T2; dbg_steps += 1;
+        if (dbg_last) dbg_g += T0 - dbg_last;
+        dbg_last = T3;
+      }
+    } else if constexpr (ABL == 6) {
+      // Pipelined inside the wave: the LDS reads of k-step s + 1 (weight fragments, generator constants, side-column weights) are
+      // issued BEFORE the transform and the MFMAs of step s into the other of two register sets (compile-time parity: DQ is even),
+      // so a wave never sits on an LDS round trip with an idle matrix pipe.
+      typedef typename R2Fin<AOp>::Pref Pref;
+      struct Stage { bf16x8 fb[R2_NT]; Pref c; u32x4 wv[R2_SIDE]; };
+      auto fetch = [&](Stage& st, int ks) {
+#pragma unroll
+        for (int j = 0; j < R2_NT; ++j) st.fb[j] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)j * 32 * KP2 + ks * 16);
+        st.c = R2Fin<AOp>::pre(aop, row, kcs, Kp, ks * 16 + h * 8);
+        if (nside) {
+#pragma unroll
+          for (int t = 0; t < R2_SIDE; ++t)
+            if (t < nside) st.wv[t] = *reinterpret_cast<const u32x4*>(Ws + (size_t)(R2_COLS + t) * KP2 + ks * 16 + h * 8);
+        }
+      };
+      auto stepp = [&](typename AOp::Raw& qs, int ks, Stage& cur, Stage& nxt) {
+        fetch(nxt, ks + 1 < nks ? ks + 1 : ks);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 a0 = R2Fin<AOp>::finq(cur.c, qs);
+        src.load(qs, roff, ks + DQ);
+        if constexpr (!R2Sentinel<AOp>::value) { if (!ok) a0 = u32x4{0u, 0u, 0u, 0u}; }
+        const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
+#pragma unroll
+        for (int j = 0; j < R2_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, cur.fb[j], acc[j], 0, 0, 0);
+        if (nside) {
+#pragma unroll
+          for (int t = 0; t < R2_SIDE; ++t) {
+            if (t < nside) {
+              float s0 = side[t];
+              asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.x), "v"(cur.wv[t].x));
+              asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.y), "v"(cur.wv[t].y));
+              asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.z), "v"(cur.wv[t].z));
+              asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(a0.w), "v"(cur.wv[t].w));
+              side[t] = s0;
+            }
+          }
+        }
+      };
+      static_assert(DQ % 2 == 0, "the two register sets alternate with compile-time parity");
+      Stage sa, sb;
+      fetch(sa, 0);
+      for (; s + DQ <= nks; s += DQ) {
+#pragma unroll
+        for (int u = 0; u < DQ; ++u) {
+          if (u & 1) stepp(q[u], s + u, sb, sa);
+          else stepp(q[u], s + u, sa, sb);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < DQ; ++u)
+        if (s + u < nks) {
+          if (u & 1) stepp(q[u], s + u, sb, sa);
+          else stepp(q[u], s + u, sa, sb);
+        }
+    } else {
     for (; s + DQ <= nks; s += DQ) {
 #pragma unroll
       for (int u = 0; u < DQ; ++u) step(q[u], s + u);
@@ -795,6 +925,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
 #pragma unroll
     for (int u = 0; u < DQ; ++u)
       if (s + u < nks) step(q[u], s + u);
+    }
     if (nside) {  // the two lane halves covered different k: combine
 #pragma unroll
       for (int t = 0; t < R2_SIDE; ++t) side[t] += __shfl_xor(side[t], 32, 64);
@@ -804,8 +935,21 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
       for (int j = 0; j < R2_NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r]));
+    } else if constexpr (ABL == 8) {
+      const unsigned long long E0 = __builtin_readcyclecounter();
+      epi.tile(est, acc, side, ctx, geo, red);
+      const unsigned long long E1 = __builtin_readcyclecounter();
+      dbg_e += E1 - E0;
+      dbg_last = 0;
     } else {
       epi.tile(est, acc, side, ctx, geo, red);
+    }
+  }
+  if constexpr (ABL == 8) {
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned long long* o = r2_dbg + ((size_t)blockIdx.x * R2_WAVES + wave) * 8;
+      o[0] = dbg_l; o[1] = dbg_v; o[2] = dbg_m; o[3] = dbg_g; o[4] = dbg_e; o[5] = dbg_steps;
+      o[6] = __builtin_readcyclecounter() - dbg_t0; o[7] = (unsigned long long)(vt_end - vt_beg);
     }
   }
   epi.flush(est, ctx, geo, smem);

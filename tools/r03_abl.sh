@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: ablations of the h2 rows2 kernel's k loop (OBMAN_R2_ABL, measurement only)
 cd /tmp && export TMPDIR=/tmp
-for m in 0 1 2 3 4 5; do
+for m in ${ABLS:-0 1 2 3 4 5}; do
   rm -rf /tmp/prof_dec
   OBMAN_R2_ABL=$m OBMAN_KBENCH_DEC=bf16:12 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -- python $GRAFT_REPO_ROOT/tools/kbench.py decoder > /tmp/kb.log 2>&1
   f=$(find /tmp/prof_dec -name "*kernel_stats.csv" | head -1)
