@@ -767,6 +767,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 
 #include "decoder_bf16.h"
 #include "decoder_rows2.h"
+#include "decoder_tn2.h"
 
 }  // namespace dec
 
@@ -1729,6 +1730,34 @@ int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, 
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
+bool tn2_enabled() {
+  static const int on = [] { const char* e = getenv("OBMAN_DEC_TN2"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = first-generation weight-gradient GEMM
+  return on != 0;
+}
+// second generation (decoder_tn2.h): same tiles, chunks, partials and reduction, operands through 16-byte loads and transposing LDS reads
+template <class AOp, class BOp>
+int launch_tn2_bf16(const AOp& a, const BOp& b, int M, int Nc, int N, int Bsz, float* part, float* out, int ldo, int off, hipStream_t st,
+                    int transposed) {
+  constexpr int WN = 5;
+  constexpr int PA = BM + 32, PB = 64 * WN + 96;
+  const size_t lds = (size_t)2 * T2_KT * (PA + PB) * sizeof(bfraw);
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if (!granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)tn2_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store(1, std::memory_order_relaxed);
+  }
+  const int chunks = tn_bf16_chunks(M, Nc, N, Bsz, 64 * WN);
+  const long ntiles = (long)((Bsz + 7) / 8) * ((N + 7) / 8);
+  const int tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
+  const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))) * (unsigned)chunks;
+  tn2_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, N, Bsz, tiles_per_chunk, part);
+  OBMAN_LAUNCH_CHECK();
+  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out, transposed);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
 template <class AOp, class BOp>
 int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
                    hipStream_t st, int transposed = 0) {
@@ -1869,6 +1898,10 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
     const double* mom = moments;
     int mrows;
+    // pre-scaled layer-1 factors (+ the sentinel row): read by the h2 GEMM below and by the weight-gradient GEMM of the backward pass
+    prescale_l1_kernel<<<obman_cdiv((long)(d.N + 1 + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
+                                                                                      d.C1, ws + w.Gy, ws + w.Fy);
+    OBMAN_LAUNCH_CHECK();
     if (rows2_enabled() && r2_lds_bytes<BGridFeatPre, EpiStoreB2>(kpad16(d.C1), r2_geo(d, d.C2, 2)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C1);
       // rows as (8 samples x 4 vertices) per wave: a load instruction touches 4 rows of the layer-1 grid factor and 8 of the
@@ -1876,9 +1909,6 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
       // and the feature factor's 8 rows of the block live in LDS.  Factors pre-scaled by BatchNorm-1's gamma / beta: add + max per element
       const R2Geo g2 = r2_geo(d, d.C2, 2);
       EpiStoreB2 e2{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
-      prescale_l1_kernel<<<obman_cdiv((long)(d.N + 1 + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
-                                                                                        d.C1, ws + w.Gy, ws + w.Fy);
-      OBMAN_LAUNCH_CHECK();
       BGridFeatPre ap{ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st, Kp))) return rc;
       if ((rc = launch_rows2<BGridFeatPre, EpiStoreB2>(ap, wb, Kp, d.C2, g2, e2, st))) return rc;
@@ -1978,13 +2008,28 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
+  const bool gh_plain = tn2_enabled() && wide_wn(d.C2) == 5 && rows2_enabled() && (d.ld2 & 7) == 0 && d.ld2 <= 512 &&
+                        r2_lds_bytes<BPlain, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT;
   {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c], formed TRANSPOSED (M = the 515 channels of a1, one 320-wide tile for the 257 of gh2):
      // every operand is regenerated once per tile of the OTHER operand, and a1 (fp32 factors, add + fma + max per element) is the
      // expensive one - as the A operand of five 128 x 320 tiles it is generated once (640 channel columns per k-tile) and gh2 five
      // times (1 600), against 1 920 + 768 with gh2 as A on 3 x 2 tiles
-    TGridFeat ta{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, d.C1};
-    TGradH tb{GY2, H2, k1, k2, k3, d.ld2, d.C2};
-    if ((rc = launch_tn_bf16<TGridFeat, TGradH>(ta, tb, d.C1, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
+    if (gh_plain) {
+      // gh2 materialised once (in place over gy2): both GEMMs below read it as a plain bf16 operand
+      gh2_inplace_kernel<<<obman_cdiv(d.R, GH2_ROWS), dim3(64, 4), 0, st>>>(GY2, H2, k1, k2, k3, d.R, d.ld2, d.C2);
+      OBMAN_LAUNCH_CHECK();
+      T2Pre ta{ws + w.Gy, ws + w.Fy, d.ld1, d.N, d.B};
+      T2Plain tb{GY2, d.ld2, d.N, d.B};
+      if ((rc = launch_tn2_bf16<T2Pre, T2Plain>(ta, tb, d.C1, d.C2, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
+    } else if (tn2_enabled() && wide_wn(d.C2) == 5) {
+      T2Pre ta{ws + w.Gy, ws + w.Fy, d.ld1, d.N, d.B};
+      T2GradH tb{GY2, H2, k1, k2, k3, d.ld2, d.C2, d.N, d.B};
+      if ((rc = launch_tn2_bf16<T2Pre, T2GradH>(ta, tb, d.C1, d.C2, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
+    } else {
+      TGridFeat ta{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, d.C1};
+      TGradH tb{GY2, H2, k1, k2, k3, d.ld2, d.C2};
+      if ((rc = launch_tn_bf16<TGridFeat, TGradH>(ta, tb, d.C1, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
+    }
   }
   const L1Geo lg = l1_geo(d);
   int l1_prow = lg.tiles, l1_groups = lg.groups;
@@ -1993,7 +2038,16 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     EpiL1B e{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
     const RowGeo tiled{(int)d.R, d.N, d.B, lg.tiles, 1};
     bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt2);
-    if (rows2_enabled() && r2_lds_bytes<BGradH, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT) {
+    if (gh_plain) {
+      const int Kp = kpad16(d.C2);
+      const R2Geo g2 = r2_geo(d, d.C1, 1);
+      EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
+      BPlain ap{GY2, d.ld2, d.C2};
+      if ((rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st, Kp))) return rc;
+      if ((rc = launch_rows2<BPlain, EpiL1B2>(ap, wt, Kp, d.C1, g2, e2, st))) return rc;
+      l1_prow = g2.spb;
+      l1_groups = g2.nbg;
+    } else if (rows2_enabled() && r2_lds_bytes<BGradH, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C2);
       const R2Geo g2 = r2_geo(d, d.C1, 1);
       EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};

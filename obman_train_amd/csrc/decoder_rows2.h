@@ -82,6 +82,19 @@ struct BGridFeatPre {
   __device__ Row row(long, int b, int, bool ok) const { return Row{b & 7, ok}; }
 };
 
+// A operand stored as it is consumed: bf16 [R, ld] (gh2 after gh2_inplace_kernel).  Rows outside the problem are addressed beyond
+// the buffer's range - the hardware bounds check returns zeros, so there is neither a transform nor a select.
+struct BPlain {
+  const bfraw* A;
+  int ld, K;
+  static constexpr int NC = 0;
+  static constexpr bool SELFMASK = true;
+  struct Row {};
+  struct Raw { u32x4 v; };
+  __device__ Row row(long, int, int, bool) const { return Row{}; }
+  __device__ void stage(float*, int, int) const {}
+};
+
 // request-queue depth per operand generator (k-steps in flight per wave): 16 registers per step for the fp32 layer-1 factors,
 // 4 / 8 for the bf16-stored activations
 template <class AOp> struct R2Depth { static constexpr int value = 8; };
@@ -172,6 +185,17 @@ struct R2Src<BGradH3> {
   __device__ __forceinline__ void load(BGradH3::Raw& q, const Off& o, int s) const { q.h = r2_ld16(rh, o.h, s * 32); }
 };
 template <>
+struct R2Src<BPlain> {
+  __amdgpu_buffer_rsrc_t ra;
+  struct Off { unsigned o; };
+  __device__ __forceinline__ void init(const BPlain& op, const R2Geo& geo) { ra = r2_rsrc(op.A, (size_t)geo.R * op.ld * 2); }
+  __device__ __forceinline__ Off off(const BPlain& op, long r, int, int, int h) const { return Off{(unsigned)(((size_t)r * op.ld + h * 8) * 2)}; }
+  __device__ __forceinline__ Off off_masked(const BPlain& op, long r, int h, bool ok) const {
+    return Off{ok ? (unsigned)(((size_t)r * op.ld + h * 8) * 2) : 0x7ffffff0u};  // beyond num_records whatever the scalar offset adds
+  }
+  __device__ __forceinline__ void load(BPlain::Raw& q, const Off& o, int s) const { q.v = r2_ld16(ra, o.o, s * 32); }
+};
+template <>
 struct R2Src<BGradH> {
   __amdgpu_buffer_rsrc_t rgy, rh;
   struct Off { unsigned o; };
@@ -198,6 +222,8 @@ struct R2Fin {
 // does the generator produce the packed bf16 fragment itself (finp) / zero the rows outside the problem itself?
 template <class F, class = void> struct R2Packed { static constexpr bool value = false; };
 template <class F> struct R2Packed<F, std::enable_if_t<F::PACKED>> { static constexpr bool value = true; };
+template <class AOp, class = void> struct R2SelfMask { static constexpr bool value = false; };
+template <class AOp> struct R2SelfMask<AOp, std::enable_if_t<AOp::SELFMASK>> { static constexpr bool value = true; };
 template <class AOp, class = void> struct R2Sentinel { static constexpr bool value = false; };
 template <class AOp> struct R2Sentinel<AOp, std::enable_if_t<AOp::SENTINEL>> { static constexpr bool value = true; };
 typedef short s16x2v __attribute__((ext_vector_type(2)));
@@ -240,6 +266,11 @@ struct R2Fin<BGridFeatPre> {
     o[0] = fmaxf(g0.x + f0.x, 0.f); o[1] = fmaxf(g0.y + f0.y, 0.f); o[2] = fmaxf(g0.z + f0.z, 0.f); o[3] = fmaxf(g0.w + f0.w, 0.f);
     o[4] = fmaxf(g1.x + f1.x, 0.f); o[5] = fmaxf(g1.y + f1.y, 0.f); o[6] = fmaxf(g1.z + f1.z, 0.f); o[7] = fmaxf(g1.w + f1.w, 0.f);
   }
+};
+template <>
+struct R2Fin<BPlain> {
+  static constexpr bool PACKED = true;
+  static __device__ __forceinline__ u32x4 finp(const BPlain&, const BPlain::Row&, const float*, int, int, const BPlain::Raw& q) { return q.v; }
 };
 template <>
 struct R2Fin<BBnRelu> {
@@ -766,7 +797,8 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
       geo.row(bg, vt, wave, li, b, n, r, ok);
       if constexpr (R2Sentinel<AOp>::value) { if (!ok) n = geo.N; }
       row = aop.row(r, b, n, ok);
-      roff = src.off(aop, r, b, n, h);
+      if constexpr (R2SelfMask<AOp>::value) roff = src.off_masked(aop, r, h, ok);
+      else roff = src.off(aop, r, b, n, h);
     }
     f32x16 acc[R2_NT];
 #pragma unroll
@@ -805,7 +837,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
         a0 = pack8(o0);
       }
       if constexpr (ABL != 1) src.load(qs, roff, s + DQ);
-      if constexpr (!R2Sentinel<AOp>::value) { if (!ok) a0 = u32x4{0u, 0u, 0u, 0u}; }
+      if constexpr (!R2Sentinel<AOp>::value && !R2SelfMask<AOp>::value) { if (!ok) a0 = u32x4{0u, 0u, 0u, 0u}; }
       const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
       if constexpr (ABL == 4) {
 #pragma unroll
@@ -883,7 +915,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
         __builtin_amdgcn_sched_barrier(0);
         u32x4 a0 = R2Fin<AOp>::finq(cur.c, qs);
         src.load(qs, roff, ks + DQ);
-        if constexpr (!R2Sentinel<AOp>::value) { if (!ok) a0 = u32x4{0u, 0u, 0u, 0u}; }
+        if constexpr (!R2Sentinel<AOp>::value && !R2SelfMask<AOp>::value) { if (!ok) a0 = u32x4{0u, 0u, 0u, 0u}; }
         const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
 #pragma unroll
         for (int j = 0; j < R2_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, cur.fb[j], acc[j], 0, 0, 0);

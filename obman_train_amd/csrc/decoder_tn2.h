@@ -1,0 +1,244 @@
+// K6, bf16-MFMA flavour, second generation of the weight-gradient ("TN") GEMMs: included by decoder.hip inside namespace dec.
+//
+//   out[m, n] = sum_r  A[r, m] * B[r, n]         (dW2: A = a1 [R, 515], B = gh2 [R, 257]; contraction over the R = B * N rows)
+//
+// Same tiling, split-K chunks, partial layout and reduction as tn_bf16_kernel (decoder_bf16.h): block tile BM x 64 WN, eight
+// waves as 4 (m) x 2 (n), k-tiles of 64 rows = (8 samples) x (8 template vertices).  What changed is how the operands reach
+// the matrix pipe.  The first generation gave a thread an (8 rows) x (2 channels) strip: eight 4- or 8-byte loads per source
+// array, ~50 load instructions per thread and k-tile, and a k-major LDS image written through a VALU transpose - on this
+// chip every wave-level load instruction costs the texture path ~16 cycles whatever its width, and load, VALU, LDS and MFMA
+// time ADD UP with two waves per SIMD (tools/ubench/mfma_loop.hip), so the kernel ran at 10x its MFMA time.  Here
+//   * a task is (row, 8 consecutive channels): ONE 16-byte load per bf16 source, two per fp32 source;
+//   * the transforms are the packed ones of decoder_rows2.h on the 8 channels (constants per thread: its channel octet is fixed);
+//   * tiles are stored ROW-major [row][channel] with one 16-byte LDS write per task, and the k-major fragments the MFMA wants
+//     come from ds_read_b64_tr_b16 (the transposing read: inside a 16-lane group, lane c receives elements c of the four rows
+//     the lanes 4r .. 4r+3 point at) - no VALU transpose anywhere.
+// Rows outside the problem: the A operand reads the sentinel row of Gy (exact zeros after relu); B then only has to be finite.
+constexpr int T2_KT = 64;
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4v* lds_s16x4_ptr;
+
+struct T2Pre {  // a1[r, c .. c+7] = relu(Gy[n] + Fy[b])  (prescale_l1_kernel; Gy row N = -3e38)
+  const float *Gy, *Fy;
+  int ld, N, B;
+  struct Consts {};
+  struct Raw { u32x4 g0, g1, f0, f1; };
+  __device__ __forceinline__ Consts consts(int) const { return Consts{}; }
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool ok, int c0) const {
+    const float* g = Gy + (size_t)(ok ? n : N) * ld + c0;
+    const float* f = Fy + (size_t)(b < B ? b : B - 1) * ld + c0;
+    q.g0 = *reinterpret_cast<const u32x4*>(g); q.g1 = *reinterpret_cast<const u32x4*>(g + 4);
+    q.f0 = *reinterpret_cast<const u32x4*>(f); q.f1 = *reinterpret_cast<const u32x4*>(f + 4);
+  }
+  __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts&) const {
+    const float4 g0 = r2_f4(q.g0), g1 = r2_f4(q.g1), f0 = r2_f4(q.f0), f1 = r2_f4(q.f1);
+    const f32x2v s0 = f32x2v{g0.x, g0.y} + f32x2v{f0.x, f0.y}, s1 = f32x2v{g0.z, g0.w} + f32x2v{f0.z, f0.w};
+    const f32x2v s2 = f32x2v{g1.x, g1.y} + f32x2v{f1.x, f1.y}, s3 = f32x2v{g1.z, g1.w} + f32x2v{f1.z, f1.w};
+    u32x4 o;
+    o.x = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s0, bf16x2)));
+    o.y = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s1, bf16x2)));
+    o.z = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s2, bf16x2)));
+    o.w = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(s3, bf16x2)));
+    return o;
+  }
+};
+
+struct T2GradH {  // gh[r, c .. c+7] = ka * gy + kb * h + kc  (gy, h bf16 [R, ld]; per-channel constants zero beyond K)
+  const bfraw *GY, *H;
+  const float *ka, *kb, *kc_;
+  int ld, K, N, B;
+  struct Consts { float a[8], b[8], c[8]; };
+  struct Raw { u32x4 gy, h; };
+  __device__ __forceinline__ Consts consts(int c0) const {
+    Consts k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = c0 + e < K;
+      k.a[e] = ok ? ka[c0 + e] : 0.f; k.b[e] = ok ? kb[c0 + e] : 0.f; k.c[e] = ok ? kc_[c0 + e] : 0.f;
+    }
+    return k;
+  }
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool, int c0) const {
+    const size_t o = ((size_t)(b < B ? b : B - 1) * N + (n < N ? n : N - 1)) * ld + c0;  // any finite row will do where the other operand is zero
+    q.gy = *reinterpret_cast<const u32x4*>(GY + o);
+    q.h = *reinterpret_cast<const u32x4*>(H + o);
+  }
+  __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts& k) const {
+    float gy[8], h[8];
+    unpack8(q.gy, gy);
+    unpack8(q.h, h);
+    u32x4 o;
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x2v t = __builtin_elementwise_fma(f32x2v{k.b[2 * e], k.b[2 * e + 1]}, f32x2v{h[2 * e], h[2 * e + 1]}, f32x2v{k.c[2 * e], k.c[2 * e + 1]});
+      const f32x2v y = __builtin_elementwise_fma(f32x2v{k.a[2 * e], k.a[2 * e + 1]}, f32x2v{gy[2 * e], gy[2 * e + 1]}, t);
+      w[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2));
+    }
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    return o;
+  }
+};
+
+struct T2Plain {  // operand stored as it is consumed: bf16 [R, ld] (gh2 after gh2_inplace_kernel)
+  const bfraw* A;
+  int ld, N, B;
+  struct Consts {};
+  struct Raw { u32x4 v; };
+  __device__ __forceinline__ Consts consts(int) const { return Consts{}; }
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool, int c0) const {
+    q.v = *reinterpret_cast<const u32x4*>(A + ((size_t)(b < B ? b : B - 1) * N + (n < N ? n : N - 1)) * ld + c0);
+  }
+  __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts&) const { return q.v; }
+};
+
+// gh2 = ka * gy2 + kb * h2 + kc, rounded to bf16 exactly as the operand generators of the two GEMMs that consume it did on the
+// fly (dA re-generated it once per column group = 4 times, dW2 once per output tile = 5 times); IN PLACE over gy2, which has no
+// other reader.  One thread = 8 channels of a row.
+constexpr int GH2_ROWS = 64;  // rows per block
+__global__ __launch_bounds__(256) void gh2_inplace_kernel(bfraw* __restrict__ GY, const bfraw* __restrict__ H, const float* __restrict__ ka,
+                                                          const float* __restrict__ kb, const float* __restrict__ kc, long R, int ld, int K) {
+  // blockDim = (64 octet slots, 4 row slots); a thread keeps its octet's 24 constants in registers and walks 16 rows: per row
+  // two 16-byte loads and one 16-byte store (scalar-indexed constant loads per element made this pass 5x slower than its traffic)
+  const int c0 = threadIdx.x * 8;
+  if (c0 >= ld) return;
+  float a[8], b[8], c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool ok = c0 + e < K;
+    a[e] = ok ? ka[c0 + e] : 0.f; b[e] = ok ? kb[c0 + e] : 0.f; c[e] = ok ? kc[c0 + e] : 0.f;
+  }
+  const long r0 = (long)blockIdx.x * GH2_ROWS + threadIdx.y;
+#pragma unroll 4
+  for (int i = 0; i < GH2_ROWS / 4; ++i) {
+    const long r = r0 + 4 * i;
+    if (r >= R) break;
+    const size_t o = (size_t)r * ld + c0;
+    float gy[8], h[8], y[8];
+    unpack8(*reinterpret_cast<const u32x4*>(GY + o), gy);
+    unpack8(*reinterpret_cast<const u32x4*>(H + o), h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = __fmaf_rn(a[e], gy[e], __fmaf_rn(b[e], h[e], c[e]));
+    *reinterpret_cast<u32x4*>(GY + o) = pack8(y);
+  }
+}
+
+// grid as tn_bf16_kernel: (output tiles) x (split-K chunks), XCD-aware virtual ids.  Dynamic LDS: 2 x (64 x PA + 64 x PB) bf16.
+template <class AOp, class BOp, int WN>
+__global__ __launch_bounds__(NTB) void tn2_bf16_kernel(AOp aop, BOp bop, int M, int Nc, int N, int Bsz, int tiles_per_chunk, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BNW = 64 * WN;
+  // row pitches: 2 * pitch = 64 (mod 256) bytes, so the four rows a transposing read touches cover all 64 banks once
+  constexpr int PA = BM + 32, PB = BNW + (BNW % 128 == 0 ? 32 : 96);
+  static_assert((2 * PA) % 256 == 64 && (2 * PB) % 256 == 64, "LDS row pitch");
+  constexpr int NOA = BM / 8, RA = NTB / NOA, TA = T2_KT / RA;             // A: 16 octets x 32 row slots, 2 tasks per thread
+  constexpr int NOB = BNW / 8, RB = NTB / NOB, TB = (T2_KT + RB - 1) / RB;  // B (WN = 5): 40 octets x 12 row slots, 6 tasks
+  static_assert(T2_KT % RA == 0, "A tasks");
+  bfraw* As = reinterpret_cast<bfraw*>(smem);  // [2][64][PA]
+  bfraw* Bs = As + 2 * T2_KT * PA;             // [2][64][PB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int mt = (M + BM - 1) / BM, ntile = mt * ((Nc + BNW - 1) / BNW);
+  const int vid = xcd_virtual_id(blockIdx.x, gridDim.x), chunk = vid / ntile, tile = vid - chunk * ntile;
+  const int bm0 = (tile % mt) * BM, bn0 = (tile / mt) * BNW;
+  const int NV8 = (N + 7) / 8, ntiles = ((Bsz + 7) / 8) * NV8;
+  const int tbeg = chunk * tiles_per_chunk, tend = tbeg + tiles_per_chunk < ntiles ? tbeg + tiles_per_chunk : ntiles;
+
+  const int oa = tid % NOA, ra0 = tid / NOA, ca = bm0 + oa * 8;
+  const bool a_live = ca < aop.ld;
+  const bool b_thread = tid < NOB * RB;
+  const int ob = tid % NOB, rb0 = tid / NOB, cb = bn0 + ob * 8;
+  const bool b_live = b_thread && cb < bop.ld;
+  const typename AOp::Consts ka = aop.consts(a_live ? ca : 0);
+  const typename BOp::Consts kb = bop.consts(b_live ? cb : 0);
+  typename AOp::Raw qa[TA];
+  typename BOp::Raw qb[TB];
+
+  int cur_bg = tbeg / NV8, cur_ng = tbeg - cur_bg * NV8;  // cursor: (sample group, vertex group) of the tile to load next
+  auto fetch = [&]() {
+    const int b0 = cur_bg * 8, n0 = cur_ng * 8;
+    if (a_live) {
+#pragma unroll
+      for (int j = 0; j < TA; ++j) {
+        const int rho = ra0 + RA * j, b = b0 + (rho >> 3), n = n0 + (rho & 7);
+        aop.load(qa[j], b, n, b < Bsz && n < N, ca);
+      }
+    }
+    if (b_live) {
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int rho = rb0 + RB * j;
+        if (rho < T2_KT) {
+          const int b = b0 + (rho >> 3), n = n0 + (rho & 7);
+          bop.load(qb[j], b, n, b < Bsz && n < N, cb);
+        }
+      }
+    }
+    if (++cur_ng == NV8) { cur_ng = 0; ++cur_bg; }
+  };
+  auto stash = [&](int buf) {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+      const int rho = ra0 + RA * j;
+      *reinterpret_cast<u32x4*>(As + ((size_t)buf * T2_KT + rho) * PA + oa * 8) = a_live ? aop.fin(qa[j], ka) : zero;
+    }
+    if (b_thread) {
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int rho = rb0 + RB * j;
+        if (rho < T2_KT) *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * T2_KT + rho) * PB + ob * 8) = b_live ? bop.fin(qb[j], kb) : zero;
+      }
+    }
+  };
+
+  f32x16 acc[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int nk = tend > tbeg ? tend - tbeg : 0;
+  if (nk > 0) {
+    fetch();
+    stash(0);
+  }
+  __syncthreads();
+  // fragment addressing of the transposing reads: 16-lane group g covers channels 16 (g & 1) .. + 15 and rows 8 (g >> 1) .. + 7 of
+  // the k-step; lane j of the group points at row (j >> 2) (+ 4 for the second read) and channel quad (j & 3)
+  const int j16 = lane & 15, g16 = lane >> 4;
+  const int frow = 8 * (g16 >> 1) + (j16 >> 2), fcol = 16 * (g16 & 1) + 4 * (j16 & 3);
+  const bool wave_live = bm0 + wm * 32 < M;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) fetch();
+    if (wave_live) {
+      const bfraw* abase = As + ((size_t)cur * T2_KT + frow) * PA + wm * 32 + fcol;
+      const bfraw* bbase = Bs + ((size_t)cur * T2_KT + frow) * PB + wn * 32 * WN + fcol;
+#pragma unroll
+      for (int ks = 0; ks < T2_KT / 16; ++ks) {
+        const s16x4v a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(abase + (size_t)(ks * 16) * PA));
+        const s16x4v a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(abase + (size_t)(ks * 16 + 4) * PA));
+        const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const s16x4v b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bbase + (size_t)(ks * 16) * PB + j * 32));
+          const s16x4v b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bbase + (size_t)(ks * 16 + 4) * PB + j * 32));
+          const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+  }
+  float* dst = part + (size_t)chunk * M * Nc;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = bn0 + wn * 32 * WN + j * 32 + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = bm0 + wm * 32 + acc_row(reg, lane);
+      if (m < M && col < Nc) dst[(size_t)m * Nc + col] = acc[j][reg];
+    }
+  }
+}
