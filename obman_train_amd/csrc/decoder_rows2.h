@@ -524,7 +524,9 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
 };
 
 struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum C, S2 = sum C * xhat, xhat = (H - mean) * rstd
-  static constexpr int LDS_FLOATS = 0;
+  // H in and C out as 16-byte row pieces through 1 KB of LDS per wave (see EpiStoreB2): 8 loads + 8 stores per tile instead of
+  // 32 + 32 four-byte ones - with only 8 k-steps per tile (K = 128) this epilogue IS the kernel.
+  static constexpr int LDS_FLOATS = R2_WAVES * 256;
   bfraw* C;
   const bfraw* H;  // same pitch as C
   double* sums;    // [slots][Nc][2]
@@ -541,7 +543,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
     for (int u = 0; u < R2_SIDE; ++u) { q.e1[u] = 0.f; q.e2[u] = 0.f; }
   }
   __device__ __forceinline__ void tile(State& q, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c,
-                                       const R2Geo& geo, float*) const {
+                                       const R2Geo& geo, float* red) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     const bool odd = c.lane & 1;
     float cs[R2_NT], ct[R2_NT], cm[R2_NT], cr[R2_NT];
@@ -556,34 +558,58 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { p1[j] = 0.f; p2[j] = 0.f; }
     {
+      unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
+      // the rows this lane moves: row 16 G + (lane >> 2) of the tile, columns 8 (lane & 3) .. + 7 of each 32-column piece
+      size_t og[2];
+      bool okg[2];
+#pragma unroll
+      for (int G = 0; G < 2; ++G) {
+        int b, n; long r;
+        geo.row(c.bg, c.vt, c.wave, 16 * G + (c.lane >> 2), b, n, r, okg[G]);
+        og[G] = (size_t)r * ldc + c.c0 + (c.lane & 3) * 8;
+      }
+      u32x4 hq[R2_NT][2];  // all eight pieces of H requested up front
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j) {
+        const bool cokp = c.c0 + j * 32 + (c.lane & 3) * 8 < ldc;
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+          hq[j][G] = u32x4{0u, 0u, 0u, 0u};
+          if (okg[G] && cokp) hq[j][G] = *reinterpret_cast<const u32x4*>(H + og[G] + j * 32);
+        }
+      }
+      bool ok0[8], ok1[8];  // which rows of the tile this lane's registers hold
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const int i0 = acc_row(2 * p, c.lane);
-        int b, n; long r0; bool ok0;
-        geo.row(c.bg, c.vt, c.wave, i0, b, n, r0, ok0);
-        const bool ok1 = ok0 && n + 1 < geo.N;
-        const size_t ro = (size_t)(odd ? r0 + 1 : r0) * ldc;
-        const bool okw = odd ? ok1 : ok0;
-        unsigned hw[R2_NT];
+        int b, n; long r0;
+        geo.row(c.bg, c.vt, c.wave, acc_row(2 * p, c.lane), b, n, r0, ok0[p]);
+        ok1[p] = ok0[p] && n + 1 < geo.N;
+      }
 #pragma unroll
-        for (int j = 0; j < R2_NT; ++j) {
-          const int cl = c.c0 + j * 32 + li;
-          hw[j] = (okw && (cl & ~1) < ldc) ? *reinterpret_cast<const unsigned*>(H + ro + (cl & ~1)) : 0u;
-        }
+      for (int j = 0; j < R2_NT; ++j) {
+        const int cl = c.c0 + j * 32 + li;
+        const bool cok = cl < Nc;
+        const bool cokp = c.c0 + j * 32 + (c.lane & 3) * 8 < ldc;
 #pragma unroll
-        for (int j = 0; j < R2_NT; ++j) {
-          const int cl = c.c0 + j * 32 + li;
-          const bool cok = cl < Nc;
-          float h0, h1;
-          pair_unexchange(hw[j], odd, h0, h1);
-          const float g0 = (cok && ok0 && __fmaf_rn(cs[j], h0, ct[j]) > 0.f) ? acc[j][2 * p] : 0.f;
-          const float g1 = (cok && ok1 && __fmaf_rn(cs[j], h1, ct[j]) > 0.f) ? acc[j][2 * p + 1] : 0.f;
-          const unsigned pk = pack_bf16(g0, g1);
-          const float v0 = bf_lo(pk), v1 = bf_hi(pk);
-          p1[j] += v0 + v1;
-          p2[j] = __fmaf_rn(v0, (h0 - cm[j]) * cr[j], __fmaf_rn(v1, (h1 - cm[j]) * cr[j], p2[j]));
-          const unsigned w = pair_exchange(pk, odd);
-          if (okw && (cl & ~1) < ldc) *reinterpret_cast<unsigned*>(C + ro + (cl & ~1)) = w;
+        for (int G = 0; G < 2; ++G) {
+          *reinterpret_cast<u32x4*>(tb + (c.lane >> 2) * 16 + (c.lane & 3) * 4) = hq[j][G];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int p = 4 * G + qq;
+            // even lane: row 2p, columns (li, li + 1); odd lane: row 2p + 1, columns (li - 1, li)
+            const int rr = ((2 * qq) & 3) + 8 * ((2 * qq) >> 2) + 4 * h + (odd ? 1 : 0);
+            float h0, h1;
+            pair_unexchange(tb[rr * 16 + (li >> 1)], odd, h0, h1);
+            const float g0 = (cok && ok0[p] && __fmaf_rn(cs[j], h0, ct[j]) > 0.f) ? acc[j][2 * p] : 0.f;
+            const float g1 = (cok && ok1[p] && __fmaf_rn(cs[j], h1, ct[j]) > 0.f) ? acc[j][2 * p + 1] : 0.f;
+            const unsigned pk = pack_bf16(g0, g1);
+            const float v0 = bf_lo(pk), v1 = bf_hi(pk);
+            p1[j] += v0 + v1;
+            p2[j] = __fmaf_rn(v0, (h0 - cm[j]) * cr[j], __fmaf_rn(v1, (h1 - cm[j]) * cr[j], p2[j]));
+            tb[rr * 16 + (li >> 1)] = pair_exchange(pk, odd);
+          }
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tb + (c.lane >> 2) * 16 + (c.lane & 3) * 4);
+          if (okg[G] && cokp) *reinterpret_cast<u32x4*>(C + og[G] + j * 32) = v;
         }
       }
       if (c.last_group) {
