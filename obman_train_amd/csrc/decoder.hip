@@ -2041,7 +2041,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     if (gh_plain) {
       const int Kp = kpad16(d.C2);
       const R2Geo g2 = r2_geo(d, d.C1, 1);
-      EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
+      EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       BPlain ap{GY2, d.ld2, d.C2};
       if ((rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st, Kp))) return rc;
       if ((rc = launch_rows2<BPlain, EpiL1B2>(ap, wt, Kp, d.C1, g2, e2, st))) return rc;
@@ -2050,7 +2050,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     } else if (rows2_enabled() && r2_lds_bytes<BGradH, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C2);
       const R2Geo g2 = r2_geo(d, d.C1, 1);
-      EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.ld1, d.C1};
+      EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       if ((rc = launch_wcast(p->w2, d.C1, d.C1, d.C2, 1, wt, st, Kp))) return rc;
       if ((rc = launch_rows2<BGradH, EpiL1B2>(a, wt, Kp, d.C1, g2, e2, st))) return rc;
       l1_prow = g2.spb;

@@ -99,7 +99,7 @@ struct BPlain {
 // 4 / 8 for the bf16-stored activations
 template <class AOp> struct R2Depth { static constexpr int value = 8; };
 template <> struct R2Depth<BGridFeat> { static constexpr int value = 4; };
-template <> struct R2Depth<BGradH> { static constexpr int value = 6; };
+template <> struct R2Depth<BGradH> { static constexpr int value = 2; };  // fallback path (OBMAN_DEC_TN2=0): EpiL1B2 keeps 32 registers of state
 template <> struct R2Depth<BGridFeatPre> { static constexpr int value = 4; };
 
 // LDS floats an operand generator needs besides the weight slice (per-channel constants; the 8 Fy rows), and how it fills them
@@ -655,13 +655,18 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
 // Leftover (side) columns of the last column group: one row per lane; their vertex / sample sums go through lane exchanges.
 struct EpiL1B2 {
   float *Pp, *Qp;  // [spb][B][ld], [nbg][N][ld]
-  const float *Gx, *Fx, *gamma, *beta;
+  // the PRE-SCALED layer-1 factors of the forward pass (prescale_l1_kernel): the mask is the forward's own relu argument,
+  // Gy[n] + Fy[b] > 0.  A block's 64 samples and its columns are fixed for its whole life, so its Fy values sit in registers
+  // (16 per lane) and a tile only fetches the 4 x 4 Gy values of its vertices: 16 load instructions per tile instead of 40.
+  // Vertices beyond N read Gy's sentinel row (-3e38) and samples beyond B cache -3e38: no selects.
+  const float *Gy, *Fy;
   int ld, Nc;
   static constexpr int LDS_FLOATS = 2 * R2_WAVES * (R2_NT * 4 * 32 + R2_SIDE * 4);  // two buffers of per-wave Q partials
   struct State {
     float p[4][R2_NT];   // samples h, h+2, h+4, h+6 of the wave x column tiles
+    float fy[4][R2_NT];  // Fy of those samples at the lane's columns
     float ps[R2_SIDE];   // side columns: lanes (li % 4 == 0, h == 0) hold sample li >> 2
-    int parity;
+    int parity, ready;
   };
   __device__ __forceinline__ void init(State& s, const R2Ctx&) const {
 #pragma unroll
@@ -671,31 +676,38 @@ struct EpiL1B2 {
 #pragma unroll
     for (int t = 0; t < R2_SIDE; ++t) s.ps[t] = 0.f;
     s.parity = 0;
+    s.ready = 0;
   }
   __device__ __forceinline__ void tile(State& s, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c, const R2Geo& geo,
                                        float* red) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     float* buf = red + (size_t)s.parity * (LDS_FLOATS / 2);
     const int b0 = c.bg * 64 + c.wave * 8, n0 = c.vt * 4;
+    if (!s.ready) {  // first tile of the block (wave-uniform)
+      s.ready = 1;
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j) {
+        const int cl = c.c0 + j * 32 + li, cc = cl < ld ? cl : ld - 1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s.fy[m][j] = b0 + h + 2 * m < geo.B ? Fy[(size_t)(b0 + h + 2 * m) * ld + cc] : -3.0e38f;
+      }
+    }
     float q[R2_NT][4];
+    float gy[R2_NT][4];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) {
-      const int cl = c.c0 + j * 32 + li;
-      const bool cok = cl < Nc;
-      const int cc = cok ? cl : 0;
-      const float ga = cok ? gamma[cc] : 0.f, be = cok ? beta[cc] : 0.f;
-      float gx[4], fx[4];
+      const int cl = c.c0 + j * 32 + li, cc = cl < ld ? cl : ld - 1;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) gx[v] = (cok && n0 + v < geo.N) ? Gx[(size_t)(n0 + v) * ld + cc] : 0.f;
+      for (int v = 0; v < 4; ++v) gy[j][v] = Gy[(size_t)(n0 + v < geo.N ? n0 + v : geo.N) * ld + cc];
+    }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) fx[m] = (cok && b0 + h + 2 * m < geo.B) ? Fx[(size_t)(b0 + h + 2 * m) * ld + cc] : 0.f;
+    for (int j = 0; j < R2_NT; ++j) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) q[j][v] = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int v = r & 3, m = r >> 2;
-        const bool live = cok && n0 + v < geo.N && b0 + h + 2 * m < geo.B;
-        const float g = (live && __fmaf_rn(ga, gx[v] + fx[m], be) > 0.f) ? acc[j][r] : 0.f;
+        const float g = gy[j][v] + s.fy[m][j] > 0.f ? acc[j][r] : 0.f;  // columns beyond Nc: acc is exactly zero (zero weights)
         q[j][v] += g;
         s.p[m][j] += g;
       }
@@ -714,7 +726,7 @@ struct EpiL1B2 {
         if (t < c.nside) {
           const int col = c.c0 + R2_COLS + t;
           const bool live = n0 + v < geo.N && b0 + sm < geo.B;
-          const float y = live ? __fmaf_rn(gamma[col], Gx[(size_t)(n0 + v) * ld + col] + Fx[(size_t)(b0 + sm) * ld + col], beta[col]) : 0.f;
+          const float y = live ? Gy[(size_t)(n0 + v) * ld + col] + Fy[(size_t)(b0 + sm) * ld + col] : 0.f;
           const float g = (live && y > 0.f) ? side[t] : 0.f;
           float pv = g + __shfl_xor(g, 1, 64);  // over the sample's 4 vertices
           pv += __shfl_xor(pv, 2, 64);
