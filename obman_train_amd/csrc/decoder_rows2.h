@@ -421,7 +421,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
   const float* bias;
   double* moments;  // [slots][Nc][2] or null
   int ldc, Nc;
-  struct State {  // only what must persist across the wave's row tiles (constants are re-read per tile: L1 hits, and registers are tight)
+  struct State {  // only what must persist across the wave's row tiles (the bias is re-read per tile: the h2 kernel has no register left)
     double d1[R2_NT], d2[R2_NT];
     float e1[R2_SIDE], e2[R2_SIDE];
   };
@@ -535,25 +535,29 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
   struct State {
     double d1[R2_NT], d2[R2_NT];
     float e1[R2_SIDE], e2[R2_SIDE];
+    float cs[R2_NT], ct[R2_NT], cm[R2_NT], cr[R2_NT];  // the lane's per-column constants, fetched once per block
   };
-  __device__ __forceinline__ void init(State& q, const R2Ctx&) const {
+  __device__ __forceinline__ void init(State& q, const R2Ctx& c) const {
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { q.d1[j] = 0.0; q.d2[j] = 0.0; }
 #pragma unroll
     for (int u = 0; u < R2_SIDE; ++u) { q.e1[u] = 0.f; q.e2[u] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < R2_NT; ++j) {
+      const int col = c.c0 + j * 32 + (c.lane & 31);
+      const bool cok = col < Nc;
+      const int cc = cok ? col : 0;
+      q.cs[j] = cok ? s[cc] : 0.f; q.ct[j] = cok ? t[cc] : 0.f; q.cm[j] = cok ? mean[cc] : 0.f; q.cr[j] = cok ? rstd[cc] : 0.f;
+    }
   }
   __device__ __forceinline__ void tile(State& q, const f32x16 (&acc)[R2_NT], const float (&side)[R2_SIDE], const R2Ctx& c,
                                        const R2Geo& geo, float* red) const {
     const int li = c.lane & 31, h = c.lane >> 5;
     const bool odd = c.lane & 1;
-    float cs[R2_NT], ct[R2_NT], cm[R2_NT], cr[R2_NT];
-#pragma unroll
-    for (int j = 0; j < R2_NT; ++j) {
-      const int col = c.c0 + j * 32 + li;
-      const bool cok = col < Nc;
-      const int cc = cok ? col : 0;
-      cs[j] = cok ? s[cc] : 0.f; ct[j] = cok ? t[cc] : 0.f; cm[j] = cok ? mean[cc] : 0.f; cr[j] = cok ? rstd[cc] : 0.f;
-    }
+    const float (&cs)[R2_NT] = q.cs;
+    const float (&ct)[R2_NT] = q.ct;
+    const float (&cm)[R2_NT] = q.cm;
+    const float (&cr)[R2_NT] = q.cr;
     float p1[R2_NT], p2[R2_NT];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { p1[j] = 0.f; p2[j] = 0.f; }

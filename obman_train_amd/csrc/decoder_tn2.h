@@ -24,11 +24,15 @@ struct T2Pre {  // a1[r, c .. c+7] = relu(Gy[n] + Fy[b])  (prescale_l1_kernel; G
   struct Consts {};
   struct Raw { u32x4 g0, g1, f0, f1; };
   __device__ __forceinline__ Consts consts(int) const { return Consts{}; }
-  __device__ __forceinline__ void load(Raw& q, int b, int n, bool ok, int c0) const {
+  // same_b: the task's sample did not change since the previous k-tile (consecutive k-tiles walk the vertices of one sample
+  // group), so the Fy half of the raw operand is still in the registers
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool ok, int c0, bool same_b = false) const {
     const float* g = Gy + (size_t)(ok ? n : N) * ld + c0;
-    const float* f = Fy + (size_t)(b < B ? b : B - 1) * ld + c0;
     q.g0 = *reinterpret_cast<const u32x4*>(g); q.g1 = *reinterpret_cast<const u32x4*>(g + 4);
-    q.f0 = *reinterpret_cast<const u32x4*>(f); q.f1 = *reinterpret_cast<const u32x4*>(f + 4);
+    if (!same_b) {
+      const float* f = Fy + (size_t)(b < B ? b : B - 1) * ld + c0;
+      q.f0 = *reinterpret_cast<const u32x4*>(f); q.f1 = *reinterpret_cast<const u32x4*>(f + 4);
+    }
   }
   __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts&) const {
     const float4 g0 = r2_f4(q.g0), g1 = r2_f4(q.g1), f0 = r2_f4(q.f0), f1 = r2_f4(q.f1);
@@ -58,7 +62,7 @@ struct T2GradH {  // gh[r, c .. c+7] = ka * gy + kb * h + kc  (gy, h bf16 [R, ld
     }
     return k;
   }
-  __device__ __forceinline__ void load(Raw& q, int b, int n, bool, int c0) const {
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool, int c0, bool = false) const {
     const size_t o = ((size_t)(b < B ? b : B - 1) * N + (n < N ? n : N - 1)) * ld + c0;  // any finite row will do where the other operand is zero
     q.gy = *reinterpret_cast<const u32x4*>(GY + o);
     q.h = *reinterpret_cast<const u32x4*>(H + o);
@@ -86,7 +90,7 @@ struct T2Plain {  // operand stored as it is consumed: bf16 [R, ld] (gh2 after g
   struct Consts {};
   struct Raw { u32x4 v; };
   __device__ __forceinline__ Consts consts(int) const { return Consts{}; }
-  __device__ __forceinline__ void load(Raw& q, int b, int n, bool, int c0) const {
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool, int c0, bool = false) const {
     q.v = *reinterpret_cast<const u32x4*>(A + ((size_t)(b < B ? b : B - 1) * N + (n < N ? n : N - 1)) * ld + c0);
   }
   __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts&) const { return q.v; }
@@ -154,13 +158,16 @@ __global__ __launch_bounds__(NTB) void tn2_bf16_kernel(AOp aop, BOp bop, int M, 
   typename BOp::Raw qb[TB];
 
   int cur_bg = tbeg / NV8, cur_ng = tbeg - cur_bg * NV8;  // cursor: (sample group, vertex group) of the tile to load next
+  int last_bg = -1;
   auto fetch = [&]() {
     const int b0 = cur_bg * 8, n0 = cur_ng * 8;
+    const bool same = cur_bg == last_bg;  // block-uniform
+    last_bg = cur_bg;
     if (a_live) {
 #pragma unroll
       for (int j = 0; j < TA; ++j) {
         const int rho = ra0 + RA * j, b = b0 + (rho >> 3), n = n0 + (rho & 7);
-        aop.load(qa[j], b, n, b < Bsz && n < N, ca);
+        aop.load(qa[j], b, n, b < Bsz && n < N, ca, same);
       }
     }
     if (b_live) {
