@@ -11,7 +11,7 @@ for m in 1; do
   python3 - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if "rows2" in r["Name"] or "tn" in r["Name"][:40] or "gh2" in r["Name"] or "prescale" in r["Name"]:
+    if "rows2" in r["Name"] or "tn" in r["Name"][:40] or "gh2" in r["Name"] or "gh3" in r["Name"] or "l4_" in r["Name"] or "prescale" in r["Name"]:
         print(r["Name"][28:80], "avg %.1f us" % (float(r["AverageNs"]) / 1e3))
 PY
 done
