@@ -5,7 +5,8 @@
 // VGPRs; per-triangle constants (v0, e1, e2, pvec = dir x e2, 1/(det+1e-8) - NaN when |det| < tol so
 // every comparison fails exactly like the reference's `not parallel` factor) are computed ONCE per
 // block while staging the triangle chunk into LDS (4 x float4 per triangle, broadcast ds_read_b128),
-// then the hot loop is pure VALU (~31 lane-ops/pair).  Hit counts are integers: chunks of the
+// then the hot loop is pure VALU (round 3: the per-pair cross product folded into per-triangle
+// vectors, ~20 lane-ops/pair instead of ~31).  Hit counts are integers: chunks of the
 // triangle list handled by different blocks merge with integer atomicAdd => deterministic.
 // Same constants/inequalities as the reference (App. C #8): fixed direction, tol 1e-7, strict
 // u>0,u<1,v>0,u+v<1, t>=tol, exterior <=> even hit count.
@@ -78,26 +79,26 @@ __global__ __launch_bounds__(MC_THREADS) void contains_kernel(const float* __res
       const float det = e1x * px + e1y * py + e1z * pz;
       float inv = 1.f / (det + 0.1f * TOL);
       if (fabsf(det) < TOL) inv = __builtin_nanf("");  // parallel: every test below becomes false
-      stri[t * 4 + 0] = make_float4(ax, ay, az, inv);
-      stri[t * 4 + 1] = make_float4(e1x, e1y, e1z, 0.f);
-      stri[t * 4 + 2] = make_float4(e2x, e2y, e2z, 0.f);
-      stri[t * 4 + 3] = make_float4(px, py, pz, 0.f);
+      // The reference's v = dir . (tvec x e1) and t = e2 . (tvec x e1) are triple products: tvec . (e1 x dir) and tvec . (e1 x e2).
+      // Both cross products and the 1/det factor belong to the triangle, so the per-pair work is three 3-term dot products of
+      // tvec (was: a dot, a cross product, two dots and three multiplies - 21 -> 12 arithmetic lane-ops per pair).
+      const float wx = e1y * RAY_Z - e1z * RAY_Y, wy = e1z * RAY_X - e1x * RAY_Z, wz = e1x * RAY_Y - e1y * RAY_X;
+      const float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+      stri[t * 4 + 0] = make_float4(ax, ay, az, 0.f);
+      stri[t * 4 + 1] = make_float4(px * inv, py * inv, pz * inv, 0.f);
+      stri[t * 4 + 2] = make_float4(wx * inv, wy * inv, wz * inv, 0.f);
+      stri[t * 4 + 3] = make_float4(nx * inv, ny * inv, nz * inv, 0.f);
     }
     __syncthreads();
 #pragma unroll 2
     for (int t = 0; t < n; ++t) {
-      const float4 A = stri[t * 4], E1 = stri[t * 4 + 1], E2 = stri[t * 4 + 2], PV = stri[t * 4 + 3];
-      const float inv = A.w;
+      const float4 A = stri[t * 4], PU = stri[t * 4 + 1], PW = stri[t * 4 + 2], PN = stri[t * 4 + 3];
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const float tx = ox[k] - A.x, ty = oy[k] - A.y, tz = oz[k] - A.z;
-        const float u = dot3(tx, ty, tz, PV.x, PV.y, PV.z) * inv;
-        // qvec = tvec x e1
-        const float qx = __fmaf_rn(ty, E1.z, -(tz * E1.y));
-        const float qy = __fmaf_rn(tz, E1.x, -(tx * E1.z));
-        const float qz = __fmaf_rn(tx, E1.y, -(ty * E1.x));
-        const float v = dot3(RAY_X, RAY_Y, RAY_Z, qx, qy, qz) * inv;
-        const float tt = dot3(E2.x, E2.y, E2.z, qx, qy, qz) * inv;
+        const float u = dot3(tx, ty, tz, PU.x, PU.y, PU.z);
+        const float v = dot3(tx, ty, tz, PW.x, PW.y, PW.z);
+        const float tt = dot3(tx, ty, tz, PN.x, PN.y, PN.z);
         const bool hit = (u > 0.f) & (u < 1.f) & (v > 0.f) & (u + v < 1.f) & (tt >= TOL);
         cnt[k] += hit ? 1 : 0;
       }
