@@ -1119,9 +1119,20 @@ __global__ __launch_bounds__(256) void l4_fwd_kernel(const HT* __restrict__ H3, 
     w0[j] = ok ? W4[c] : 0.f; w1[j] = ok ? W4[C3 + c] : 0.f; w2[j] = ok ? W4[2 * C3 + c] : 0.f;
   }
   const int cl = c0 + 4 <= ld3 ? c0 : 0;  // ld3 is a multiple of 16: a lane's four channels are inside the pitch or wholly masked
-  for (long r = r0; r < R; r += stride) {
-    float h[4];
-    ld4act(H3 + (size_t)r * ld3 + cl, h);
+  // four rows per step, every load issued before the first use (one 8- or 16-byte load in flight per lane left this pass at
+  // 2.5 TB/s); rows are still finished in their original order
+  for (long rq = r0; rq < R; rq += 4 * stride) {
+    float hq[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = rq + u * stride;
+      ld4act(H3 + (size_t)(rr < R ? rr : rq) * ld3 + cl, hq[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+    const long r = rq + u * stride;
+    if (r >= R) break;
+    const float (&h)[4] = hq[u];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1137,6 +1148,7 @@ __global__ __launch_bounds__(256) void l4_fwd_kernel(const HT* __restrict__ H3, 
       out[r * 3] = f * (a0 + b4[0]);
       out[r * 3 + 1] = f * (a1 + b4[1]);
       out[r * 3 + 2] = f * (a2 + b4[2]);
+    }
     }
   }
 }
@@ -1165,10 +1177,19 @@ __global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G
   const int cl = c + 2 <= ld3 ? c : 0;
   double S1[2] = {0, 0}, S2[2] = {0, 0};
   float ga[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb[3] = {0.f, 0.f, 0.f};
-  for (long r = rbeg + half; r < rend; r += 2) {
-    const float g0 = f * G[r * 3], g1 = f * G[r * 3 + 1], g2 = f * G[r * 3 + 2];
-    float h[2];
-    ld2act(H3 + (size_t)r * ld3 + cl, h[0], h[1]);
+  for (long rq = rbeg + half; rq < rend; rq += 8) {  // four rows per step, loads first (rows finish in their original order)
+    float gq[4][3], hq[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = rq + 2 * u < rend ? rq + 2 * u : rq;
+      gq[u][0] = G[rr * 3]; gq[u][1] = G[rr * 3 + 1]; gq[u][2] = G[rr * 3 + 2];
+      ld2act(H3 + (size_t)rr * ld3 + cl, hq[u][0], hq[u][1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+    if (rq + 2 * u >= rend) break;
+    const float g0 = f * gq[u][0], g1 = f * gq[u][1], g2 = f * gq[u][2];
+    const float (&h)[2] = hq[u];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float y = __fmaf_rn(cs[e], h[e], ct[e]);
@@ -1179,6 +1200,7 @@ __global__ __launch_bounds__(128) void l4_bwd_kernel(const float* __restrict__ G
       ga[e][0] = __fmaf_rn(g0, a, ga[e][0]); ga[e][1] = __fmaf_rn(g1, a, ga[e][1]); ga[e][2] = __fmaf_rn(g2, a, ga[e][2]);
     }
     gb[0] += g0; gb[1] += g1; gb[2] += g2;
+    }
   }
   __shared__ double sd[64][4];
   __shared__ float sf[64][9];
