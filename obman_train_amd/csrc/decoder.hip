@@ -2003,7 +2003,11 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sp, srows, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2], g->bn_b[2],
                                                                  g->b3, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
-  {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
+  if (tn2_enabled() && wide_wn(d.C2) == 5 && (d.ld3 & 7) == 0 && (d.ld2 & 7) == 0) {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
+    T2GradH3 ta{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3, d.N, d.B};
+    T2BnRelu tb{H2, ws + w.s2, ws + w.t2, d.ld2, d.C2, d.N, d.B};
+    if ((rc = launch_tn2_bf16<T2GradH3, T2BnRelu>(ta, tb, d.C3, d.C2, d.N, d.B, ws2 + v.tn, g->w3, d.C2, 0, st, 0))) return rc;
+  } else {
     TGradH3 ta{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
     TBnRelu tb{H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
     if ((rc = launch_tn_bf16<TGradH3, TBnRelu>(ta, tb, d.C3, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;

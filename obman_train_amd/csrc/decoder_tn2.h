@@ -96,6 +96,78 @@ struct T2Plain {  // operand stored as it is consumed: bf16 [R, ld] (gh2 after g
   __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts&) const { return q.v; }
 };
 
+struct T2BnRelu {  // a[r, c .. c+7] = relu(s * h + t), h bf16 [R, ld]; s = t = 0 beyond K
+  const bfraw* H;
+  const float *s, *t;
+  int ld, K, N, B;
+  struct Consts { float s[8], t[8]; };
+  struct Raw { u32x4 h; };
+  __device__ __forceinline__ Consts consts(int c0) const {
+    Consts k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = c0 + e < K;
+      k.s[e] = ok ? s[c0 + e] : 0.f; k.t[e] = ok ? t[c0 + e] : 0.f;
+    }
+    return k;
+  }
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool, int c0, bool = false) const {
+    q.h = *reinterpret_cast<const u32x4*>(H + ((size_t)(b < B ? b : B - 1) * N + (n < N ? n : N - 1)) * ld + c0);
+  }
+  __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts& k) const {
+    float h[8];
+    unpack8(q.h, h);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x2v y = __builtin_elementwise_fma(f32x2v{k.s[2 * e], k.s[2 * e + 1]}, f32x2v{h[2 * e], h[2 * e + 1]}, f32x2v{k.t[2 * e], k.t[2 * e + 1]});
+      w[e] = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2)));
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+  }
+};
+
+// gh3[r, o] = (s*h3 + t > 0 ? f g[r, :] . W4[:, o] : 0) * ka + kb * h3 + kc, from the 3-channel output gradient g (TGradH3's
+// operation order).  The A operand of the layer-3 weight gradient: rows outside the problem are zeroed here.
+struct T2GradH3 {
+  const float *G, *W4;
+  const bfraw* H;
+  const float *s, *t, *ka, *kb, *kc_;
+  float f;
+  int ld, K, N, B;
+  struct Consts { float s[8], t[8], a[8], b[8], c[8], w0[8], w1[8], w2[8]; };
+  struct Raw { u32x4 h; float g0, g1, g2; bool ok; };
+  __device__ __forceinline__ Consts consts(int c0) const {
+    Consts k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = c0 + e < K;
+      const int cc = ok ? c0 + e : 0;
+      k.s[e] = ok ? s[cc] : 0.f; k.t[e] = ok ? t[cc] : 0.f; k.a[e] = ok ? ka[cc] : 0.f; k.b[e] = ok ? kb[cc] : 0.f; k.c[e] = ok ? kc_[cc] : 0.f;
+      k.w0[e] = ok ? W4[cc] : 0.f; k.w1[e] = ok ? W4[K + cc] : 0.f; k.w2[e] = ok ? W4[2 * K + cc] : 0.f;
+    }
+    return k;
+  }
+  __device__ __forceinline__ void load(Raw& q, int b, int n, bool ok, int c0, bool = false) const {
+    const size_t r = (size_t)(b < B ? b : B - 1) * N + (n < N ? n : N - 1);
+    q.h = *reinterpret_cast<const u32x4*>(H + r * ld + c0);
+    q.g0 = G[r * 3]; q.g1 = G[r * 3 + 1]; q.g2 = G[r * 3 + 2];
+    q.ok = ok;
+  }
+  __device__ __forceinline__ u32x4 fin(const Raw& q, const Consts& k) const {
+    float h[8], y[8];
+    unpack8(q.h, h);
+    const float g0 = f * q.g0, g1 = f * q.g1, g2 = f * q.g2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gy = __fmaf_rn(k.s[e], h[e], k.t[e]) > 0.f ? (g0 * k.w0[e] + g1 * k.w1[e] + g2 * k.w2[e]) : 0.f;
+      y[e] = __fmaf_rn(k.a[e], gy, __fmaf_rn(k.b[e], h[e], k.c[e]));
+    }
+    const u32x4 v = pack8(y);
+    return q.ok ? v : u32x4{0u, 0u, 0u, 0u};
+  }
+};
+
 // gh2 = ka * gy2 + kb * h2 + kc, rounded to bf16 exactly as the operand generators of the two GEMMs that consume it did on the
 // fly (dA re-generated it once per column group = 4 times, dW2 once per output tile = 5 times); IN PLACE over gy2, which has no
 // other reader.  One thread = 8 channels of a row.

@@ -1,5 +1,9 @@
 #!/bin/bash
-# GPU box: epilogue ablations of the rows2 kernels (variant libraries built with -DR2_EPI_ABL=n, measurement only)
+# GPU box: epilogue ablations of the rows2 kernels (variant libraries built with -DR2_EPI_ABL=n, measurement only).
+# Build the variants first, in the container (they travel with the snapshot; csrc/build/ is git-ignored):
+#   cd obman_train_amd/csrc && mkdir -p build/variants && for v in 1 2 3; do
+#     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DR2_EPI_ABL=$v -c decoder.hip -o build/variants/decoder_$v.o
+#     hipcc --offload-arch=gfx950 -fPIC -shared -o build/variants/lib_$v.so $(ls build/*.o | grep -v build/decoder.o) build/variants/decoder_$v.o; done
 cd /tmp && export TMPDIR=/tmp
 L=$GRAFT_REPO_ROOT/obman_train_amd/csrc
 cp $L/libobman_hip.so /tmp/lib_0.so
