@@ -1823,6 +1823,8 @@ int device_cus() {
   }
   return n;
 }
+// the rows2 generators address their bf16 operands ([R, ld2] is the largest) with 32-bit byte offsets into a buffer descriptor
+bool r2_addr32(const Dims& d) { return (size_t)d.R * d.ld2 * sizeof(bfraw) <= R2_PLAIN_MAX_BYTES && (size_t)d.R * d.ld3 * sizeof(bfraw) <= R2_PLAIN_MAX_BYTES; }
 bool rows2_enabled() {
   static const int on = [] { const char* e = getenv("OBMAN_DEC_ROWS2"); return e ? atoi(e) : 1; }();  // A/B knob
   return on != 0;
@@ -1924,7 +1926,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     prescale_l1_kernel<<<obman_cdiv((long)(d.N + 1 + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
                                                                                       d.C1, ws + w.Gy, ws + w.Fy);
     OBMAN_LAUNCH_CHECK();
-    if (rows2_enabled() && r2_lds_bytes<BGridFeatPre, EpiStoreB2>(kpad16(d.C1), r2_geo(d, d.C2, 2)) <= R2_LDS_LIMIT) {
+    if (rows2_enabled() && r2_addr32(d) && r2_lds_bytes<BGridFeatPre, EpiStoreB2>(kpad16(d.C1), r2_geo(d, d.C2, 2)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C1);
       // rows as (8 samples x 4 vertices) per wave: a load instruction touches 4 rows of the layer-1 grid factor and 8 of the
       // feature factor instead of 32 + 1 (the fp32 factors go through the texture path 64 B per clock and CU),
@@ -1951,7 +1953,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb3);
     const double* mom = moments;
     int mrows;
-    if (rows2_enabled() && r2_lds_bytes<BBnRelu, EpiStoreB2>(kpad16(d.C2), r2_geo(d, d.C3)) <= R2_LDS_LIMIT) {
+    if (rows2_enabled() && r2_addr32(d) && r2_lds_bytes<BBnRelu, EpiStoreB2>(kpad16(d.C2), r2_geo(d, d.C3)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C2);
       const R2Geo g2 = r2_geo(d, d.C3);
       EpiStoreB2 e2{H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
@@ -2016,7 +2018,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     BGradH3 a{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
     EpiMaskB e{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
     bfraw* wt = reinterpret_cast<bfraw*>(ws2 + v.wt3);
-    if (rows2_enabled() && r2_lds_bytes<BGradH3, EpiMaskB2>(kpad16(d.C3), r2_geo(d, d.C2)) <= R2_LDS_LIMIT) {
+    if (rows2_enabled() && r2_addr32(d) && r2_lds_bytes<BGradH3, EpiMaskB2>(kpad16(d.C3), r2_geo(d, d.C2)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C3);
       const R2Geo g2 = r2_geo(d, d.C2);
       EpiMaskB2 e2{GY2, H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
@@ -2035,6 +2037,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
                                                                  g->b2, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
   const bool gh_plain = tn2_enabled() && wide_wn(d.C2) == 5 && rows2_enabled() && (d.ld2 & 7) == 0 && d.ld2 <= 512 &&
+                        (size_t)d.R * d.ld2 * sizeof(bfraw) <= R2_PLAIN_MAX_BYTES &&
                         r2_lds_bytes<BPlain, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT;
   {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c], formed TRANSPOSED (M = the 515 channels of a1, one 320-wide tile for the 257 of gh2):
      // every operand is regenerated once per tile of the OTHER operand, and a1 (fp32 factors, add + fma + max per element) is the
@@ -2073,7 +2076,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
       if ((rc = launch_rows2<BPlain, EpiL1B2>(ap, wt, Kp, d.C1, g2, e2, st))) return rc;
       l1_prow = g2.spb;
       l1_groups = g2.nbg;
-    } else if (rows2_enabled() && r2_lds_bytes<BGradH, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT) {
+    } else if (rows2_enabled() && r2_addr32(d) && r2_lds_bytes<BGradH, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C2);
       const R2Geo g2 = r2_geo(d, d.C1, 1);
       EpiL1B2 e2{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};

@@ -84,6 +84,7 @@ struct BGridFeatPre {
 
 // A operand stored as it is consumed: bf16 [R, ld] (gh2 after gh2_inplace_kernel).  Rows outside the problem are addressed beyond
 // the buffer's range - the hardware bounds check returns zeros, so there is neither a transform nor a select.
+constexpr size_t R2_PLAIN_MAX_BYTES = 0xffff0000ull;  // BPlain addresses its operand with 32-bit byte offsets and masks rows with 0xffffff00
 struct BPlain {
   const bfraw* A;
   int ld, K;
@@ -190,8 +191,10 @@ struct R2Src<BPlain> {
   struct Off { unsigned o; };
   __device__ __forceinline__ void init(const BPlain& op, const R2Geo& geo) { ra = r2_rsrc(op.A, (size_t)geo.R * op.ld * 2); }
   __device__ __forceinline__ Off off(const BPlain& op, long r, int, int, int h) const { return Off{(unsigned)(((size_t)r * op.ld + h * 8) * 2)}; }
+  // The per-lane offset alone decides the range check of a raw buffer load (the scalar k offset is not part of it): 0xffffff00 is
+  // beyond every buffer this path accepts (R2_PLAIN_MAX_BYTES, checked by the host - the configs[4] operand is 2.2 GB).
   __device__ __forceinline__ Off off_masked(const BPlain& op, long r, int h, bool ok) const {
-    return Off{ok ? (unsigned)(((size_t)r * op.ld + h * 8) * 2) : 0x7ffffff0u};  // beyond num_records whatever the scalar offset adds
+    return Off{ok ? (unsigned)(((size_t)r * op.ld + h * 8) * 2) : 0xffffff00u};
   }
   __device__ __forceinline__ void load(BPlain::Raw& q, const Off& o, int s) const { q.v = r2_ld16(ra, o.o, s * 32); }
 };
