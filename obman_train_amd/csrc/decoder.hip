@@ -1863,6 +1863,7 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
     if (err != hipSuccess) return (int)err;
     granted[dev].store((int)lds, std::memory_order_relaxed);
   }
+#ifdef OBMAN_ABLATION  // tools/ablate_gemm.sh build: the product library holds no measurement-only kernel
   if constexpr (std::is_same<AOp, BGridFeatPre>::value) {
     // measurement-only ablations of the k loop (wrong results; tools/r03_abl.sh): where does a k-step's time go?
     static const int abl = [] { const char* v = getenv("OBMAN_R2_ABL"); return v ? atoi(v) : 0; }();
@@ -1900,6 +1901,7 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
       return 0;
     }
   }
+#endif
   rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, aop_floats);
   OBMAN_LAUNCH_CHECK();
   return 0;

@@ -789,11 +789,16 @@ struct EpiL1B2 {
 // grid = ngroups * slots blocks (1-D, XCD-aware virtual ids: the column groups of one slot are neighbours on one XCD - they
 // stream the same activation rows).  Dynamic LDS: weight slice [(R2_COLS + geo.wside)][Kp + 8] bf16, then the generator's
 // per-channel constants [AOp::NC][Kp] fp32.
-// ABL != 0: measurement-only variants (tools/r03_abl.sh, OBMAN_R2_ABL; wrong results): 1 no operand requests inside the k loop,
+// ABL != 0: measurement-only variants, instantiated only with -DOBMAN_ABLATION (tools/ablate_gemm.sh build, then tools/r03_abl.sh /
+// tools/r03_dbg.sh with OBMAN_R2_ABL; wrong results): 1 no operand requests inside the k loop,
 // 2 weight fragments read once, 3 no epilogue, 4 no MFMAs, 5 = 2 + the generator's LDS constants read once
 // ABL == 8: s_memtime stamps inside the k-step of every wave (LDS phase / transform + operand wait / MFMA issue / rest / epilogue),
 // summed per wave into r2_dbg[block][wave][8] - printed by launch_rows2 (measurement only; the stamps serialise the phases)
+#ifdef OBMAN_ABLATION
 __device__ unsigned long long r2_dbg[1024 * R2_WAVES * 8];
+#else
+__device__ unsigned long long* const r2_dbg = nullptr;  // the ABL == 8 variant is never instantiated in the product build
+#endif
 template <class AOp, class Epi, int ABL = 0>
 __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const bfraw* __restrict__ Wb, int Kp, int Nc, Epi epi, R2Geo geo,
                                                                  int lds_aop_floats) {
