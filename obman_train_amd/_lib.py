@@ -100,8 +100,32 @@ def lib():
     got = handle.obman_abi_version()
     if got != ABI_VERSION:
         raise ObmanHipError("libobman_hip.so ABI %d != expected %d - rebuild" % (got, ABI_VERSION))
+    if os.environ.get("OBMAN_TRACE_LAUNCH", "0") not in ("", "0"):
+        _trace_launches(handle)
     _lib = handle
     return _lib
+
+
+def _trace_launches(handle):
+    """Debug mode (OBMAN_TRACE_LAUNCH=1, used by tools/efence): every kernel launcher writes its name to stderr before it
+    runs and waits for the device afterwards, so a GPU memory fault is attributed to the launch that caused it."""
+    import sys
+
+    import torch
+
+    def wrap(name, fn):
+        def traced(*args):
+            sys.stderr.write("[obman-launch] %s\n" % name)
+            sys.stderr.flush()
+            status = fn(*args)
+            torch.cuda.synchronize()
+            return status
+
+        return traced
+
+    for name, (res, args) in _SIGNATURES.items():
+        if res is _c_int and args.endswith("p") and len(args) > 3:  # launchers: int status, last argument = the stream
+            setattr(handle, name, wrap(name, getattr(handle, name)))
 
 
 def check(status, what):

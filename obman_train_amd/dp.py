@@ -169,8 +169,12 @@ class GradientBuckets:
             if p not in self._seen or p.grad is None:
                 p.grad = torch.zeros_like(p)
                 self._missing.append(p)
-            elif not (p.grad.is_contiguous() or (p.grad.dim() == 4 and p.grad.is_contiguous(memory_format=torch.channels_last))):
-                p.grad = p.grad.contiguous()
+            elif p.grad.stride() != p.stride():
+                # RCCL reduces raw memory: every rank must hand over the SAME element order.  The zero contribution above is
+                # laid out like the parameter, so the produced gradient is normalised to the parameter's strides too (autograd
+                # normally does that already; a contiguous gradient for a channels_last filter would otherwise be averaged
+                # element-permuted against another rank's zeros)
+                p.grad = torch.empty_like(p).copy_(p.grad)
             if not self._no_reduce:
                 self._works.append((b, dist.all_reduce(p.grad, op=op, group=self.group, async_op=True)))
             return

@@ -41,6 +41,25 @@ def make_optimizer(model, name="adam", lr=1e-4, momentum=0.9, weight_decay=0.0, 
     raise ValueError(name)
 
 
+def _same_entry(a, b):
+    """Equality of two non-tensor sample entries (lists of strings, numpy arrays, scalars, None)."""
+    if a is b:
+        return True
+    if a is None or b is None:
+        return False
+    try:
+        import numpy as np
+
+        if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+            return np.array_equal(np.asarray(a), np.asarray(b))
+    except ImportError:
+        pass
+    try:
+        return bool(a == b)
+    except (ValueError, RuntimeError):  # "truth value of an array is ambiguous"
+        return False
+
+
 class GraphedTrainStep:
     """One training step (forward -> zero_grad -> backward -> optimizer.step) recorded ONCE into a hipGraph and replayed.
 
@@ -57,16 +76,25 @@ class GraphedTrainStep:
     batch into the static input buffers and replays.  Outputs are static tensors overwritten by every replay (clone what must
     survive).  Not for the data-parallel path: the bucket hooks issue collectives from Python.
 
+    Side effect of construction: the ``warmup`` eager steps and the capture pass are REAL train steps on the capture batch
+    (``warmup`` optimizer updates, BatchNorm running statistics, Adam step counters move; the capture pass itself only
+    records).  A training loop that must not see them passes ``restore_state=True``: model and optimizer state are
+    snapshotted before the warm-up and copied back (in place - the recorded kernels keep their addresses) after the capture.
+
     ROCm 7.0 caveat (measured, tools/graph_probe.py): ``hipGraphInstantiate`` segfaults at the end of the capture while the
     OUTPUTS of an earlier eager step (loss tensor, results dict - and through them their autograd nodes) are still referenced.
     Drop them before constructing this object (``bench.py`` does); the constructor collects garbage first."""
 
-    def __init__(self, model, optimizer, sample, warmup=3):
+    def __init__(self, model, optimizer, sample, warmup=3, restore_state=False):
+        import copy
         import gc
 
         gc.collect()
         dev = next(model.parameters()).device
         self.model, self.optimizer = model, optimizer
+        snapshot = None
+        if restore_state:
+            snapshot = ({k: v.detach().clone() for k, v in model.state_dict().items()}, copy.deepcopy(optimizer.state_dict()))
         self.static = {k: (v.detach().to(dev).clone(memory_format=torch.preserve_format) if torch.is_tensor(v) else v)
                        for k, v in sample.items()}
         self._fixed = {k: v for k, v in sample.items() if not torch.is_tensor(v)}
@@ -80,13 +108,33 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.total, self.results, self.losses = train_step(model, optimizer, self.static)
+        if snapshot is not None:
+            with torch.no_grad():
+                live = model.state_dict()
+                for k, v in snapshot[0].items():
+                    live[k].copy_(v)
+                # in place as well: capturable Adam's exp_avg / exp_avg_sq / step tensors are addresses inside the graph
+                saved = snapshot[1]["state"]
+                order = [p for g in optimizer.param_groups for p in g["params"]]
+                for idx, p in enumerate(order):
+                    cur = optimizer.state.get(p, {})
+                    old = saved.get(idx)
+                    for name, t in cur.items():
+                        if not torch.is_tensor(t):
+                            continue
+                        if old is not None and name in old:
+                            t.copy_(old[name])
+                        else:  # state created by the warm-up itself (first step of a fresh optimizer): back to its initial value
+                            t.zero_()
 
     def __call__(self, sample):
         for k, v in sample.items():
             if torch.is_tensor(v):
                 self.static[k].copy_(v, non_blocking=True)
-            elif self._fixed.get(k) != v:
-                raise ValueError("GraphedTrainStep: the non-tensor entry %r differs from the captured batch (%r != %r); "
-                                 "capture one graph per layout" % (k, v, self._fixed.get(k)))
+            elif not _same_entry(self._fixed.get(k), v):
+                raise ValueError("GraphedTrainStep: the non-tensor entry %r differs from the captured batch (%r != %r).  A "
+                                 "recorded step replays the kernels of ONE batch layout - the hand-side split (`sides`) and "
+                                 "every other host-side entry decide which kernels run and on how many rows - so every batch "
+                                 "must carry the captured values; capture one graph per layout" % (k, v, self._fixed.get(k)))
         self.graph.replay()
         return self.total, self.results, self.losses
