@@ -27,6 +27,13 @@ HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3      # fp32 vector peak (the bound that actually binds the pair-min kernel)
 
 
+def _say(msg):
+    """Progress marker on stderr (OBMAN_BENCH_TRACE=1): where a run died when it leaves no JSON line."""
+    if os.environ.get("OBMAN_BENCH_TRACE", "0") not in ("", "0"):
+        sys.stderr.write("[bench] %s\n" % msg)
+        sys.stderr.flush()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -418,8 +425,9 @@ def main():
             h0 = time.perf_counter()
             last = graphed(sample) if graphed is not None else train_step(model, opt, sample, buckets)
             evs[i + 1].record()
-            if sync_each:
+            if sync_each or os.environ.get("OBMAN_BENCH_SYNC_EACH"):  # debugging aid: which step of a phase dies
                 evs[i + 1].synchronize()
+                _say("%s step %d done" % (name, i))
             host.append((time.perf_counter() - h0) * 1e3)
         return evs, host, last
 
@@ -445,6 +453,7 @@ def main():
         if settled:
             break
 
+    _say("precondition done: %d steps" % precondition_steps)
     if args.graph:
         from obman_train_amd.trainer import GraphedTrainStep
 
@@ -454,10 +463,20 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         graphed = GraphedTrainStep(model, opt, sample, warmup=2)
+        _say("graph captured")
     evs, host, _ = run_phase("warmup", args.warmup)
     torch.cuda.synchronize()
+    _say("warmup done")
     close_phase("warmup", evs, host)
     _lib.prof_enable(not args.graph)
+    if os.environ.get("OBMAN_BENCH_MEMSNAP"):  # debugging aid: the allocator's segment map right before the timed region
+        segs = [{"address": sg["address"], "total_size": sg["total_size"], "allocated_size": sg["allocated_size"],
+                 "segment_pool_id": list(sg.get("segment_pool_id", (0, 0))), "stream": sg.get("stream"),
+                 "blocks": [(b["address"] if "address" in b else None, b["size"], b["state"]) for b in sg["blocks"]]}
+                for sg in torch.cuda.memory_snapshot()]
+        with open(os.environ["OBMAN_BENCH_MEMSNAP"], "w") as fh:
+            json.dump(segs, fh)
+        _say("memory snapshot written: %d segments" % len(segs))
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -468,6 +487,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    _say("timed region done")
     step_gpu_ms = sorted(close_phase("timed", evs, host))
     loss_val = float(total)
     pm_ms, pm_n = _lib.prof_summary(10)  # ChamferLoss forward launches only (csrc/prof.h; 1 = the hand<->object closest-vertex launches)
@@ -571,9 +591,13 @@ def main():
                            "distinct_devices": len({(r["hostname"], r["pci_bus_id"] or r["device_uuid"] or r["device_index"])
                                                     for r in ranks_info})}
         if world == 1:
+            _say("chamfer_throughput_probe")
             roof["throughput_bound_point"] = chamfer_throughput_probe(args.batch)
+            _say("input_stream_probe")
             out["input_stream"] = input_stream_probe(args.batch, args.image_size)
+            _say("pcie_inclusive_probe")
             out["pcie_inclusive"] = pcie_inclusive_probe(model, opt, sample, args.batch, args.image_size, train_step)
+            _say("probes done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size, args.config)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -56,3 +56,25 @@ __device__ __forceinline__ float obman_wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
+
+// Stream-ordered fill of `n_words` 32-bit words - instead of hipMemsetAsync.  A memset issued inside a stream capture becomes a
+// hipGraph MEMSET node; replays of the captured training step (trainer.GraphedTrainStep) at configs[2] died with GPU memory
+// faults a few replays in (profiles/r04_graph_fault.md), a graph whose only nodes are kernels does not.  16 bytes per lane.
+static __global__ void obman_fill_u32_kernel(unsigned* __restrict__ p, unsigned v, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    if ((reinterpret_cast<size_t>(p + i) & 15) == 0) {
+      *reinterpret_cast<uint4*>(p + i) = make_uint4(v, v, v, v);
+    } else {
+      p[i] = v; p[i + 1] = v; p[i + 2] = v; p[i + 3] = v;
+    }
+  } else {
+    for (size_t k = i; k < n; ++k) p[k] = v;
+  }
+}
+static inline hipError_t obman_fill_u32(void* p, unsigned v, size_t n_words, hipStream_t st) {
+  if (n_words == 0) return hipSuccess;
+  const size_t blocks = (n_words + 1023) / 1024;
+  obman_fill_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(static_cast<unsigned*>(p), v, n_words);
+  return hipGetLastError();
+}

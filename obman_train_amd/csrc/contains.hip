@@ -130,7 +130,7 @@ int contains_launch(const float* points, const float* verts, const int* faces, i
   if (B < 0 || P < 0 || Nv <= 0 || F < 0 || !hits) return -1;
   if (group_faces < 0 || (group_faces > 0 && (F % group_faces != 0 || F / group_faces > 32))) return -1;
   if (B == 0 || P == 0) return 0;
-  if (F == 0) return (int)hipMemsetAsync(hits, 0, sizeof(int) * (size_t)B * P, st);
+  if (F == 0) return (int)obman_fill_u32(hits, 0u, (size_t)B * P, st);
   int ppt = 4;
   while (ppt > 1 && MC_THREADS * (ppt / 2) >= P) ppt >>= 1;  // smallest PPT whose tile still covers P
   if (P > MC_THREADS * 4) ppt = 4;
@@ -146,7 +146,7 @@ int contains_launch(const float* points, const float* verts, const int* faces, i
   int tchunk = obman_cdiv(obman_cdiv(F, tsplit), 64) * 64;
   tsplit = obman_cdiv(F, tchunk);
   if (tsplit > 1) {
-    hipError_t e = hipMemsetAsync(hits, 0, sizeof(int) * (size_t)B * P, st);
+    hipError_t e = obman_fill_u32(hits, 0u, (size_t)B * P, st);
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid(ptiles * tsplit, B);

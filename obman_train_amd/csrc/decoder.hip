@@ -1566,6 +1566,11 @@ Dims dims_of(const obman_pointgen_params* p) {
 constexpr int L4_ROWS = 32;   // rows per block of the layer-4 backward (1284 blocks at 64 x 642 points)
 constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gradient GEMMs
 
+// The branch-free k loop of the rows2 kernels (decoder_rows2.h) requests up to R2Depth k-steps past the end of a row; for the
+// LAST row of an operand that is up to 8 x 64 bytes past the end of its array, and the scalar k offset of a raw buffer load is not
+// part of the hardware range check.  Every operand lives inside one of the two arenas below and is followed by other arrays, so
+// those (never consumed) reads stay inside the arena; the tail padding keeps that true whatever the order of the arrays.
+constexpr long WS_TAIL_FLOATS = 256;  // 1 KB
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
   long Gx, Fx, Gy, Fy, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
@@ -1583,7 +1588,7 @@ FwdWs fwd_ws(const Dims& d) {
   w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
   w.Gy = take(d.bf16 ? (long)(d.N + 1) * d.ld1 : 0);  // pre-scaled layer-1 factors of the bf16 forward (prescale_l1_kernel)
   w.Fy = take(d.bf16 ? (long)d.B * d.ld1 : 0);
-  w.total = o;
+  w.total = o + WS_TAIL_FLOATS;
   return w;
 }
 // rows per split-K chunk of the fp32 weight-gradient kernel.  768 block slots (256 CUs x 3 blocks of 49.7 KB LDS): aim at just
@@ -1674,7 +1679,7 @@ BwdWs bwd_ws(const Dims& d) {
   }
   w.wt2 = take(d.bf16 ? ((long)d.C1 * kpad(d.C2) + 1) / 2 : 0);  // bf16 [C1][kpad(C2)] image of W2^T (dA GEMM of layer 2)
   w.wt3 = take(d.bf16 ? ((long)d.C2 * kpad(d.C3) + 1) / 2 : 0);
-  w.total = o;
+  w.total = o + WS_TAIL_FLOATS;
   return w;
 }
 

@@ -126,7 +126,9 @@ template <> struct R2Lds<BGridFeatPre> {
 // per-lane byte offset fixed for the whole row tile (row start + the lane half's 8 k), and the k-step as the instruction's
 // SCALAR offset - no per-load 64-bit address arithmetic and no clamping on the VALU (the flat-load version spent ~16 of its
 // ~100 instructions per k-step on it).  Reads past the last k-step of a row land in the next row (finite values, never
-// consumed: only issued to keep the loop branch-free); reads past the end of the array return zeros (hardware bounds check).
+// consumed: only issued to keep the loop branch-free).  The hardware range check covers the PER-LANE offset only (not the
+// scalar k offset): the requests past the last row of an array land in whatever follows it in the workspace arena - never
+// consumed either; fwd_ws / bwd_ws (decoder.hip) end with WS_TAIL_FLOATS of padding so that this is always inside the arena.
 // The transforms are the B* generators' own fin().
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t r2_rsrc(const void* p, size_t bytes) {
   // uniformity made PROVABLE (readfirstlane on the inputs): under SGPR pressure hipcc parks the descriptor in VGPRs and then

@@ -281,7 +281,7 @@ extern "C" int obman_imgstream_fwd(const uint8_t* src, int B, int pitch_h, int p
     OBMAN_LAUNCH_CHECK();
   }
   if (any_contrast) {
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * sizeof(u64), stream);
+    hipError_t e = obman_fill_u32(sums, 0u, (size_t)2 * B, stream);
     if (e != hipSuccess) return (int)e;
     const int blocks = min(pitch_h, 64);  // rows are dealt round-robin to the blocks of a sample
     hipLaunchKernelGGL(mean_kernel, dim3(blocks, B), dim3(256), 0, stream, src, blurred, params, pitch_h, pitch_w, sums);

@@ -729,8 +729,8 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   plan_dir(d1, B, q1, have_ws);
   if (d0.rsplit > 1) d0.ws = (u64*)ws;
   if (d1.rsplit > 1) d1.ws = (u64*)ws + (size_t)B * Nx;
-  if (d0.rsplit > 1) (void)hipMemsetAsync(d0.ws, 0xff, sizeof(u64) * (size_t)B * Nx, st);
-  if (d1.rsplit > 1) (void)hipMemsetAsync(d1.ws, 0xff, sizeof(u64) * (size_t)B * Ny, st);
+  if (d0.rsplit > 1) (void)obman_fill_u32(d0.ws, 0xffffffffu, (size_t)2 * B * Nx, st);
+  if (d1.rsplit > 1) (void)obman_fill_u32(d1.ws, 0xffffffffu, (size_t)2 * B * Ny, st);
   // LDS reference tile (points per staging pass); OBMAN_PM_TILE overrides the 2048-point cap for the tile sweep of
   // BASELINE.json configs[4] (multiples of 16, <= 3072 so that tile + merge buffers stay under 64 KiB)
   static const int tile_cap = [] {

@@ -55,11 +55,12 @@ class PointGenCon(nn.Module):
 
         The only tensor the reference ever passes here is the concatenation it builds in ``atlasbranch.py:117-132`` /
         ``:92-101``: rows 0..2 = the sphere points, rows 3.. = the image feature repeated for every point.  On a ROCm tensor
-        that layout is recognised (one device-side comparison, one host read - this entry point is not on the training path,
-        ``AtlasBranch`` calls ``decode``) and routed to the fused HIP decoder with the points as a per-sample grid; the
+        that layout is recognised (one device-side comparison over [B,C-3,N] and ONE device->host read per call, i.e. a
+        stream synchronisation - this entry point is not on the training path, ``AtlasBranch`` calls ``decode``) and routed to the fused HIP decoder with the points as a per-sample grid; the
         result is transposed back to [B,3,N].  Any other input (features that vary along N) cannot be factorised and takes
         the stock ops below - with a one-time warning, so leaving the fused path is never silent."""
-        if x.is_cuda and x.dim() == 3 and x.shape[1] == self.bottleneck_size and x.shape[2] > 0 and not self.use_tanh:
+        if (x.is_cuda and x.dim() == 3 and x.shape[1] == self.bottleneck_size and x.shape[2] > 0 and not self.use_tanh
+                and not self._grid_rows_need_grad(x)):
             feat = x[:, 3:, :]
             if bool((feat == feat[:, :, :1]).all()):
                 pts = self.decode(feat[:, :, 0].contiguous(), x[:, :3, :].transpose(1, 2).contiguous())
@@ -71,6 +72,20 @@ class PointGenCon(nn.Module):
                 warnings.warn("PointGenCon.forward(x): x is not the [grid ; broadcast feature] concatenation of atlasbranch.py:117-132, "
                               "running the generic stock-op path (use PointGenCon.decode(features, grid) for the fused HIP decoder)")
         return self._tail(torch_f.relu(self.bn1(self.conv1(x))))
+
+    @staticmethod
+    def _grid_rows_need_grad(x):
+        """The fused decoder has no gradient for the point rows x[:, :3, :] (``ops._PointGen.backward`` returns None for
+        ``grid``).  They need none when autograd is off, when x carries no graph, or when x is the reference's
+        ``torch.cat((grid, features), 1)`` whose first input is not part of the graph (the template sphere / drawn points,
+        ``atlasbranch.py:92-101,117-132``).  Anything else (a leaf x, learned or refined point sets) keeps the stock ops, which
+        propagate that gradient."""
+        if not torch.is_grad_enabled() or not x.requires_grad:
+            return False
+        fn = x.grad_fn
+        if fn is not None and fn.name().startswith("CatBackward") and len(fn.next_functions) >= 2:
+            return fn.next_functions[0][0] is not None
+        return True
 
     def decode(self, features, grid):
         """features [B,C-3], grid [N,3] (shared template) or [B,N,3] (one point set per sample) -> points [B,N,3] (already

@@ -130,6 +130,21 @@ def test_decoder_matches_reference_golden_pointgen(golden):
     for other in ("decode", "stock"):
         for a, b in zip(outs["forward"], outs[other]):
             np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * np.abs(b).max())
+    # (3) point rows that NEED a gradient (a learned / refined point set, or a leaf x): the fused decoder has no gradient for
+    # them, so forward() must keep the stock ops - silently dropping that gradient was ADVICE r03's finding
+    grads = {}
+    for how in ("forward", "stock"):
+        dec_k, f, gl = mk(), feats.clone().requires_grad_(), grid.clone().requires_grad_()
+        x = torch.cat((gl.t().unsqueeze(0).expand(3, -1, -1), f.unsqueeze(2).expand(-1, -1, 42)), 1)
+        out = dec_k(x) if how == "forward" else dec_k._tail(F.relu(dec_k.bn1(dec_k.conv1(x))))
+        (out * cot).sum().backward()
+        assert gl.grad is not None and float(gl.grad.abs().max()) > 0
+        grads[how] = (gl.grad.cpu().numpy(), f.grad.cpu().numpy())
+    for a, b in zip(grads["forward"], grads["stock"]):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6 * np.abs(b).max())
+    leaf = torch.cat((grid.t().unsqueeze(0).expand(3, -1, -1), feats.unsqueeze(2).expand(-1, -1, 42)), 1).clone().requires_grad_()
+    (mk()(leaf) * cot).sum().backward()
+    assert float(leaf.grad[:, :3].abs().max()) > 0 and float(leaf.grad[:, 3:, 1:].abs().max()) > 0  # per-point gradients, not column 0 only
 
 
 def test_decoder_multi_patch_and_determinism():

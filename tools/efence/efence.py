@@ -4,7 +4,6 @@
     python tools/efence/efence.py --selftest                       # the tool itself: in-range accesses pass, 1 byte past faults
     python tools/efence/efence.py --config c3 --batch 64 --encoder-dtype bf16 --decoder-dtype bf16 --steps 2
     python tools/efence/efence.py --left ...                       # guard BEFORE every tensor instead of after it
-    python tools/efence/efence.py --ops                            # every op of obman_train_amd.ops at the configs' shapes
 
 Every tensor of the process (inputs, outputs, workspaces, autograd-saved state, MIOpen workspaces) sits right-aligned against an
 unmapped page, and every launcher of the C-ABI is traced + synchronised (OBMAN_TRACE_LAUNCH=1), so an out-of-bounds access
@@ -167,7 +166,11 @@ def main():
     ap.add_argument("--eval", action="store_true", help="also one eval-mode forward")
     ap.add_argument("--left", action="store_true")
     ap.add_argument("--align", type=int, default=None)
+    ap.add_argument("--env", action="append", default=[], help="NAME=VALUE set before the HIP library loads (A/B knobs)")
     args = ap.parse_args()
+    for kv in args.env:
+        k, _, v = kv.partition("=")
+        os.environ[k] = v
     if args.selftest_child:
         selftest_child(args.selftest_child)
     if args.selftest:
