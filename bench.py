@@ -46,6 +46,11 @@ def parse():
                     help="bf16 = autocast the ResNet encoder (configs[2] flavour; NOT the headline fp32 config)")
     ap.add_argument("--decoder-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16 = AtlasNet decoder GEMMs on the bf16 matrix pipe (configs[2] flavour; NOT the headline fp32 config)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend.  nccl (= RCCL) is the product path.  gloo is a SELF-TEST of this script's world > 1 "
+                         "code path on a box with fewer GPUs than ranks: the ranks share the visible devices and the collectives "
+                         "are staged through host memory when this torch build's gloo cannot reduce device tensors; the line is "
+                         "labelled `selftest` and its value means nothing")
     ap.add_argument("--force-dist", action="store_true",
                     help="self-test: run the RCCL process group + gradient buckets even with a single rank")
     ap.add_argument("--dp-accumulate-in-place", action="store_true",
@@ -372,16 +377,24 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     import torch.distributed as dist
 
+    selftest = args.backend == "gloo"
+    if selftest:
+        local = local % max(torch.cuda.device_count(), 1)  # more ranks than devices: share them
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
+    collectives = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        from obman_train_amd.dp import init_rccl
+        from obman_train_amd.dp import init_rccl, stage_collectives_through_host_if_needed
 
-        init_rccl(dev, rank=rank, world_size=world)  # RCCL on a high-priority stream (own hardware queue)
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            collectives = stage_collectives_through_host_if_needed(dev)
+        else:
+            init_rccl(dev, rank=rank, world_size=world)  # RCCL on a high-priority stream (own hardware queue)
     import warnings
     warnings.simplefilter("ignore")
     torch.backends.cudnn.benchmark = True
@@ -585,8 +598,11 @@ def main():
                                 "note": "host time per step inside the timed region (launch enqueue; the GPU runs asynchronously)"},
         }
         if use_dist:
+            if selftest:
+                out["selftest"] = ("--backend gloo: %d ranks on %d visible device(s), collectives %s; exercises the world > 1 code "
+                                   "path of this script only - `value` is not a measurement" % (world, torch.cuda.device_count(), collectives))
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "launcher_world_size": world,
-                           "rccl_high_priority_stream": True, "buckets": buckets.describe(),
+                           "rccl_high_priority_stream": not selftest, "buckets": buckets.describe(),
                            "accumulate_in_place": bool(args.dp_accumulate_in_place), "ranks": ranks_info,
                            "distinct_devices": len({(r["hostname"], r["pci_bus_id"] or r["device_uuid"] or r["device_index"])
                                                     for r in ranks_info})}

@@ -50,45 +50,15 @@ def _shard(rank):
     return sample
 
 
-def _stage_collectives_through_host_if_needed(dist):
-    """gloo with device tensors works on builds whose gloo has the HIP transport; otherwise reduce / broadcast a host copy."""
-    try:
-        probe = torch.ones(2, device="cuda:0")
-        dist.all_reduce(probe)
-        if float(probe[0]) == float(dist.get_world_size()):
-            return "device tensors"
-    except Exception:  # noqa: BLE001 - any backend error means "not supported here"
-        pass
-    real_reduce, real_bcast = dist.all_reduce, dist.broadcast
-
-    class _Done:
-        def wait(self):
-            return True
-
-    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-        host = t.detach().cpu()
-        real_reduce(host, op=op, group=group)
-        t.copy_(host)
-        return _Done() if async_op else None
-
-    def broadcast(t, src=0, group=None, async_op=False):
-        host = t.detach().cpu()
-        real_bcast(host, src=src, group=group)
-        t.copy_(host)
-        return _Done() if async_op else None
-
-    dist.all_reduce, dist.broadcast = all_reduce, broadcast
-    return "host-staged (harness)"
-
-
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OBMAN_MANO_SYNTHETIC="1")
     import torch.distributed as dist
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    mode = _stage_collectives_through_host_if_needed(dist)
-    from obman_train_amd.dp import GradientBuckets, broadcast_parameters
+    from obman_train_amd.dp import GradientBuckets, broadcast_parameters, stage_collectives_through_host_if_needed
+
+    mode = stage_collectives_through_host_if_needed(torch.device("cuda", 0))
     from obman_train_amd.trainer import make_optimizer, train_step
 
     model = _build()

@@ -87,13 +87,17 @@ def test_graphed_train_step_configs2_replays_match_eager(flavour):
     sample[TransQueries.images] = sample[TransQueries.images].contiguous(memory_format=torch.channels_last)
     n_cmp, n_replays = 4, 30
 
-    model = _c3_model(flavour)
-    opt = make_optimizer(model, "adam", lr=1e-4, capturable=True)
-    eager = []
-    for _ in range(n_cmp):
-        total, _, losses = train_step(model, opt, sample)
-        eager.append((float(total), {k: float(v) for k, v in losses.items() if torch.is_tensor(v)}))
-    del model, opt, total, losses
+    def eager_run():
+        model = _c3_model(flavour)
+        opt = make_optimizer(model, "adam", lr=1e-4, capturable=True)
+        out = []
+        for _ in range(n_cmp):
+            total, _, losses = train_step(model, opt, sample)
+            out.append((float(total), {k: float(v) for k, v in losses.items() if torch.is_tensor(v)}))
+        return out
+
+    eager, again = eager_run(), eager_run()  # two eager runs: what "the same steps" means on this stack (run-to-run noise)
+    noise = [abs(a[0] - b[0]) / abs(a[0]) for a, b in zip(eager, again)]
 
     model = _c3_model(flavour)
     opt = make_optimizer(model, "adam", lr=1e-4, capturable=True)
@@ -110,10 +114,17 @@ def test_graphed_train_step_configs2_replays_match_eager(flavour):
     for i in range(n_cmp):
         rel = abs(float(got[i][0]) - eager[i][0]) / abs(eager[i][0])
         worst = max(worst, rel)
-        # same kernels, same inputs; MIOpen's atomically accumulated weight gradients make two runs differ in the last bits, and
-        # the difference is amplified through i Adam steps
-        assert rel <= (2e-4 if flavour == "decoder-bf16" else 3e-2) * (i + 1), (i, float(got[i][0]), eager[i][0])
+        # Replay 0 is a pure forward on the restored initial weights: same kernels, same inputs, same loss.  From the second
+        # step on the weights carry an Adam update, whose first steps are ~lr * sign(gradient): MIOpen's atomically accumulated
+        # weight gradients differ in the last bits from run to run, near-zero gradient entries flip their sign, and two EAGER
+        # runs already drift apart by ~1e-3 per step (measured: 9e-4 at step 2; tests/test_handnet_gpu.py holds whole
+        # flavours to 1e-2 over 5 steps for the same reason)
+        # ... so the yardstick is measured in the same process: 4 x the eager-vs-eager difference of that step, with a floor
+        # (the all-bf16 flavour is not run-to-run deterministic even in its first forward: 2.6e-3 measured; its later steps
+        # scatter between 2e-3 and 1.4e-2 - so the largest difference of the run is the scale, not the step's own)
+        bound = 4.0 * max(max(noise) if flavour == "all-bf16" else noise[i], 1e-5 if i == 0 else 1e-3 * i)
+        assert rel <= bound, (i, float(got[i][0]), eager[i][0], bound, noise)
         assert set(got[i][1]) == set(eager[i][1])
     assert final < eager[0][0]  # 30 Adam steps on one batch: the loss went down
-    record_measurement("graph_replay_vs_eager[%s]" % flavour, {"worst_rel_total_first_%d_steps" % n_cmp: worst, "replays": n_replays,
+    record_measurement("graph_replay_vs_eager[%s]" % flavour, {"worst_rel_total_first_%d_steps" % n_cmp: worst, "eager_vs_eager": noise, "replays": n_replays,
                                                                  "loss_first": eager[0][0], "loss_last": final})
