@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (trainer.GraphedTrainStep): same kernels, one launch call per step; the live "
                          "per-kernel Chamfer / decoder timings are not available in this mode (no events inside a graph)")
+    ap.add_argument("--secondary-steps", type=int, default=10,
+                    help="timed steps of each secondary leg run after the headline (configs[2] and configs[4] in bf16, configs[1] as "
+                         "one hipGraph); 0 disables them.  Only with the default --config c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget (all legs together)")
     ap.add_argument("--precondition-max", type=int, default=60,
@@ -344,6 +347,137 @@ def chamfer_throughput_probe(batch, n_pred=64050, n_gt=600, iters=10):
             "note": "whole obman_chamfer_fwd call (both directions + split merge), torch events; throughput-bound size"}
 
 
+def chamfer_roofline(batch, n_pred, n_gt, steps, prof):
+    """`roofline` of the ChamferLoss forward, PER LAUNCH: algorithmic bytes of a launch / its own average duration (HIP events on
+    the launch stream inside the timed loop, csrc/prof.hip).  Sizes up to 1024 points per side run ONE launch (both directions
+    + the per-sample means: 20 (N + M) B per sample); asymmetric 25-patch sizes run one launch per direction, each
+    booked under its own id and priced against its own bytes: queries 12 B in + 8 B out (minimum, index), references 12 B in."""
+    (f_ms, f_n), (b_ms, b_n), (y_ms, y_n) = prof[10], prof[11], prof[12]
+    flop = 10.0 * n_pred * n_gt * batch
+
+    def entry(kernel, alg_bytes, ms, n, flop_launch):
+        if not n:
+            return None
+        t = ms / n * 1e-3
+        return {"kernel": kernel, "avg_launch_us": t * 1e6, "launches": n, "alg_bytes_per_launch": alg_bytes,
+                "achieved": alg_bytes / t / 1e9, "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBPS,
+                "valu_tflops": flop_launch / t / 1e12, "valu_frac": flop_launch / t / 1e12 / VALU_PEAK_TFLOPS}
+
+    if n_pred <= 1024 and n_gt <= 1024:  # csrc/pairmin.hip S5 path
+        launches = [entry("pairmin_s5_kernel (whole ChamferLoss.forward: both directions + per-sample means, %d samples, ONE launch)" % batch,
+                          20.0 * (n_pred + n_gt) * batch, f_ms, f_n, flop)]
+    elif y_n:
+        launches = [entry("pairmin_fwd_kernel, predicted -> ground truth (%d x %d queries against %d references each)" % (batch, n_pred, n_gt),
+                          (20.0 * n_pred + 12.0 * n_gt) * batch, f_ms, f_n, flop / 2),
+                    entry("pairmin_fwd_kernel, ground truth -> predicted (%d x %d queries against %d references each%s)"
+                          % (batch, n_gt, n_pred, ", reference set split over blocks + merge" if n_pred >= 8192 else ""),
+                          (20.0 * n_gt + 12.0 * n_pred) * batch, y_ms, y_n, flop / 2)]
+    else:
+        launches = [entry("pairmin_fwd_kernel (both directions in one launch, %d samples)" % batch, 20.0 * (n_pred + n_gt) * batch,
+                          f_ms, f_n, flop)]
+    launches = [e for e in launches if e]
+    head = max(launches, key=lambda e: e["avg_launch_us"]) if launches else None  # the dominant launch is the headline entry
+    roof = {"kernel": head["kernel"] if head else None, "bound": "hbm", "achieved": head["achieved"] if head else None,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": head["frac"] if head else None, "traffic": None,
+            "avg_launch_us": head["avg_launch_us"] if head else None, "launches": head["launches"] if head else 0,
+            "launches_per_call": (f_n + y_n) / max(steps, 1), "alg_bytes_per_launch": head["alg_bytes_per_launch"] if head else None,
+            "per_launch": launches,
+            "backward": {"kernel": "pairmin_bwd_kernel (Chamfer backward, both sides)", "avg_launch_us": (b_ms / b_n * 1e3) if b_n else None,
+                         "launches": b_n, "alg_bytes_per_launch": 32.0 * (n_pred + n_gt) * batch},
+            "valu": {"achieved_tflops": head["valu_tflops"] if head else None, "peak_tflops": VALU_PEAK_TFLOPS,
+                     "frac": head["valu_frac"] if head else None,
+                     "note": "binding bound (10 flop per pair evaluation, the launch's own pairs): intensity N*M/(2(N+M)) = %.0f flop/B "
+                             ">> 20 flop/B ridge" % (n_pred * n_gt / (2.0 * (n_pred + n_gt)))}}
+    return roof
+
+
+def decoder_roofline(model, batch, n_pred, decoder_dtype, prof):
+    """decoder (K6): algorithmic flops of the three MFMA layers (861 720 flop/point incl. layer 1, which this
+    implementation removes analytically; counted here: layers 2-4 only), backward = 2x forward."""
+    (dec_f_ms, dec_f_n), (dec_b_ms, dec_b_n) = prof[8], prof[9]
+    if not (dec_f_n and dec_b_n):
+        return None
+    c1 = model.atlas_branch.decoder.bottleneck_size
+    dec_flop = 2.0 * batch * n_pred * (c1 * (c1 // 2) + (c1 // 2) * (c1 // 4) + (c1 // 4) * 3)
+    tf, tb = dec_f_ms / dec_f_n * 1e-3, dec_b_ms / dec_b_n * 1e-3
+    dpeak = VALU_PEAK_TFLOPS if decoder_dtype == "f32" else 2500.0
+    return {"bound": "mfma", "dtype": decoder_dtype, "peak": dpeak, "unit": "TFLOP/s",
+            "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_achieved": dec_flop / tf / 1e12,
+            "bwd_achieved": 2 * dec_flop / tb / 1e12, "frac": 3 * dec_flop / (tf + tb) / 1e12 / dpeak,
+            "note": "whole obman_pointgen_fwd/bwd call (all its kernels); peak = dense MFMA rate of the operand "
+                    "dtype (157.3 TF fp32-in, 2500 TF bf16)"}
+
+
+def secondary_leg(cfg_name, encoder_dtype, decoder_dtype, batch, image_size, steps, dev, graph=False):
+    """One more configuration after the timed region (NOT `value`): BASELINE.json configs[2] / configs[4] in their stated
+    precision, ~`steps` timed steps each, so that the driver's record carries them too."""
+    import gc
+
+    from obman_train_amd import _lib
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.queries import TransQueries
+    from obman_train_amd.synthetic import CONFIGS, make_batch
+    from obman_train_amd.trainer import GraphedTrainStep, make_optimizer, train_step
+
+    cfg = CONFIGS[cfg_name]
+    torch.manual_seed(0)
+    model = HandNet(**cfg).to(dev).train()
+    if encoder_dtype == "bf16":
+        model.base_net.autocast_dtype = torch.bfloat16
+    model.atlas_branch.decoder.mfma_dtype = decoder_dtype
+    opt = make_optimizer(model, "adam", lr=1e-4, capturable=graph)
+    sample = make_batch(batch, dev, seed=0, image_size=image_size)
+    sample[TransQueries.images] = sample[TransQueries.images].contiguous(memory_format=torch.channels_last)
+    times, pre = [], 0
+    while pre < 40:  # the same settle rule as the headline's precondition phase
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        train_step(model, opt, sample)
+        b.record()
+        b.synchronize()
+        times.append(a.elapsed_time(b))
+        pre += 1
+        tail = times[-5:]
+        if pre >= 8 and max(tail) - min(tail) <= 0.03 * sorted(tail)[2]:
+            break
+    step = None
+    if graph:
+        gc.collect()
+        torch.cuda.synchronize()
+        step = GraphedTrainStep(model, opt, sample, warmup=2)
+        for _ in range(2):
+            step(sample)
+    _lib.prof_enable(not graph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        total = (step(sample) if step is not None else train_step(model, opt, sample))[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = {k: _lib.prof_summary(k) for k in (8, 9, 10, 11, 12)}
+    _lib.prof_enable(False)
+    n_pred = model.atlas_branch.test_verts.shape[0]
+    n_gt = sample[TransQueries.objpoints3d].shape[1]
+    out = {"config": cfg_name, "workload": describe_workload(SimpleArgs(cfg_name, batch, image_size, encoder_dtype, decoder_dtype), cfg, n_pred, n_gt),
+           "value": batch * steps / dt, "unit": "images/sec", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "precondition_steps": pre, "hipgraph": bool(graph), "final_loss": float(total),
+           "dtype": "%s encoder / %s decoder MFMA / f32 heads, losses, optimizer" % (encoder_dtype, decoder_dtype)}
+    if not graph:
+        out["roofline"] = chamfer_roofline(batch, n_pred, n_gt, steps, prof)
+        out["decoder_roofline"] = decoder_roofline(model, batch, n_pred, decoder_dtype, prof)
+    del model, opt, sample, step, total
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+class SimpleArgs:
+    def __init__(self, config, batch, image_size, encoder_dtype, decoder_dtype):
+        self.config, self.batch, self.image_size = config, batch, image_size
+        self.encoder_dtype, self.decoder_dtype = encoder_dtype, decoder_dtype
+
+
+
 def describe_workload(args, cfg, n_pred, n_gt):
     """Human-readable description of the configuration ACTUALLY run (BASELINE.json configs[k] when it is one of them)."""
     patches = cfg.get("atlas_patches", 1)
@@ -503,10 +637,7 @@ def main():
     _say("timed region done")
     step_gpu_ms = sorted(close_phase("timed", evs, host))
     loss_val = float(total)
-    pm_ms, pm_n = _lib.prof_summary(10)  # ChamferLoss forward launches only (csrc/prof.h; 1 = the hand<->object closest-vertex launches)
-    pmb_ms, pmb_n = _lib.prof_summary(11)
-    dec_f_ms, dec_f_n = _lib.prof_summary(8)
-    dec_b_ms, dec_b_n = _lib.prof_summary(9)
+    prof = {k: _lib.prof_summary(k) for k in (8, 9, 10, 11, 12)}  # csrc/prof.h ids -> (total ms, launches)
     _lib.prof_enable(False)
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -531,42 +662,8 @@ def main():
     if rank == 0:
         n_pred = model.atlas_branch.test_verts.shape[0]
         n_gt = sample[TransQueries.objpoints3d].shape[1]
-        # Chamfer fwd algorithmic bytes 20*(N+M) per sample, ~10*N*M flop per sample
-        alg_bytes = 20.0 * (n_pred + n_gt) * args.batch
-        alg_flop = 10.0 * n_pred * n_gt * args.batch
-        # per Chamfer call: one launch at configs[1]; at asymmetric 25-patch sizes each direction is its own launch and the
-        # algorithmic bytes below are those of the whole call, so the durations of a call's launches are summed
-        avg_s = (pm_ms / max(args.steps, 1)) * 1e-3
-        achieved = alg_bytes / avg_s / 1e9 if pm_n else None
-        single = n_pred <= 1024 and n_gt <= 1024  # csrc/pairmin.hip S5 path: minima of both directions AND the per-sample means in one launch
-        roof = {
-            "kernel": ("pairmin_s5_kernel (whole ChamferLoss.forward: both directions + per-sample means, %d samples, ONE launch)"
-                       if single else "pairmin_fwd_kernel (ChamferLoss forward: one launch per direction, %d samples; durations of a call's "
-                                      "launches are summed against the bytes of one call)") % args.batch,
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
-            "avg_launch_us": avg_s * 1e6, "launches": pm_n, "launches_per_call": pm_n / max(args.steps, 1),
-            "alg_bytes_per_launch": alg_bytes,
-            "backward": {"kernel": "pairmin_bwd_kernel (Chamfer backward, both sides)", "avg_launch_us": (pmb_ms / pmb_n * 1e3) if pmb_n else None,
-                         "launches": pmb_n, "alg_bytes_per_launch": 32.0 * (n_pred + n_gt) * args.batch},
-            "valu": {"achieved_tflops": alg_flop / avg_s / 1e12 if pm_n else None, "peak_tflops": VALU_PEAK_TFLOPS,
-                     "frac": (alg_flop / avg_s / 1e12 / VALU_PEAK_TFLOPS) if pm_n else None,
-                     "note": "binding bound: intensity N*M/(2(N+M)) = %.0f flop/B >> 20 flop/B ridge"
-                             % (n_pred * n_gt / (2.0 * (n_pred + n_gt)))},
-        }
-        # decoder (K6): algorithmic flops of the three MFMA layers (861 720 flop/point incl. layer 1, which
-        # this implementation removes analytically; counted here: layers 2-4 only), backward = 2x forward
-        c1 = model.atlas_branch.decoder.bottleneck_size
-        dec_flop = 2.0 * args.batch * n_pred * (c1 * (c1 // 2) + (c1 // 2) * (c1 // 4) + (c1 // 4) * 3)
-        decoder = None
-        if dec_f_n and dec_b_n:
-            tf, tb = dec_f_ms / dec_f_n * 1e-3, dec_b_ms / dec_b_n * 1e-3
-            dpeak = VALU_PEAK_TFLOPS if args.decoder_dtype == "f32" else 2500.0
-            decoder = {"bound": "mfma", "dtype": args.decoder_dtype, "peak": dpeak, "unit": "TFLOP/s",
-                       "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_achieved": dec_flop / tf / 1e12,
-                       "bwd_achieved": 2 * dec_flop / tb / 1e12, "frac": 3 * dec_flop / (tf + tb) / 1e12 / dpeak,
-                       "note": "whole obman_pointgen_fwd/bwd call (all its kernels); peak = dense MFMA rate of the operand "
-                               "dtype (157.3 TF fp32-in, 2500 TF bf16)"}
+        roof = chamfer_roofline(args.batch, n_pred, n_gt, args.steps, prof)
+        decoder = decoder_roofline(model, args.batch, n_pred, args.decoder_dtype, prof)
         traffic_file = os.path.join(REPO, "profiles", "chamfer_traffic.json")
         if os.path.exists(traffic_file):  # PMC cannot run inside this process: the committed per-launch figure of a labelled PMC run
             with open(traffic_file) as fh:
@@ -614,6 +711,15 @@ def main():
             _say("pcie_inclusive_probe")
             out["pcie_inclusive"] = pcie_inclusive_probe(model, opt, sample, args.batch, args.image_size, train_step)
             _say("probes done")
+        if world == 1 and args.secondary_steps > 0 and args.config == "c2" and not args.graph:
+            sec = []
+            for cfg_name, bs in (("c3", args.batch), ("c5", args.batch)):
+                _say("secondary leg %s" % cfg_name)
+                sec.append(secondary_leg(cfg_name, "bf16", "bf16", bs, args.image_size, args.secondary_steps, dev))
+            _say("secondary leg c2 as one hipGraph")
+            sec.append(secondary_leg("c2", "f32", "f32", args.batch, args.image_size, args.secondary_steps, dev, graph=True))
+            out["secondary"] = {"note": "other BASELINE.json configurations, timed after the headline's timed region with the same rules "
+                                        "(inputs resident, settle phase, whole train step); never part of `value`", "legs": sec}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size, args.config)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -258,7 +258,8 @@ int obman_imgstream_fwd(const uint8_t* src, int B, int pitch_h, int pitch_w, con
  * obman_prof_enable(1) makes the launchers bracket their main kernel with HIP events on the launch
  * stream (pool of 8192 records, reset by every enable call); obman_prof_summary synchronises and
  * returns the summed duration / launch count of one kernel id (1 pair-min fwd, 2 pair-min bwd,
- * 3 inside test, 4/5 contact fwd/bwd, 6/7 MANO fwd/bwd, 8/9 decoder fwd/bwd).  Used by bench.py for
+ * 3 inside test, 4/5 contact fwd/bwd, 6/7 MANO fwd/bwd, 8/9 decoder fwd/bwd, 10/11 ChamferLoss fwd/bwd,
+ * 12/13 the second direction's own launch of a ChamferLoss / pair-min forward at asymmetric sizes).  Used by bench.py for
  * the `roofline` object; off by default. */
 int obman_prof_enable(int on);
 int obman_prof_summary(int kernel_id, double* total_ms, long* launches);

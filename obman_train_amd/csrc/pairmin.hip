@@ -756,7 +756,9 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
     }
     if (min_y) {
       d1.tile = tile_of(d1);
-      launch_fwd(q1, dim3(d1.qtiles * d1.rsplit, B, 1), smem_of(d1.tile, q1), st, d1, d1, kid);
+      // the second direction's own launch has its own profiler id: a launch is priced against ITS bytes (bench.py roofline)
+      launch_fwd(q1, dim3(d1.qtiles * d1.rsplit, B, 1), smem_of(d1.tile, q1), st, d1, d1,
+                 kid == OBMAN_K_CHAMFER_FWD ? OBMAN_K_CHAMFER_FWD_Y : (kid == OBMAN_K_PAIRMIN_FWD ? OBMAN_K_PAIRMIN_FWD_Y : kid));
     }
   }
   OBMAN_LAUNCH_CHECK();
