@@ -26,7 +26,7 @@ RECIPES = {
     # BASELINE.json configs[0] / [1] flags
     "baseline_configs1": "--atlas_mesh --mano_use_pca --atlas_lambda 0.167".split(),
     # contact + penetration fine-tuning (README's contact options; BASELINE.json configs[2])
-    "contact": "--atlas_predict_trans --atlas_predict_scale --atlas_mesh --mano_use_shape --mano_use_pca --contact_lambda 1 "
+    "contact": "--atlas_predict_trans --atlas_predict_scale --atlas_mesh --atlas_lambda 0.167 --mano_use_shape --mano_use_pca --contact_lambda 1 "
                "--collision_lambda 1 --contact_thresh 10 --collision_thresh 20 --contact_mode dist_tanh --collision_mode dist_tanh "
                "--contact_zones zones --contact_target all".split(),
 }
