@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 #include "decoder_bf16.h"
 #include "decoder_rows2.h"
 #include "decoder_tn2.h"
+#include "decoder_rows2f.h"
 
 }  // namespace dec
 
@@ -1586,8 +1587,9 @@ FwdWs fwd_ws(const Dims& d) {
   w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS_NARROW * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
   w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
   w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
-  w.Gy = take(d.bf16 ? (long)(d.N + 1) * d.ld1 : 0);  // pre-scaled layer-1 factors of the bf16 forward (prescale_l1_kernel)
-  w.Fy = take(d.bf16 ? (long)d.B * d.ld1 : 0);
+  // pre-scaled layer-1 factors (prescale_l1_kernel): the bf16 flavour and the second-generation fp32 kernels (shared template grid)
+  w.Gy = take(d.bf16 || !d.ps ? (long)(d.N + 1) * d.ld1 : 0);
+  w.Fy = take(d.bf16 || !d.ps ? (long)d.B * d.ld1 : 0);
   w.total = o + WS_TAIL_FLOATS;
   return w;
 }
@@ -1912,6 +1914,86 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
   return 0;
 }
 
+// ---- second-generation fp32 rows GEMMs (decoder_rows2f.h)
+bool rows2f_enabled() {
+  static const int on = [] { const char* e = getenv("OBMAN_DEC_ROWS2F"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = first-generation fp32 kernels
+  return on != 0;
+}
+F2Geo f2_geo(const Dims& d, int Nc, int NT, int mode = 0) {
+  F2Geo g{};
+  const int cols = 32 * NT;
+  g.R = (int)d.R; g.N = d.N; g.B = d.B; g.mode = mode;
+  g.nvt = (d.N + 3) / 4;
+  g.tiles = mode == 0 ? (int)((d.R + 31) / 32) : g.nvt * ((d.B + 7) / 8);
+  g.ngroups = Nc > F2_SIDE ? (Nc - F2_SIDE + cols - 1) / cols : 1;
+  { const int last = Nc - (g.ngroups - 1) * cols; g.wside = last > cols ? last - cols : 0; }
+  // one block per CU.  A block of the last column group also carries the 1 .. 3 side columns on the VALU: measured per tile
+  // (s_memtime in the k loop, profiles/r04_kernels.md) +19 % with one side column at NT = 2, +14.5 % with three at NT = 4 - the
+  // last group gets proportionally more blocks (fewer tiles each) so that all groups finish together.
+  const int cus = device_cus();
+  const int need = (g.tiles + F2_WAVES - 1) / F2_WAVES;  // no block without a tile
+  const int cap = need < d.rb ? need : d.rb;              // the per-block moment / sum partials are sized for d.rb row blocks (fwd_ws / bwd_ws)
+  if (g.ngroups == 1) {
+    g.slots = 0;
+    g.slots_last = cus < cap ? cus : cap;
+  } else {
+    const double w = g.wside ? 1.0 + (0.14 + 0.05 * g.wside) * 2.0 / NT : 1.0;
+    int last = (int)(cus * w / (g.ngroups - 1 + w) + 0.5);
+    int main_ = (cus - last) / (g.ngroups - 1);
+    if (main_ < 1) main_ = 1;
+    if (last < 1) last = 1;
+    g.slots = main_ < cap ? main_ : cap;
+    g.slots_last = last < cap ? last : cap;
+  }
+  return g;
+}
+template <class AOp, class Epi, int NT>
+size_t f2_lds_bytes(int Kp, const F2Geo& geo) {
+  const size_t lds = ((size_t)(32 * NT + geo.wside) * (Kp + 4) + (size_t)AOp::lds_floats(Kp) + (size_t)Epi::LDS_FLOATS) * sizeof(float);
+  return lds < f2_flush_bytes(NT) ? f2_flush_bytes(NT) : lds;
+}
+constexpr size_t F2_LDS_LIMIT = 160 * 1024;
+template <class AOp, class Epi, int NT>
+int launch_rows2f(const AOp& a, const float* W, int ldw, int w_kn, int K, int Nc, const F2Geo& geo, const Epi& e, hipStream_t st) {
+  const int Kp = kpad8(K);
+  const size_t lds = f2_lds_bytes<AOp, Epi, NT>(Kp, geo);
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if ((int)lds > granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)rows2f_kernel<AOp, Epi, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store((int)lds, std::memory_order_relaxed);
+  }
+  rows2f_kernel<AOp, Epi, NT><<<(unsigned)((geo.ngroups - 1) * geo.slots + geo.slots_last), F2_THREADS, lds, st>>>(a, W, ldw, w_kn, K, Kp, Nc, e, geo, AOp::lds_floats(Kp));
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+// 128 columns per block (4 accumulator tiles per wave) where that weight slice fits in LDS, else 64
+template <class AOp, class Epi4, class Epi2>
+bool f2_wide(const Dims& d, int K, int Nc) { return f2_lds_bytes<AOp, Epi4, 4>(kpad8(K), f2_geo(d, Nc, 4)) <= F2_LDS_LIMIT; }
+template <class AOp, template <int> class Epi, bool WIDE_OK = true>
+int launch_rows2f_auto(const Dims& d, const AOp& a, const float* W, int ldw, int w_kn, int K, int Nc, const Epi<4>& e4, const Epi<2>& e2, int mode2,
+                       int* slots, hipStream_t st) {
+  // 128 columns per block halve the operand loads per MFMA but double the tile: only with at least 4 tiles per wave (at 64 x 642
+  // points a 128-column h3 GEMM has one tile per wave on 161 of the 256 CUs)
+  if constexpr (WIDE_OK) if (f2_wide<AOp, Epi<4>, Epi<2>>(d, K, Nc) && f2_geo(d, Nc, 4, mode2).tiles >= 4 * F2_WAVES * device_cus() / f2_geo(d, Nc, 4, mode2).ngroups) {
+    const F2Geo g = f2_geo(d, Nc, 4, mode2);
+    if (slots) *slots = g.mrows();
+    return launch_rows2f<AOp, Epi<4>, 4>(a, W, ldw, w_kn, K, Nc, g, e4, st);
+  }
+  const F2Geo g = f2_geo(d, Nc, 2, mode2);
+  if (slots) *slots = g.mrows();
+  return launch_rows2f<AOp, Epi<2>, 2>(a, W, ldw, w_kn, K, Nc, g, e2, st);
+}
+// the whole fp32 call takes the second-generation kernels or none of them (they share the pre-scaled factors and the zeroed pitch columns)
+bool use_rows2f(const Dims& d) {
+  if (d.bf16 || d.ps || !rows2f_enabled()) return false;
+  return f2_lds_bytes<F2GridFeatPre, F2EpiStore<2>, 2>(kpad8(d.C1), f2_geo(d, d.C2, 2, 2)) <= F2_LDS_LIMIT &&
+         f2_lds_bytes<F2BnRelu, F2EpiStore<2>, 2>(kpad8(d.C2), f2_geo(d, d.C3, 2)) <= F2_LDS_LIMIT &&
+         f2_lds_bytes<F2GradH3, F2EpiMask<2>, 2>(kpad8(d.C3), f2_geo(d, d.C2, 2)) <= F2_LDS_LIMIT &&
+         f2_lds_bytes<F2GradH, F2EpiL1<2>, 2>(kpad8(d.C2), f2_geo(d, d.C1, 2)) <= F2_LDS_LIMIT;
+}
+
 // ---- bf16 flavour: layers 2-4 of the forward (after prep_kernel) and the whole backward (decoder_bf16.h)
 int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, float* out, float* ws, hipStream_t st) {
   const int tr = p->training;
@@ -2144,29 +2226,48 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
   }
   if (d.bf16) return forward_bf16(p, d, w, out, ws, st);
   double* moments = reinterpret_cast<double*>(ws + w.moments);
+  const bool f2 = use_rows2f(d);
   {  // h2 = W2 relu(bn1(h1)) + b2
+    int rc, mrows = d.rb;
+    if (f2) {
+      prescale_l1_kernel<<<obman_cdiv((long)(d.N + 1 + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
+                                                                                        d.C1, ws + w.Gy, ws + w.Fy);
+      OBMAN_LAUNCH_CHECK();
+      F2GridFeatPre a{ws + w.Gy, ws + w.Fy, d.ld1, d.N};
+      F2EpiStore<4> e4{ws + w.H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
+      F2EpiStore<2> e2{ws + w.H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
+      // 64-column blocks (K = 515) tile their rows as 8 samples x 4 vertices: the factor loads touch 4 + 8 rows, not 32 + 1
+      if ((rc = launch_rows2f_auto<F2GridFeatPre, F2EpiStore>(d, a, p->w2, d.C1, 0, d.C1, d.C2, e4, e2, 2, &mrows, st))) return rc;
+    } else {
     AGridFeat a{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, (int)d.R, d.C1, d.ps};
     EpiStoreImpl e;
     e.C = ws + w.H2; e.bias = p->b2; e.moments = tr ? moments : nullptr; e.ldc = d.ld2; e.R = (int)d.R; e.Nc = d.C2;
     e.mstride = d.C2;
-    int rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
+    rc = launch_rows<AGridFeat, true, EpiStoreImpl>(a, p->w2, d.C1, d.C1, d.C2, d.R, e, st);
     if (rc) return rc;
+    }
     const double* mom = moments;
-    int mrows = d.rb;
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C2 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(mom, mrows, d.R, d.C2, tr, p->eps, p->momentum, p->bn_w[1], p->bn_b[1],
                                                                p->bn_rm[1], p->bn_rv[1], ws + w.mean2, ws + w.rstd2, ws + w.s2, ws + w.t2);
     OBMAN_LAUNCH_CHECK();
   }
   {  // h3 = W3 relu(bn2(h2)) + b3
+    int rc, mrows = d.rb;
+    if (f2) {
+      F2BnRelu a{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
+      F2EpiStore<4> e4{ws + w.H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
+      F2EpiStore<2> e2{ws + w.H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
+      if ((rc = launch_rows2f_auto<F2BnRelu, F2EpiStore>(d, a, p->w3, d.C2, 0, d.C2, d.C3, e4, e2, 0, &mrows, st))) return rc;
+    } else {
     ABnRelu a{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, (int)d.R, d.C2};
     EpiStoreImpl e;
     e.C = ws + w.H3; e.bias = p->b3; e.moments = tr ? moments : nullptr; e.ldc = d.ld3; e.R = (int)d.R; e.Nc = d.C3;
     e.mstride = d.C3;
-    int rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
+    rc = launch_rows<ABnRelu, true, EpiStoreImpl>(a, p->w3, d.C2, d.C2, d.C3, d.R, e, st);
     if (rc) return rc;
+    }
     const double* mom = moments;
-    int mrows = d.rb;
     if (tr && (rc = pre_reduce<double>(mom, mrows, d.C3 * 2, reinterpret_cast<double*>(ws + w.mred), st))) return rc;
     bn_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(mom, mrows, d.R, d.C3, tr, p->eps, p->momentum, p->bn_w[2], p->bn_b[2],
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
@@ -2217,7 +2318,16 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
       ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
       if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
     }
-    {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
+    const bool f2 = use_rows2f(d);
+    srows = d.rb;
+    if (f2) {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums: second-generation kernel
+      F2GradH3 a{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
+      F2EpiMask<4> e4{ws2 + v.GY2, ws + w.H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
+      F2EpiMask<2> e2{ws2 + v.GY2, ws + w.H2, sums, ws + w.s2, ws + w.t2, ws + w.mean2, ws + w.rstd2, d.ld2, d.C2};
+      // 64 columns per block: the gh3 generator (7 VALU operations and two constant vectors per element) plus this epilogue's
+      // state spill with four accumulator tiles
+      if ((rc = launch_rows2f_auto<F2GradH3, F2EpiMask, false>(d, a, p->w3, d.C2, 1, d.C3, d.C2, e4, e2, 0, &srows, st))) return rc;
+    } else {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY2; e.sums = sums; e.ldc = d.ld2; e.R = R; e.Nc = d.C2; e.mode = 0;
       e.H = ws + w.H2; e.s = ws + w.s2; e.t = ws + w.t2; e.mean = ws + w.mean2; e.rstd = ws + w.rstd2;
@@ -2225,7 +2335,6 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
       if ((rc = launch_rows<AGradH3, false, EpiMaskStatsImpl>(gh3, p->w3, d.C2, d.C3, d.C2, d.R, e, st))) return rc;
     }
     sp = sums;
-    srows = d.rb;
     if ((rc = pre_reduce<double>(sp, srows, d.C2 * 2, reinterpret_cast<double*>(ws2 + v.sred), st))) return rc;
     bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1],
                                                                    g->bn_b[1], g->b2, k1, k2, k3);
@@ -2236,7 +2345,12 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     // three columns on VALU edge kernels - the tile kernel went 244 -> 146 us, the extra passes over the regenerated operands
     // cost 180 us; profiles/r02_kernels.md.)
     if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
-    {  // gy1 = (gh2 W2) * (y1 > 0)
+    if (f2) {  // gy1 = (gh2 W2) * (y1 > 0): second-generation kernel, mask from the pre-scaled factors
+      F2GradH a{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, d.C2};
+      F2EpiL1<4> e4{ws2 + v.GY1, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
+      F2EpiL1<2> e2{ws2 + v.GY1, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
+      if ((rc = launch_rows2f_auto<F2GradH, F2EpiL1>(d, a, p->w2, d.C1, 1, d.C2, d.C1, e4, e2, 2, nullptr, st))) return rc;  // row mode 2: see F2EpiL1
+    } else {  // gy1 = (gh2 W2) * (y1 > 0)
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
       e.H = e.s = e.t = e.mean = e.rstd = nullptr;
