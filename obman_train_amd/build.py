@@ -16,6 +16,8 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libobman_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# measurement builds only (e.g. OBMAN_EXTRA_HIPCC_FLAGS=-DOBMAN_F2_TIMING with --force): never set for the product library
+FLAGS += os.environ.get("OBMAN_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

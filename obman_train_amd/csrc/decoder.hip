@@ -1966,6 +1966,25 @@ int launch_rows2f(const AOp& a, const float* W, int ldw, int w_kn, int K, int Nc
   }
   rows2f_kernel<AOp, Epi, NT><<<(unsigned)((geo.ngroups - 1) * geo.slots + geo.slots_last), F2_THREADS, lds, st>>>(a, W, ldw, w_kn, K, Kp, Nc, e, geo, AOp::lds_floats(Kp));
   OBMAN_LAUNCH_CHECK();
+#ifdef OBMAN_F2_TIMING
+  {
+    static int calls = 0;
+    (void)hipStreamSynchronize(st);
+    if (++calls % 8 == 5) {
+      static unsigned long long host[2048 * 8];
+      (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(f2_dbg), sizeof(host));
+      const int nball = (geo.ngroups - 1) * geo.slots + geo.slots_last, nb = nball < 256 ? nball : 256;
+      double st_[8] = {0}, mx[8] = {0};
+      for (int i = 0; i < nb * 8; ++i) for (int k = 0; k < 6; ++k) { st_[k] += (double)host[i * 8 + k]; if ((double)host[i * 8 + k] > mx[k]) mx[k] = (double)host[i * 8 + k]; }
+      double lastg[3] = {0}; int nl = 0;
+      for (int i = 0; i < nb * 8; ++i) if ((int)host[i * 8 + 6] == geo.ngroups - 1) { lastg[0] += (double)host[i * 8 + 1]; lastg[1] += (double)host[i * 8 + 3]; lastg[2] += (double)host[i * 8 + 5]; ++nl; }
+      const int nw = nb * 8;
+      fprintf(stderr, "F2DBG K=%d Nc=%d NT=%d blocks=%d(+%d last) tiles=%d | per wave avg (max) ticks: stage %.0f (%.0f) kloop %.0f (%.0f) epi %.0f (%.0f) tiles %.1f (%.0f) total %.0f (%.0f) | per tile: kloop %.0f (per k-step %.1f) epi %.0f; last group: kloop/tile %.0f total %.0f\n",
+              K, Nc, NT, nball, geo.slots_last, geo.tiles, st_[0] / nw, mx[0], st_[1] / nw, mx[1], st_[2] / nw, mx[2], st_[3] / nw, mx[3], st_[5] / nw, mx[5],
+              st_[1] / st_[3], st_[1] / st_[3] / (Kp / 8), st_[2] / st_[3], nl ? lastg[0] / lastg[1] : 0.0, nl ? lastg[2] / nl : 0.0);
+    }
+  }
+#endif
   return 0;
 }
 // 128 columns per block (4 accumulator tiles per wave) where that weight slice fits in LDS, else 64

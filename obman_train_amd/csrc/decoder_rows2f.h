@@ -260,6 +260,26 @@ __device__ __forceinline__ void f2_zero_pitch(float* C, int ldc, int Nc, const F
       for (int col = Nc; col < ldc; ++col) C[(size_t)r * ldc + col] = 0.f;
   }
 }
+// Accumulator register q = 4 m + v of a lane holds tile row i = 8 m + 4 h + v (h = lane >> 5).  rows(): the element offset of
+// row (m, v = 0) for m = 0 .. 3 - rows v = 1 .. 3 follow at + v * ld in BOTH row modes (mode 0: consecutive rows; mode 2: the
+// consecutive vertices of one sample) - and whether the whole tile lies inside the problem (wave-uniform: the common case takes
+// straight-line stores with no per-element predicate; the ISA of the predicated form was ~20 scalar / vector instructions and
+// two branches per store).
+struct F2TileRows { size_t base[4]; bool full; };
+__device__ __forceinline__ F2TileRows f2_tile_rows(const F2Geo& geo, const F2Ctx& c, int ld) {
+  F2TileRows o;
+  const int h = c.lane >> 5;
+  if (geo.mode == 0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) o.base[m] = (size_t)(c.r0 + 8 * m + 4 * h) * ld;
+    o.full = c.r0 + 32 <= geo.R;
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) o.base[m] = ((size_t)(c.b0 + 2 * m + h) * geo.N + c.n0) * ld;
+    o.full = c.b0 + 8 <= geo.B && c.n0 + 4 <= geo.N;
+  }
+  return o;
+}
 // row of accumulator register q of this lane (register q <-> tile row acc_row(q, lane)); linear-row kernels (mode 0) only
 __device__ __forceinline__ long f2_lin_row(const F2Ctx& c, int q) { return c.r0 + acc_row(q, c.lane); }
 
@@ -288,6 +308,23 @@ struct F2EpiStore {  // C[r,n] = acc + bias[n]; fp64 column moments (sum, sum of
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const F2TileRows tr = f2_tile_rows(geo, c, ldc);
+    if (tr.full && c.c0 + 32 * NT <= Nc) {  // whole tile inside the problem: no predicates
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float* dst = C + tr.base[m] + c.c0 + li;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float val = acc[j][4 * m + v] + s.bv[j];
+            dst[(size_t)v * ldc + j * 32] = val;
+            s1[j] += val;
+            s2[j] = __fmaf_rn(val, val, s2[j]);
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < 16; ++q) {  // row-major over the registers: one row index per 32 x NT stored values
       long r; bool ok;
@@ -365,6 +402,28 @@ struct F2EpiMask {  // C = acc * (y > 0), y = s*H+t; column sums S1 = sum C, S2 
   }
   __device__ __forceinline__ void tile(State& q, const Pre& p, const f32x16 (&acc)[NT], const float (&side)[F2_SIDE], const F2Ctx& c, const F2Geo& geo) const {
     const int li = c.lane & 31;
+    const F2TileRows tr = f2_tile_rows(geo, c, ldc);
+    if (tr.full && c.c0 + 32 * NT <= Nc) {  // whole tile inside the problem: straight-line loads and stores
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (j < NPRE) hv[r] = p.h[j < NPRE ? j : 0][r];
+          else hv[r] = H[tr.base[r >> 2] + (size_t)(r & 3) * ldc + c.c0 + j * 32 + li];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = __fmaf_rn(q.cs[j], hv[r], q.ct[j]) > 0.f ? acc[j][r] : 0.f;
+          C[tr.base[r >> 2] + (size_t)(r & 3) * ldc + c.c0 + j * 32 + li] = v;
+          s1 += v;
+          s2 = __fmaf_rn(v, (hv[r] - q.cm[j]) * q.cr[j], s2);
+        }
+        q.d1[j] += (double)s1;
+        q.d2[j] += (double)s2;
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = c.c0 + j * 32 + li;
@@ -441,6 +500,17 @@ struct F2EpiL1 {  // gy1 = acc * (y1 > 0), y1 > 0 <=> Gy[n] + Fy[b] > 0 (the for
   }
   __device__ __forceinline__ void tile(State&, const Pre& p, const f32x16 (&acc)[NT], const float (&side)[F2_SIDE], const F2Ctx& c, const F2Geo& geo) const {
     const int li = c.lane & 31, h = c.lane >> 5;
+    const F2TileRows tr = f2_tile_rows(geo, c, ldc);
+    if (tr.full && c.c0 + 32 * NT <= Nc) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float* dst = C + tr.base[m] + c.c0 + li;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) dst[(size_t)v * ldc + j * 32] = p.g[j][v] + p.f[j][m] > 0.f ? acc[j][4 * m + v] : 0.f;
+      }
+    } else
 #pragma unroll
     for (int m = 0; m < 4; ++m) {  // accumulator register q = 4 m + v: sample b0 + 2 m + h, vertex n0 + v
       const int b = c.b0 + 2 * m + h;
@@ -478,6 +548,12 @@ struct F2EpiL1 {  // gy1 = acc * (y1 > 0), y1 > 0 <=> Gy[n] + Fy[b] > 0 (the for
 // grid = ngroups * slots blocks (1-D, XCD-aware virtual ids: the column groups of one slot are neighbours on one XCD - they
 // stream the same activation rows).  Dynamic LDS: weight slice [(32 NT + wside)][Kp + 4] fp32, then the generator's constants.
 // W is the fp32 weight matrix as the module holds it: w_kn == 0: W[n][k] (row stride ldw), w_kn == 1: W[k][n].
+#ifdef OBMAN_F2_TIMING  // measurement build (tools/r04/dec_dbg.sh): s_memtime per wave around staging / k loops / epilogues
+__device__ unsigned long long f2_dbg[2048 * 8];
+#define F2_TICK() __builtin_readcyclecounter()
+#else
+#define F2_TICK() 0ull
+#endif
 template <class AOp, class Epi, int NT>
 __global__ __launch_bounds__(F2_THREADS) void rows2f_kernel(AOp aop, const float* __restrict__ W, int ldw, int w_kn, int K, int Kp, int Nc, Epi epi,
                                                             F2Geo geo, int lds_aop_floats) {
@@ -519,8 +595,11 @@ __global__ __launch_bounds__(F2_THREADS) void rows2f_kernel(AOp aop, const float
         if (dst[u] >= 0) Ws[dst[u]] = v[u];
     }
   }
+  const unsigned long long T0 = F2_TICK();
   aop.stage(kcs, Kp, tid);
   __syncthreads();
+  const unsigned long long T1 = F2_TICK();
+  unsigned long long tk = 0, te = 0, ntile = 0;
 
   F2Ctx ctx{lane, wave, c0, nside, last_group, slot, my_slots, geo.mrows(), 0, 0, 0, 0};
   typename Epi::State est;
@@ -555,6 +634,7 @@ __global__ __launch_bounds__(F2_THREADS) void rows2f_kernel(AOp aop, const float
     // Raw operand chunks are requested F2_DQ k-steps ahead into a register queue with compile-time slots (the loop is unrolled
     // by F2_DQ); requests past the last step read the following bytes of the arena (never consumed; WS_TAIL_FLOATS of padding
     // close the workspaces), so the loop body is branch-free and the counted vmcnt waits leave the younger requests in flight.
+    const unsigned long long TA = F2_TICK();
     typename AOp::Raw q[F2_DQ];
 #pragma unroll
     for (int u = 0; u < F2_DQ; ++u) aop.load(q[u], row, u);
@@ -623,7 +703,15 @@ __global__ __launch_bounds__(F2_THREADS) void rows2f_kernel(AOp aop, const float
 #pragma unroll
       for (int u = 0; u < F2_SIDE; ++u) side[u] += __shfl_xor(side[u], 32, 64);
     }
+    const unsigned long long TB = F2_TICK();
     epi.tile(est, pre, acc, side, ctx, geo);
+    tk += TB - TA; te += F2_TICK() - TB; ++ntile;
   }
+  const unsigned long long T2 = F2_TICK();
   epi.flush(est, ctx, smem);
+#ifdef OBMAN_F2_TIMING
+  if (lane == 0 && blockIdx.x < 256) { unsigned long long* o = f2_dbg + ((size_t)blockIdx.x * 8 + wave) * 8; o[0] = T1 - T0; o[1] = tk; o[2] = te; o[3] = ntile; o[4] = T2 - T1; o[5] = F2_TICK() - T0; o[6] = cg; o[7] = nks; }
+#else
+  (void)T0; (void)T1; (void)T2; (void)tk; (void)te; (void)ntile;
+#endif
 }
