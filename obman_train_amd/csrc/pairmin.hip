@@ -22,6 +22,7 @@ namespace {
 
 constexpr int PM_THREADS = 256;
 constexpr int PM_REF_TILE = 2048;  // float4 -> 32 KiB LDS per block
+constexpr int PM_CHUNK = 8;        // references per arg-min chunk of the general kernel
 constexpr float PM_BIG = 1.0e18f;  // padding coordinate: d = 3e36 < FLT_MAX, never wins
 typedef unsigned long long u64;
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
   const bool single = rend - rbeg <= d.tile;  // whole reference range stays in LDS: resolve indices from it
   for (int base = rbeg; base < rend; base += d.tile) {
     const int cnt = min(d.tile, rend - base);
-    const int slice = ((cnt + 15) >> 4) << 2;  // references per wave, multiple of 4
+    const int slice = ((cnt + 31) >> 5) << 3;  // references per wave, multiple of PM_CHUNK
     const int padded = slice * 4;
     for (int i = tid; i < padded; i += PM_THREADS) {
       float4 v = make_float4(PM_BIG, PM_BIG, PM_BIG, 0.f);
@@ -116,19 +117,26 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
     }
     __syncthreads();
     const int jbeg = wave * slice, jend = jbeg + slice;
-#pragma unroll 2
-    for (int j = jbeg; j < jend; j += 4) {
-      const float4 r0 = sref[j], r1 = sref[j + 1], r2 = sref[j + 2], r3 = sref[j + 3];
-      asm volatile("" ::"v"(r0.w), "v"(r1.w), "v"(r2.w), "v"(r3.w));  // keep the reads ds_read_b128 (b96 is 2x the LDS cycles)
+    // One iteration = a chunk of PM_CHUNK = 8 references, all eight LDS reads issued first (the compiler refused to unroll the
+    // 4-reference form: "loop not unrolled" x 3 in r03 - one exposed LDS round trip per 4 references).  Chunk minimum with
+    // v_min3 (3 + 1 instructions for 8 values instead of 2 x 3), ONE compare + two selects per chunk and query; the exact index
+    // inside the winning chunk is resolved afterwards (first index wins ties, as before).
+    for (int j = jbeg; j < jend; j += PM_CHUNK) {
+      float4 r[PM_CHUNK];
+#pragma unroll
+      for (int u = 0; u < PM_CHUNK; ++u) r[u] = sref[j + u];
+#pragma unroll
+      for (int u = 0; u < PM_CHUNK; ++u) asm volatile("" ::"v"(r[u].w));  // keep the reads ds_read_b128 (b96 is 2x the LDS cycles)
 #pragma unroll
       for (int p = 0; p < QP; ++p) {
-        const f2 e0 = pm_dist2_pk(qx[p], qy[p], qz[p], r0.x, r0.y, r0.z);
-        const f2 e1 = pm_dist2_pk(qx[p], qy[p], qz[p], r1.x, r1.y, r1.z);
-        const f2 e2 = pm_dist2_pk(qx[p], qy[p], qz[p], r2.x, r2.y, r2.z);
-        const f2 e3 = pm_dist2_pk(qx[p], qy[p], qz[p], r3.x, r3.y, r3.z);
+        f2 e[PM_CHUNK];
+#pragma unroll
+        for (int u = 0; u < PM_CHUNK; ++u) e[u] = pm_dist2_pk(qx[p], qy[p], qz[p], r[u].x, r[u].y, r[u].z);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float m = fminf(fminf(e0[h], e1[h]), fminf(e2[h], e3[h]));
+          const float m0 = __builtin_fminf(__builtin_fminf(e[0][h], e[1][h]), e[2][h]);  // v_min3_f32
+          const float m1 = __builtin_fminf(__builtin_fminf(e[3][h], e[4][h]), e[5][h]);
+          const float m = __builtin_fminf(__builtin_fminf(m0, m1), __builtin_fminf(e[6][h], e[7][h]));
           const bool better = m < best[2 * p + h];
           best[2 * p + h] = better ? m : best[2 * p + h];
           bestj[2 * p + h] = better ? base + j : bestj[2 * p + h];
@@ -154,13 +162,13 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
       const int j = s_grp[w][t];
       if (v < bv || (v == bv && j < bj)) { bv = v; bj = j; }
     }
-    // exact index inside the winning 4-reference group, re-evaluated with the same instruction sequence
+    // exact index inside the winning PM_CHUNK-reference chunk, re-evaluated with the same instruction sequence
     const float x = qb[(size_t)qi * 3], y = qb[(size_t)qi * 3 + 1], z = qb[(size_t)qi * 3 + 2];
     if (bj == 0x7fffffff) bj = rbeg;  // NaN inputs: nothing ever compared smaller
     int idx = bj;
-    float e[4];
+    float e[PM_CHUNK];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PM_CHUNK; ++u) {
       const int j = min(bj + u, rend - 1);
       if (single) {
         const float4 r = sref[j - rbeg];
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
       }
     }
 #pragma unroll
-    for (int u = 3; u >= 0; --u)  // descending so the FIRST matching index survives
+    for (int u = PM_CHUNK - 1; u >= 0; --u)  // descending so the FIRST matching index survives
       if (bj + u < rend && e[u] == bv) idx = bj + u;
     const size_t o = (size_t)b * d.nq + qi;
     if (d.rsplit == 1) {
@@ -732,15 +740,15 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   if (d0.rsplit > 1) (void)obman_fill_u32(d0.ws, 0xffffffffu, (size_t)2 * B * Nx, st);
   if (d1.rsplit > 1) (void)obman_fill_u32(d1.ws, 0xffffffffu, (size_t)2 * B * Ny, st);
   // LDS reference tile (points per staging pass); OBMAN_PM_TILE overrides the 2048-point cap for the tile sweep of
-  // BASELINE.json configs[4] (multiples of 16, <= 3072 so that tile + merge buffers stay under 64 KiB)
+  // BASELINE.json configs[4] (multiples of 32, <= 3072 so that tile + merge buffers stay under 64 KiB)
   static const int tile_cap = [] {
     const char* e = getenv("OBMAN_PM_TILE");
     int t = e ? atoi(e) : PM_REF_TILE;
-    t = (t / 16) * 16;
+    t = (t / 32) * 32;
     return t < 64 ? 64 : (t > 3072 ? 3072 : t);
   }();
   auto tile_of = [](const PmDir& d) {
-    int t = ((d.rchunk + 15) / 16) * 16;
+    int t = ((d.rchunk + 31) / 32) * 32;  // 4 waves x whole chunks of PM_CHUNK references
     return t > tile_cap ? tile_cap : t;
   };
   auto smem_of = [](int tile, int qpt) { return (size_t)tile * sizeof(float4) + (size_t)8 * 64 * qpt * sizeof(float); };
