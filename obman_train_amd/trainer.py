@@ -68,7 +68,10 @@ class GraphedTrainStep:
     no slack - and eight ranks of one node share the host's cores.  A replay is ONE launch call (~0.1 ms of host time).
 
     What makes the step recordable: every kernel of ``csrc/`` is launched on the caller's stream through the C-ABI with no
-    hidden allocation or synchronisation; the model's forward has no device->host read (masked means, mesh IoU and the hand-side
+    hidden allocation or synchronisation, and the launchers clear their scratch with fill KERNELS, never ``hipMemsetAsync`` - a
+    captured memset becomes a hipGraph memset node, and replays of the configs[2] step (the contact path clears three scratch
+    buffers per step) died with GPU memory faults in 9 of 12 runs until the graph held kernel nodes only
+    (profiles/r04_graph_fault.md; ``tests/test_memory_safety_gpu.py`` replays that configuration in both bf16 flavours); the model's forward has no device->host read (masked means, mesh IoU and the hand-side
     split are device-side); BatchNorm counters are bumped on the device; Adam is created with ``capturable=True``
     (``make_optimizer``).  MIOpen's solution search runs in the eager warm-up steps before the capture.
 
