@@ -1635,6 +1635,7 @@ L1Geo l1_geo(const Dims& d) {
   g.tiles = (sub + g.S - 1) / g.S;
   return g;
 }
+int device_cus();
 struct BwdWs {
   long GY2, GY1, sums, sred, k, l4p, l4red, P, Q, Pp, Qp, Ppre, dF, dG, seg, segw, tn, wt2, wt3, total;
   int chunks;
@@ -1657,7 +1658,16 @@ BwdWs bwd_ws(const Dims& d) {
     w.Pp = take((long)d.B * ch * d.ld1); w.Qp = take((long)d.B * ch * 3 * d.ld1);
   } else {
     const L1Geo g = l1_geo(d);
-    w.Pp = take((long)g.tiles * d.B * d.ld1); w.Qp = take((long)g.groups * d.N * d.ld1);
+    long pp = (long)g.tiles * d.B * d.ld1, qp = (long)g.groups * d.N * d.ld1;
+    if (!d.bf16) {  // the second-generation fp32 data-gradient kernel writes its own partials (F2EpiL1PQ): <= 8 CUs' waves per sample group
+      const long nbg = (d.B + 7) / 8, nvt = (d.N + 3) / 4;
+      long wpg = (long)device_cus() * 8 / nbg;
+      if (wpg > nvt) wpg = nvt;
+      if (wpg < 1) wpg = 1;
+      if (wpg * d.B * d.ld1 > pp) pp = wpg * d.B * d.ld1;
+      if (nbg * d.N * d.ld1 > qp) qp = nbg * d.N * d.ld1;
+    }
+    w.Pp = take(pp); w.Qp = take(qp);
   }
   w.Ppre = take(d.bf16 && l1_geo(d).tiles > PRE_MIN_ROWS ? (long)pre_segments((long)d.B * d.ld1) * d.B * d.ld1 : 0);  // same rule as pre_reduce
   {  // large-template layer-1 finalize: per-segment partials
@@ -2004,6 +2014,23 @@ int launch_rows2f_auto(const Dims& d, const AOp& a, const float* W, int ldw, int
   if (slots) *slots = g.mrows();
   return launch_rows2f<AOp, Epi<2>, 2>(a, W, ldw, w_kn, K, Nc, g, e2, st);
 }
+// layer-2 data gradient with P / Q partials from the accumulators (F2EpiL1PQ): row mode 2, every wave inside one sample group
+F2Geo f2_geo_pq(const Dims& d, int Nc, int NT) {
+  F2Geo g = f2_geo(d, Nc, NT, 2);  // block counts per column group as usual (the last group, which carries the side columns, has more)
+  const int cus = device_cus(), nbg = (d.B + 7) / 8;
+  if (g.ngroups == 1) g.slots_last = cus;       // f2_geo caps the block count by the tile count: here every wave counts
+  else {
+    const double w = g.wside ? 1.0 + (0.14 + 0.05 * g.wside) * 2.0 / NT : 1.0;
+    int last = (int)(cus * w / (g.ngroups - 1 + w) + 0.5), main_ = (cus - last) / (g.ngroups - 1);
+    g.slots = main_ < 1 ? 1 : main_;
+    g.slots_last = last < 1 ? 1 : last;
+  }
+  auto per_group = [&](int slots) { int w = slots * F2_WAVES / nbg; return w > g.nvt ? g.nvt : w; };
+  g.wpg = g.ngroups > 1 ? per_group(g.slots) : per_group(g.slots_last);
+  g.wpg_last = per_group(g.slots_last);
+  if (g.wpg < 1 || g.wpg_last < 1) g.wpg = g.wpg_last = 0;  // more sample groups than waves: the caller takes the materialised form
+  return g;
+}
 // the whole fp32 call takes the second-generation kernels or none of them (they share the pre-scaled factors and the zeroed pitch columns)
 bool use_rows2f(const Dims& d) {
   if (d.bf16 || d.ps || !rows2f_enabled()) return false;
@@ -2338,6 +2365,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
       if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
     }
     const bool f2 = use_rows2f(d);
+    int f2_prow = 0, f2_groups = 0;  // > 0: the layer-2 data gradient wrote P / Q partials itself (F2EpiL1PQ)
     srows = d.rb;
     if (f2) {  // gy2 = (gh3 W3) * (y2 > 0), BN-2 sums: second-generation kernel
       F2GradH3 a{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
@@ -2366,9 +2394,26 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
     if (f2) {  // gy1 = (gh2 W2) * (y1 > 0): second-generation kernel, mask from the pre-scaled factors
       F2GradH a{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, d.C2};
+      static const int pq_on = [] { const char* e = getenv("OBMAN_DEC_F2PQ"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = materialise gy1
+      const bool wide = f2_wide<F2GradH, F2EpiL1PQ<4>, F2EpiL1PQ<2>>(d, d.C2, d.C1) &&
+                        f2_geo(d, d.C1, 4, 2).tiles >= 4 * F2_WAVES * device_cus() / f2_geo(d, d.C1, 4, 2).ngroups;
+      const F2Geo gq = f2_geo_pq(d, d.C1, wide ? 4 : 2);
+      if (pq_on && gq.wpg > 0 && f2_lds_bytes<F2GradH, F2EpiL1PQ<2>, 2>(kpad8(d.C2), gq) <= F2_LDS_LIMIT) {
+        // P / Q partials straight from the accumulators: gy1 is never written, l1_reduce_kernel is not needed
+        if (wide) {
+          F2EpiL1PQ<4> e{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
+          if ((rc = launch_rows2f<F2GradH, F2EpiL1PQ<4>, 4>(a, p->w2, d.C1, 1, d.C2, d.C1, gq, e, st))) return rc;
+        } else {
+          F2EpiL1PQ<2> e{ws2 + v.Pp, ws2 + v.Qp, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
+          if ((rc = launch_rows2f<F2GradH, F2EpiL1PQ<2>, 2>(a, p->w2, d.C1, 1, d.C2, d.C1, gq, e, st))) return rc;
+        }
+        f2_prow = gq.prow();
+        f2_groups = (d.B + 7) / 8;
+      } else {
       F2EpiL1<4> e4{ws2 + v.GY1, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       F2EpiL1<2> e2{ws2 + v.GY1, ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       if ((rc = launch_rows2f_auto<F2GradH, F2EpiL1>(d, a, p->w2, d.C1, 1, d.C2, d.C1, e4, e2, 2, nullptr, st))) return rc;  // row mode 2: see F2EpiL1
+      }
     } else {  // gy1 = (gh2 W2) * (y1 > 0)
       EpiMaskStatsImpl e;
       e.C = ws2 + v.GY1; e.sums = sums; e.ldc = d.ld1; e.R = R; e.Nc = d.C1; e.mode = 1;
@@ -2390,12 +2435,19 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
       l1ps_finalize_kernel<<<obman_cdiv(d.C1, 256), 256, 0, st>>>(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.C1, ch, ws2 + v.dF, g->b1, g->w1);
       OBMAN_LAUNCH_CHECK();
     } else {
-    // ---- layer 1 in factored form: P[b,c] = sum_n gy1, Q[n,c] = sum_b gy1 from one read of gy1
+    // ---- layer 1 in factored form: P[b,c] = sum_n gy1, Q[n,c] = sum_b gy1 from one read of gy1 - or, with the second-generation
+    // data-gradient kernel, from the partials its epilogue wrote (f2_prow > 0)
     const L1Geo lg = l1_geo(d);
-    l1_reduce_kernel<<<dim3(lg.tiles, lg.groups, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, lg.S, ws2 + v.Pp,
-                                                                                         ws2 + v.Qp);
-    OBMAN_LAUNCH_CHECK();
-    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, lg.tiles, lg.groups,
+    int prow = lg.tiles, groups = lg.groups;
+    if (f2_prow > 0) {
+      prow = f2_prow;
+      groups = f2_groups;
+    } else {
+      l1_reduce_kernel<<<dim3(lg.tiles, lg.groups, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.GY1, d.ld1, d.B, d.N, d.C1, lg.S, ws2 + v.Pp,
+                                                                                           ws2 + v.Qp);
+      OBMAN_LAUNCH_CHECK();
+    }
+    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, groups,
                                                                                 ws2 + v.P, ws2 + v.Q);
     OBMAN_LAUNCH_CHECK();
     }

@@ -47,6 +47,10 @@ struct F2Geo {
   int slots;    // blocks per column group (all groups but the last)
   int slots_last;  // blocks of the LAST column group: it also carries the side columns on the VALU and gets fewer tiles per block
   int wside;    // side-column rows of the weight slice actually present (0 .. F2_SIDE)
+  int wpg;      // > 0 (row mode 2 only): every wave stays inside ONE sample group - wpg waves per group (wpg_last in the last
+  int wpg_last; //   column group, which has more blocks), nvt / wpg consecutive vertex tiles each - so that sums over a sample's
+                //   vertices can stay in registers across tiles (F2EpiL1PQ)
+  __host__ __device__ int prow() const { return wpg > wpg_last ? wpg : wpg_last; }  // P partial rows per sample
   __host__ __device__ int mrows() const { return ngroups > 1 && slots > slots_last ? slots : slots_last; }  // rows of the per-block partials
   // row i (0 .. 31) of tile t
   __device__ __forceinline__ void rowof(int t, int i, long& r, int& b, int& n, bool& ok) const {
@@ -180,7 +184,7 @@ struct F2GradH3 {  // gh3 = (y3 > 0 ? f * g . (ka * W4) : 0) + kb * h + kc, gy3 
 };
 
 // ------------------------------------------------------------------------------------------------ epilogues
-struct F2Ctx { int lane, wave, c0, nside, last_group, slot, my_slots, mrows, t; long r0; int b0, n0; };  // r0 (mode 0) / b0, n0 (mode 2): the tile's first row
+struct F2Ctx { int lane, wave, c0, nside, last_group, slot, my_slots, mrows, t; long r0; int b0, n0; int pq_wi, pq_wpg; };  // r0 (mode 0) / b0, n0 (mode 2): the tile's first row
 
 // fp64 sums held by (two lane halves) x (eight waves) -> dst[(slot * Nc + col) * 2 + {0,1}], fixed order.  `smem` is the (dead)
 // weight slice; called by every thread of the block after its last tile.
@@ -360,7 +364,7 @@ struct F2EpiStore {  // C[r,n] = acc + bias[n]; fp64 column moments (sum, sum of
       f2_zero_pitch(C, ldc, Nc, geo, c);
     }
   }
-  __device__ __forceinline__ void flush(State& s, const F2Ctx& c, char* smem) const {
+  __device__ __forceinline__ void flush(State& s, const F2Ctx& c, const F2Geo&, char* smem) const {
     if (moments) f2_flush_cols<NT>(s.d1, s.d2, s.e1, s.e2, c, Nc, moments, smem);
   }
 };
@@ -469,7 +473,7 @@ struct F2EpiMask {  // C = acc * (y > 0), y = s*H+t; column sums S1 = sum C, S2 
       f2_zero_pitch(C, ldc, Nc, geo, c);
     }
   }
-  __device__ __forceinline__ void flush(State& q, const F2Ctx& c, char* smem) const { f2_flush_cols<NT>(q.d1, q.d2, q.e1, q.e2, c, Nc, sums, smem); }
+  __device__ __forceinline__ void flush(State& q, const F2Ctx& c, const F2Geo&, char* smem) const { f2_flush_cols<NT>(q.d1, q.d2, q.e1, q.e2, c, Nc, sums, smem); }
 };
 
 template <int NT>
@@ -541,7 +545,121 @@ struct F2EpiL1 {  // gy1 = acc * (y1 > 0), y1 > 0 <=> Gy[n] + Fy[b] > 0 (the for
       f2_zero_pitch(C, ldc, Nc, geo, c);
     }
   }
-  __device__ __forceinline__ void flush(State&, const F2Ctx&, char*) const {}
+  __device__ __forceinline__ void flush(State&, const F2Ctx&, const F2Geo&, char*) const {}
+};
+
+template <int NT>
+struct F2EpiL1PQ {  // dA(gy1) WITHOUT gy1: layer 1 only needs P[b,c] = sum_n gy1 and Q[n,c] = sum_b gy1 (the fp32 counterpart of EpiL1B2)
+  // gy1 = acc * (Gy[n] + Fy[b] > 0).  Row mode 2 with wpg > 0: a wave's tiles all belong to ONE sample group.  Accumulator
+  // register q = 4 m + v of lane (col, h): sample b0 + 2 m + h, vertex n0 + v.
+  //   P: the sum over a tile's 4 vertices is in-lane; it keeps accumulating IN REGISTERS over all tiles of the wave and leaves
+  //      once:  Pp[wave index inside the sample group][b][c]  (l1_reduce2_kernel adds the wpg partials in order).
+  //   Q: the sum over the tile's 8 samples is in-lane over m plus one exchange with the other lane half:
+  //      Qp[sample group][n][c]  (each (group, vertex tile) is written by exactly one wave).
+  // Against the materialised form: no [R, 515] fp32 store (87 MB at 64 x 642 points, 2.2 GB at 16 050) and no l1_reduce pass.
+  float *Pp, *Qp;
+  const float *Gy, *Fy;
+  int ldc, Nc;
+  static constexpr int LDS_FLOATS = 0;
+  struct State { float p[4][NT]; float ps[F2_SIDE]; };
+  struct Pre { float g[NT][4], f[NT][4]; };
+  __device__ __forceinline__ void init(State& s, const F2Ctx&) const {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) s.p[m][j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < F2_SIDE; ++u) s.ps[u] = 0.f;
+  }
+  __device__ __forceinline__ void prefetch(Pre& p, const State&, const F2Ctx& c, const F2Geo& geo) const {
+    const int li = c.lane & 31, h = c.lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = c.c0 + j * 32 + li;
+      const bool cok = col < Nc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int n = c.n0 + v, b = c.b0 + 2 * v + h;
+        p.g[j][v] = (cok && n < geo.N) ? Gy[(size_t)n * ldc + col] : -3.0e38f;  // rows / columns outside the problem: mask false
+        p.f[j][v] = (cok && b < geo.B) ? Fy[(size_t)b * ldc + col] : -3.0e38f;
+      }
+    }
+  }
+  __device__ __forceinline__ void tile(State& s, const Pre& p, const f32x16 (&acc)[NT], const float (&side)[F2_SIDE], const F2Ctx& c, const F2Geo& geo) const {
+    const int li = c.lane & 31, h = c.lane >> 5;
+    const int bg = c.b0 >> 3;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float gv = p.g[j][v] + p.f[j][m] > 0.f ? acc[j][4 * m + v] : 0.f;
+          q[v] += gv;
+          s.p[m][j] += gv;
+        }
+      }
+      const int col = c.c0 + j * 32 + li;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float tot = q[v] + __shfl_xor(q[v], 32, 64);  // the other four samples of the tile
+        if (h == 0 && col < Nc && c.n0 + v < geo.N) Qp[((size_t)bg * geo.N + c.n0 + v) * ldc + col] = tot;
+      }
+    }
+    if (c.nside) {  // side columns: lane i < 32 holds tile row i = sample i >> 2, vertex i & 3
+      const int b = c.b0 + (li >> 2), n = c.n0 + (li & 3);
+      const bool live = c.lane < 32 && b < geo.B && n < geo.N;
+#pragma unroll
+      for (int u = 0; u < F2_SIDE; ++u) {
+        if (u < c.nside) {
+          const int col = c.c0 + 32 * NT + u;
+          const float yv = live ? Gy[(size_t)n * ldc + col] + Fy[(size_t)b * ldc + col] : 0.f;
+          const float gv = (live && yv > 0.f) ? side[u] : 0.f;
+          float pv = gv + __shfl_xor(gv, 1, 64);  // over the sample's 4 vertices
+          pv += __shfl_xor(pv, 2, 64);
+          s.ps[u] += pv;                          // lanes with (li & 3) == 0 carry sample li >> 2
+          float qs = gv + __shfl_xor(gv, 4, 64);  // over the tile's 8 samples
+          qs += __shfl_xor(qs, 8, 64);
+          qs += __shfl_xor(qs, 16, 64);
+          if (c.lane < 4 && c.n0 + c.lane < geo.N) Qp[((size_t)bg * geo.N + c.n0 + c.lane) * ldc + col] = qs;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void flush(State& s, const F2Ctx& c, const F2Geo& geo, char*) const {
+    // every wave that owns tiles writes the P partial of its 8 samples (waves without tiles own no partial slot: geo.wpg counts
+    // only waves with work, see f2_geo_pq)
+    const int li = c.lane & 31, h = c.lane >> 5;
+    if (c.t < 0) return;  // no tile processed
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int b = c.b0 + 2 * m + h;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = c.c0 + j * 32 + li;
+        if (b < geo.B && col < Nc) Pp[((size_t)c.pq_wi * geo.B + b) * ldc + col] = s.p[m][j];
+      }
+    }
+    if (c.nside && c.lane < 32 && (li & 3) == 0 && c.b0 + (li >> 2) < geo.B) {
+#pragma unroll
+      for (int u = 0; u < F2_SIDE; ++u)
+        if (u < c.nside) Pp[((size_t)c.pq_wi * geo.B + c.b0 + (li >> 2)) * ldc + c.c0 + 32 * NT + u] = s.ps[u];
+    }
+    if (c.pq_wi == 0) {  // a column group with fewer waves per sample group than the widest one: its missing partial rows read as zeros
+      for (int z = c.pq_wpg; z < geo.prow(); ++z) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int b = c.b0 + 2 * m + h;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int col = c.c0 + j * 32 + li;
+            if (b < geo.B && col < Nc) Pp[((size_t)z * geo.B + b) * ldc + col] = 0.f;
+          }
+        }
+      }
+    }
+  }
 };
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -601,7 +719,7 @@ __global__ __launch_bounds__(F2_THREADS) void rows2f_kernel(AOp aop, const float
   const unsigned long long T1 = F2_TICK();
   unsigned long long tk = 0, te = 0, ntile = 0;
 
-  F2Ctx ctx{lane, wave, c0, nside, last_group, slot, my_slots, geo.mrows(), 0, 0, 0, 0};
+  F2Ctx ctx{lane, wave, c0, nside, last_group, slot, my_slots, geo.mrows(), -1, 0, 0, 0, 0, 0};
   typename Epi::State est;
   epi.init(est, ctx);
   const int nks = Kp >> 3;
@@ -611,8 +729,22 @@ __global__ __launch_bounds__(F2_THREADS) void rows2f_kernel(AOp aop, const float
   // instead of to both waves of the SIMDs of some CUs - the matrix pipe is per SIMD.
   const int stride = my_slots * F2_WAVES;
   const int vwave = wave < 4 ? slot * 4 + wave : my_slots * 4 + slot * 4 + (wave - 4);
+  // wpg > 0: wave vwave owns vertex tiles [wi * chunk, (wi + 1) * chunk) of sample group vwave / wpg (contiguous, one group)
+  const int my_wpg = last_group ? geo.wpg_last : geo.wpg;
+  const int pq_bg = my_wpg > 0 ? vwave / my_wpg : 0, pq_wi = my_wpg > 0 ? vwave - pq_bg * my_wpg : 0;
+  const int nbg = geo.nvt > 0 ? geo.tiles / geo.nvt : 0;
+  int t_beg = vwave, t_end = geo.tiles, t_step = stride;
+  if (my_wpg > 0) {  // nvt tiles over wpg waves as evenly as they go: the first nvt % wpg waves take one more (nvt / wpg >= 1)
+    const int chunk = geo.nvt / my_wpg, rem = geo.nvt - chunk * my_wpg;
+    const int v0 = pq_wi * chunk + (pq_wi < rem ? pq_wi : rem), v1 = v0 + chunk + (pq_wi < rem ? 1 : 0);
+    t_beg = pq_bg * geo.nvt + v0;
+    t_end = pq_bg < nbg && v0 < v1 ? pq_bg * geo.nvt + v1 : t_beg;
+    t_step = 1;
+  }
+  ctx.pq_wi = pq_wi;
+  ctx.pq_wpg = my_wpg;
 #pragma unroll 1
-  for (int t = vwave; t < geo.tiles; t += stride) {
+  for (int t = t_beg; t < t_end; t += t_step) {
     ctx.t = t;
     ctx.r0 = (long)t * 32;
     if (geo.mode != 0) { const int bg = t / geo.nvt; ctx.b0 = bg * 8; ctx.n0 = (t - bg * geo.nvt) * 4; }
@@ -708,7 +840,7 @@ __global__ __launch_bounds__(F2_THREADS) void rows2f_kernel(AOp aop, const float
     tk += TB - TA; te += F2_TICK() - TB; ++ntile;
   }
   const unsigned long long T2 = F2_TICK();
-  epi.flush(est, ctx, smem);
+  epi.flush(est, ctx, geo, smem);
 #ifdef OBMAN_F2_TIMING
   if (lane == 0 && blockIdx.x < 256) { unsigned long long* o = f2_dbg + ((size_t)blockIdx.x * 8 + wave) * 8; o[0] = T1 - T0; o[1] = tk; o[2] = te; o[3] = ntile; o[4] = T2 - T1; o[5] = F2_TICK() - T0; o[6] = cg; o[7] = nks; }
 #else
