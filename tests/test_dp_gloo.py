@@ -187,3 +187,41 @@ def test_single_process_is_a_noop():
     b = GradientBuckets(net.parameters())
     assert not b.enabled
     b.finish()
+
+
+def _layout_worker(rank, world, port, out_dir):
+    """A directly reduced channels_last filter whose gradient arrives CONTIGUOUS on one rank (a backward kernel that chose
+    another dense layout) while the other rank has no gradient at all and contributes zeros laid out like the parameter."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from obman_train_amd.dp import GradientBuckets
+
+    torch.manual_seed(0)
+    w = nn.Parameter(torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last))
+    small = nn.Parameter(torch.randn(5))
+    buckets = GradientBuckets([w, small], direct_bytes=512)  # w (1152 bytes) is all-reduced in place
+    assert buckets.buckets[buckets._where[w]][0] is None
+    buckets.zero_grad()
+    g = torch.arange(8 * 4 * 3 * 3, dtype=torch.float32).reshape(8, 4, 3, 3)  # logical values; contiguous (NOT channels_last) memory
+    if rank == 0:
+        w.grad = g.clone()
+        buckets._on_grad(w)  # what the post-accumulate hook does
+        small.grad = torch.ones(5)
+        buckets._on_grad(small)
+    else:
+        small.grad = torch.ones(5) * 3
+        buckets._on_grad(small)  # w receives no gradient on this rank
+    buckets.finish()
+    torch.save({"w": w.grad.clone(), "stride": w.grad.stride(), "small": small.grad.clone()}, os.path.join(out_dir, "layout_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_direct_gradient_is_normalised_to_the_parameter_layout(tmp_path):
+    """the collective reduces raw memory, so every rank must hand over the same element order."""
+    world, port = 2, _free_port()
+    mp.start_processes(_layout_worker, args=(world, port, str(tmp_path)), nprocs=world, start_method="spawn")
+    want = torch.arange(8 * 4 * 3 * 3, dtype=torch.float32).reshape(8, 4, 3, 3) / 2  # mean of (g, zeros), element by element
+    for rank in range(world):
+        got = torch.load(os.path.join(str(tmp_path), "layout_%d.pt" % rank))
+        torch.testing.assert_close(got["w"], want, rtol=0, atol=0)
+        torch.testing.assert_close(got["small"], torch.full((5,), 2.0), rtol=0, atol=0)

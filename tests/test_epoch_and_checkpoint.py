@@ -148,3 +148,16 @@ def test_save_results_writes_reference_layout(golden, monkeypatch, tmp_path):
     assert data["results"]["objfaces"].shape == (320, 3)
     assert data["results"]["contact_info"]["repulsion_masks"].shape == (3, 778)
     assert data["sample"]["sides"] == ["left", "left", "right"] and "images" in data["sample"]
+
+
+def test_graphed_step_compares_host_entries_of_any_type():
+    """ADVICE r03 (trainer.py): numpy-array and list entries of a sample must compare without 'truth value is ambiguous'."""
+    import numpy as np
+
+    from obman_train_amd.trainer import _same_entry
+
+    assert _same_entry(["left", "right"], ["left", "right"]) and not _same_entry(["left", "right"], ["left", "left"])
+    assert _same_entry(np.arange(4), np.arange(4)) and not _same_entry(np.arange(4), np.arange(4) + 1)
+    assert _same_entry(np.arange(4), [0, 1, 2, 3]) and not _same_entry(np.zeros((2, 2)), np.zeros(4))
+    assert _same_entry("wrist", "wrist") and not _same_entry("wrist", "palm")
+    assert _same_entry(None, None) and not _same_entry(None, "wrist") and not _same_entry(3, None)
