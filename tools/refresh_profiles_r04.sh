@@ -48,4 +48,5 @@ bash tools/pmc_mfma.sh f32:1 > $out/${tag}_pmc_mfma_f32_c2.txt 2>&1
 bash tools/pmc_mfma.sh f32:25 > $out/${tag}_pmc_mfma_f32_c3.txt 2>&1
 bash tools/pmc_mfma.sh bf16:25 > $out/${tag}_pmc_mfma_bf16_c3.txt 2>&1
 bash tools/pmc_dec.sh bf16:25 > $out/${tag}_pmc_dec_bf16_c3.txt 2>&1
+bash tools/pmc_dec.sh f32:25 > $out/${tag}_pmc_dec_f32_c3.txt 2>&1
 ls $out | grep "^${tag}_" | wc -l
