@@ -769,6 +769,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 #include "decoder_rows2.h"
 #include "decoder_tn2.h"
 #include "decoder_rows2f.h"
+#include "decoder_tn3.h"
 
 }  // namespace dec
 
@@ -2057,6 +2058,34 @@ F2Geo f2_geo_pq(const Dims& d, int Nc, int NT) {
   if (g.wpg < 1 || g.wpg_last < 1) g.wpg = g.wpg_last = 0;  // more sample groups than waves: the caller takes the materialised form
   return g;
 }
+// ---- second-generation fp32 weight-gradient GEMM (decoder_tn3.h)
+bool tn3_enabled() {
+  static const int on = [] { const char* e = getenv("OBMAN_DEC_TN3"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = first-generation gemm_tn_kernel
+  return on != 0;
+}
+bool tn3_ok(int M, int Nc) { return tn3_enabled() && M >= T3_BM && M % T3_BM <= T3_SIDE && Nc >= T3_BN && Nc % T3_BN <= T3_SIDE; }
+template <class AOp, class BOp>
+int launch_tn3(const AOp& a, const BOp& b, int M, int Nc, long R, int N, float* part, float* out, int ldo, int off, hipStream_t st) {
+  T3Geo g{};
+  g.M = M; g.Nc = Nc; g.R = (int)R; g.N = N;
+  g.mt = M / T3_BM; g.ms = M - g.mt * T3_BM; g.nt = Nc / T3_BN; g.ns = Nc - g.nt * T3_BN;
+  const int tiles = g.mt * g.nt;
+  // one block per CU; never more chunks than the first generation would use (the split-K partials share its workspace: bwd_ws)
+  const int rows1 = tn_chunk_rows(M, Nc, R);
+  const int max_chunks = (int)((R + rows1 - 1) / rows1);
+  int chunks = device_cus() / tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks > max_chunks) chunks = max_chunks;
+  long rows = (R + chunks - 1) / chunks;
+  rows = (rows + T3_KB - 1) / T3_KB * T3_KB;
+  g.chunk_rows = (int)rows;
+  g.chunks = (int)((R + rows - 1) / rows);
+  tn3_kernel<AOp, BOp><<<(unsigned)(tiles * g.chunks), T3_THREADS, sizeof(T3Tiles), st>>>(a, b, g, part);
+  OBMAN_LAUNCH_CHECK();
+  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, g.chunks, M, Nc, ldo, off, out);
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
 // the whole fp32 call takes the second-generation kernels or none of them (they share the pre-scaled factors and the zeroed pitch columns)
 bool use_rows2f(const Dims& d) {
   if (d.bf16 || d.ps || !rows2f_enabled()) return false;
@@ -2386,7 +2415,11 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
                                                                    g->bn_b[2], g->b3, k1, k2, k3);
     OBMAN_LAUNCH_CHECK();
     AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
-    {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
+    if (use_rows2f(d) && tn3_ok(d.C3, d.C2)) {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]: second-generation kernel
+      T3GradH3 ta{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
+      T3BnRelu tb{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
+      if ((rc = launch_tn3<T3GradH3, T3BnRelu>(ta, tb, d.C3, d.C2, d.R, d.N, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
+    } else {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
       ABnRelu a2{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, R, d.C2};
       if ((rc = launch_tn<AGradH3, ABnRelu>(gh3, a2, d.C3, d.C2, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
     }
@@ -2417,7 +2450,11 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     // gW2[o,c] = sum_r gh2[r,o] a1[r,c].  (Tried in r02 and dropped: [256 x 512] on the tile grid + the 257th row and the last
     // three columns on VALU edge kernels - the tile kernel went 244 -> 146 us, the extra passes over the regenerated operands
     // cost 180 us; profiles/r02_kernels.md.)
-    if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
+    if (f2 && tn3_ok(d.C2, d.C1)) {  // second-generation kernel, layer-1 activation from the pre-scaled factors
+      T3GradH ta{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, d.C2};
+      T3Pre tb{ws + w.Gy, ws + w.Fy, d.ld1, d.N};
+      if ((rc = launch_tn3<T3GradH, T3Pre>(ta, tb, d.C2, d.C1, d.R, d.N, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
+    } else if ((rc = launch_tn<AGradH, AGridFeat>(gh2, a1, d.C2, d.C1, d.R, TN_CHUNK_ROWS, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
     if (f2) {  // gy1 = (gh2 W2) * (y1 > 0): second-generation kernel, mask from the pre-scaled factors
       F2GradH a{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, d.C2};
       static const int pq_on = [] { const char* e = getenv("OBMAN_DEC_F2PQ"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = materialise gy1
