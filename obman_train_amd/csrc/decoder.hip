@@ -2063,11 +2063,11 @@ bool tn3_enabled() {
   static const int on = [] { const char* e = getenv("OBMAN_DEC_TN3"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = first-generation gemm_tn_kernel
   return on != 0;
 }
-bool tn3_ok(int M, int Nc) { return tn3_enabled() && M >= T3_BM && M % T3_BM <= T3_SIDE && Nc >= T3_BN && Nc % T3_BN <= T3_SIDE; }
+bool tn3_ok(int M, int Nc, int N) { return tn3_enabled() && N >= T3_KB && M >= T3_BM && M % T3_BM <= T3_SIDE && Nc >= T3_BN && Nc % T3_BN <= T3_SIDE; }
 template <class AOp, class BOp>
 int launch_tn3(const AOp& a, const BOp& b, int M, int Nc, long R, int N, float* part, float* out, int ldo, int off, hipStream_t st) {
   T3Geo g{};
-  g.M = M; g.Nc = Nc; g.R = (int)R; g.N = N;
+  g.M = M; g.Nc = Nc; g.R = (int)R; g.N = N; g.B = (int)(R / N);
   g.mt = M / T3_BM; g.ms = M - g.mt * T3_BM; g.nt = Nc / T3_BN; g.ns = Nc - g.nt * T3_BN;
   const int tiles = g.mt * g.nt;
   // one block per CU; never more chunks than the first generation would use (the split-K partials share its workspace: bwd_ws)
@@ -2080,6 +2080,16 @@ int launch_tn3(const AOp& a, const BOp& b, int M, int Nc, long R, int N, float* 
   rows = (rows + T3_KB - 1) / T3_KB * T3_KB;
   g.chunk_rows = (int)rows;
   g.chunks = (int)((R + rows - 1) / rows);
+#ifdef OBMAN_T3_DBG
+  g.dbg = getenv("OBMAN_T3_DBG") ? atoi(getenv("OBMAN_T3_DBG")) : 0;
+#endif
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if (!granted[dev].load(std::memory_order_relaxed)) {  // > 64 KB of dynamic LDS
+    const hipError_t err = hipFuncSetAttribute((const void*)tn3_kernel<AOp, BOp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(T3Tiles));
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store(1, std::memory_order_relaxed);
+  }
   tn3_kernel<AOp, BOp><<<(unsigned)(tiles * g.chunks), T3_THREADS, sizeof(T3Tiles), st>>>(a, b, g, part);
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, g.chunks, M, Nc, ldo, off, out);
@@ -2415,7 +2425,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
                                                                    g->bn_b[2], g->b3, k1, k2, k3);
     OBMAN_LAUNCH_CHECK();
     AGradH3 gh3{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, R, d.C3};
-    if (use_rows2f(d) && tn3_ok(d.C3, d.C2)) {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]: second-generation kernel
+    if (use_rows2f(d) && tn3_ok(d.C3, d.C2, d.N)) {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]: second-generation kernel
       T3GradH3 ta{g_out, p->w4, ws + w.H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
       T3BnRelu tb{ws + w.H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
       if ((rc = launch_tn3<T3GradH3, T3BnRelu>(ta, tb, d.C3, d.C2, d.R, d.N, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
@@ -2450,7 +2460,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     // gW2[o,c] = sum_r gh2[r,o] a1[r,c].  (Tried in r02 and dropped: [256 x 512] on the tile grid + the 257th row and the last
     // three columns on VALU edge kernels - the tile kernel went 244 -> 146 us, the extra passes over the regenerated operands
     // cost 180 us; profiles/r02_kernels.md.)
-    if (f2 && tn3_ok(d.C2, d.C1)) {  // second-generation kernel, layer-1 activation from the pre-scaled factors
+    if (f2 && tn3_ok(d.C2, d.C1, d.N)) {  // second-generation kernel, layer-1 activation from the pre-scaled factors
       T3GradH ta{ws2 + v.GY2, ws + w.H2, k1, k2, k3, d.ld2, d.C2};
       T3Pre tb{ws + w.Gy, ws + w.Fy, d.ld1, d.N};
       if ((rc = launch_tn3<T3GradH, T3Pre>(ta, tb, d.C2, d.C1, d.R, d.N, ws2 + v.tn, g->w2, d.C1, 0, st))) return rc;
