@@ -11,7 +11,7 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
 import csv, sys, collections
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if r["Counter_Name"] == sys.argv[2] and ("gemm_" in r["Kernel_Name"] or "_bf16_kernel" in r["Kernel_Name"] or "rows2f_kernel" in r["Kernel_Name"]):
+    if r["Counter_Name"] == sys.argv[2] and ("gemm_" in r["Kernel_Name"] or "_bf16_kernel" in r["Kernel_Name"] or "rows2f_kernel" in r["Kernel_Name"] or "tn3_kernel" in r["Kernel_Name"]):
         acc[r["Kernel_Name"][:95]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(sys.argv[2], "%-95s n=%3d avg=%.4g" % (k, len(v), sum(v) / len(v)))

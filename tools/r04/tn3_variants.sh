@@ -13,7 +13,7 @@ for lib in $GRAFT_REPO_ROOT/tools/r04/variants/*.so; do
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    if "tn3" in n:
+    if "tn3" in n or "rows2f" in n:
         print("%-60s avg %8.1f us" % (n.replace("void dec::", "").replace("dec::", "")[:60], float(r["AverageNs"]) / 1e3))
 PY
   done
