@@ -144,12 +144,12 @@ class AtlasLoss:
                 mesh = preds["objpointscentered3d"]
                 sym_final = self._sym(preds["objpoints3d"], gt)
                 out["final_{}_loss".format(self.atlas_loss)] = sym_final
-                final = (self.lambda_atlas * sym + self.final_lambda_atlas * sym_final
-                         + self.trans_weight * l_trans + self.scale_weight * l_scale)
+                terms = [(self.lambda_atlas, sym), (self.final_lambda_atlas, sym_final), (self.trans_weight, l_trans),
+                         (self.scale_weight, l_scale)]  # summed in this order (ops.weighted_terms)
             else:
                 if "objpoints3d" in preds and self.lambda_atlas:
                     sym = self._sym(preds["objpoints3d"], gt)
-                    final = self.lambda_atlas * sym
+                    terms = [(self.lambda_atlas, sym)]
                     mesh = preds["objpoints3d"]
                 else:
                     # reference: UnboundLocalError at atlasbranch.py:285 (default CLI flags; App. C #3)
@@ -159,11 +159,12 @@ class AtlasLoss:
             if self.edge_regul_lambda is not None and self.edge_regul_lambda > 0:
                 l_edge = edge_loss(mesh, preds["objfaces"])
                 out["atlas_edge_regul"] = l_edge
-                final = final + self.edge_regul_lambda * l_edge
+                terms.append((self.edge_regul_lambda, l_edge))
             if self.lambda_laplacian:
                 l_lap = self.laplacian_loss(mesh)
                 out["atlas_laplac"] = l_lap
-                final = final + self.lambda_laplacian * l_lap
+                terms.append((self.lambda_laplacian, l_lap))
+            final = ops.weighted_terms(terms, terms[0][1].shape)
         else:
             sym = None
             final = torch.zeros(1, device=preds["objpoints3d"].device)

@@ -98,31 +98,32 @@ class ManoLoss:
 
     def compute_loss(self, preds, target):
         dev = preds["verts"].device
-        final = torch.zeros(1, device=dev)
+        terms = []  # (lambda, term) in the reference's order: ``final = zeros(1); final += lambda * term`` (ops.weighted_terms)
         out = {}
         if TransQueries.verts3d in target and self.lambda_verts:
             l_verts = torch_f.mse_loss(preds["verts"], target[TransQueries.verts3d])
-            final += self.lambda_verts * l_verts
+            terms.append((self.lambda_verts, l_verts))
         else:
             l_verts = None
         out["mano_verts3d"] = l_verts
         if TransQueries.joints3d in target and self.lambda_joints3d:
             l_joints = torch_f.mse_loss(preds["joints"], target[TransQueries.joints3d])
-            final += self.lambda_joints3d * l_joints
+            terms.append((self.lambda_joints3d, l_joints))
             out["mano_joints3d"] = l_joints
         if self.lambda_shape:
             l_shape = torch_f.mse_loss(preds["shape"], torch.zeros_like(preds["shape"]))
-            final += self.lambda_shape * l_shape
+            terms.append((self.lambda_shape, l_shape))
         else:
             l_shape = None
         out["mano_shape"] = l_shape
         if self.lambda_pose_reg:
             reg = preds["pose"][:, 3:]
             l_pose = torch_f.mse_loss(reg, torch.zeros_like(reg))
-            final += self.lambda_pose_reg * l_pose
+            terms.append((self.lambda_pose_reg, l_pose))
             out["pose_reg"] = l_pose
         if BaseQueries.hand_pcas in target and self.lambda_pca:
             raise KeyError("pcas")  # the reference reads preds['pcas'], which ManoBranch never produces (App. C #14)
         out["mano_pca"] = None
+        final = ops.weighted_terms(terms, (1,)) if terms else torch.zeros(1, device=dev)
         out["mano_total_loss"] = final
         return final, out

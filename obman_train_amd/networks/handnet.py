@@ -168,7 +168,8 @@ class HandNet(nn.Module):
                         contact_ious, contact_auc = meshiou(dist_h2o_gt, contact_infos["min_dists"])
                         contact_infos["batch_ious"] = contact_ious
                         losses["contact_auc"] = contact_auc
-                    contact_loss = self.contact_lambda * attr_loss + self.collision_lambda * penetr_loss
+                    contact_loss = ops.weighted_terms([(self.contact_lambda, attr_loss), (self.collision_lambda, penetr_loss)],
+                                                      attr_loss.shape)
                     total_loss += contact_loss
                     losses["penetration_loss"] = penetr_loss
                     losses["attraction_loss"] = attr_loss

@@ -477,6 +477,53 @@ def bn_act(bn, x, skip=None, relu=True, count=True):
     return _BNAct.apply(x, skip, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum, relu)
 
 
+_TERM_WEIGHTS = {}  # (device, weights) -> fp32 tensor on the device; a handful of entries (the lambdas change once per decay epoch)
+
+
+class _WeightedTerms(torch.autograd.Function):
+    """``sum_i w[i] * terms[i]`` of scalar loss terms: three kernels forward, one backward, whatever the number of terms."""
+
+    @staticmethod
+    def forward(ctx, w, *terms):
+        ctx.save_for_backward(w)
+        ctx.shapes = [t.shape for t in terms]
+        return (torch.stack([t.reshape(()) for t in terms]) * w).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        gw = g * w
+        return (None,) + tuple(gw[i].reshape(shape) for i, shape in enumerate(ctx.shapes))
+
+
+def weighted_terms(pairs, shape=()):
+    """The loss compositions of the reference - ``final = Tensor([0]); final += lambda_i * term_i`` (``manobranch.py:252-318``),
+    ``lambda_a * a + lambda_b * b + ...`` (``atlasbranch.py:247-280``, ``handnet.py:363-366``) - for ``pairs = [(lambda_i, term_i), ...]``.
+
+    Off the GPU: exactly those operations in that order (``0 + x`` is ``x``).  On a ROCm device the 2 - 3 one-element kernels per term
+    and direction (scalar multiply, broadcast add, the ``sum`` that undoes the broadcast in the backward: ~90 us of a 10.9 ms
+    configs[1] step, profiles/r04_kernels.md section 4) become one stack + multiply + sum, and one multiply in the backward; the
+    value differs from the sequential form by the summation order of <= 6 fp32 terms."""
+    tensors = [t for _, t in pairs if torch.is_tensor(t)]
+    if tensors and tensors[0].is_cuda and all(t.numel() == 1 and t.dtype == torch.float32 for t in tensors):
+        const = sum(w * t for w, t in pairs if not torch.is_tensor(t))  # ``scale_weight * 0`` without a scale head (TypeError for a None weight, as in the reference)
+        if const != 0:
+            raise ValueError("weighted_terms: python-number terms other than 0 are not part of any reference composition")
+        pairs = [(w, t) for w, t in pairs if torch.is_tensor(t)]
+        dev = tensors[0].device
+        key = (dev, tuple(float(w) for w, _ in pairs))
+        w = _TERM_WEIGHTS.get(key)
+        if w is None:
+            if len(_TERM_WEIGHTS) > 256:
+                _TERM_WEIGHTS.clear()
+            w = _TERM_WEIGHTS[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+        return _WeightedTerms.apply(w, *tensors).reshape(shape)
+    acc = None
+    for w, t in pairs:
+        acc = w * t if acc is None else acc + w * t
+    return acc.reshape(shape) if torch.is_tensor(acc) else acc
+
+
 class _EdgeLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, faces):
@@ -546,7 +593,7 @@ class _BNReLUPool(torch.autograd.Function):
         B, C, H, W = x.shape
         lib = _lib.lib()
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)  # (not .contiguous(...): that is a 67 MB layout copy of uninitialised memory per step)
         stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.obman_bnact_ws_floats(B * H * W, C), dtype=torch.float32, device=x.device)
         if x.dtype == torch.bfloat16:  # arg-max taps for the backward: equality routing would hit every tie of the bf16 inputs

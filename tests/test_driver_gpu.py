@@ -125,8 +125,17 @@ def test_graphed_train_step_replays_the_eager_step():
         return out, model
 
     eager, m_e = run(False)
+    again, _ = run(False)
     replay, m_g = run(True)
-    np.testing.assert_allclose(replay, eager, rtol=2e-3)
+    # The yardstick is measured in the same process: two EAGER runs from the same seed.  At this size (4 images of 64 x 64) not even
+    # the first forward is bit-reproducible (tools/r04/step_det.py: loss terms differ by 1e-7 .. 1e-4 between two passes over the
+    # same weights; this package's kernels use no float atomics and the decoder is bit-reproducible - tools/r04/det_check.py - so
+    # the source is a library kernel: MIOpen's find lists split-K "gkgs" solutions with atomic accumulation among its picks), and
+    # Adam's first steps (~lr * sign(gradient)) amplify that: seven steps in, eager runs of different processes scatter by +- 1.4 %
+    # (eight runs, round 4).  Replays have to track the eager step within 4 x the eager-vs-eager difference (floor 2e-3, the
+    # bound of rounds 2 - 3, when find still picked non-atomic kernels on every box).
+    noise = max(abs(a - b) / abs(a) for a, b in zip(eager, again))
+    np.testing.assert_allclose(replay, eager, rtol=max(2e-3, 4.0 * noise))
     assert int(m_g.base_net.bn1.num_batches_tracked) == int(m_e.base_net.bn1.num_batches_tracked) == 7
     for (k, a), (_, b) in zip(m_e.named_parameters(), m_g.named_parameters()):
         assert torch.isfinite(b).all(), k

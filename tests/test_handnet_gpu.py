@@ -177,3 +177,26 @@ def test_configs2_precision_flavours_track_the_fp32_model_at_size():
             assert measured[flavour][key] <= bound, (flavour, key, measured[flavour])
 
 
+
+
+def test_weighted_terms_on_device_matches_the_sequential_composition():
+    """``ops.weighted_terms`` on the GPU (stack, multiply, sum) against the reference's term-by-term composition evaluated on the
+    CPU: value within the summation order of the terms (3e-7 relative), gradients ``lambda_i`` exactly, result usable in place."""
+    from obman_train_amd import ops
+
+    torch.manual_seed(5)
+    lambdas = [0.167, 0.167, 1e-5, 0.5]
+    host = [torch.rand(()) * 5 for _ in lambdas]
+    ref = torch.zeros(1)
+    for lam, t in zip(lambdas, host):
+        ref += lam * t
+    terms = [t.cuda().requires_grad_() for t in host]
+    out = ops.weighted_terms(list(zip(lambdas, terms)) + [(0.167, 0)], (1,))
+    assert out.is_cuda and out.shape == (1,)
+    torch.testing.assert_close(out.detach().cpu(), ref, rtol=3e-7, atol=0)
+    out += 2.0
+    out.backward()
+    for lam, t in zip(lambdas, terms):
+        torch.testing.assert_close(t.grad.cpu(), torch.tensor(lam), rtol=1e-7, atol=0)
+    with pytest.raises(TypeError):
+        ops.weighted_terms([(0.167, terms[0]), (None, 0)], ())
