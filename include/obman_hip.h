@@ -193,6 +193,11 @@ int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const
                     int training, float eps, float momentum, int relu, float* y, float* stats, float* ws, obman_stream_t stream);
 int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats, long R, int C, int training,
                     int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream);
+/* The same with TWO incoming gradients (ABI 5; relu && has_skip only, dy2 may be NULL): a residual block's output feeds the next
+ * block's first convolution and its skip branch (bases/resnet.py:38-54, 76-96), autograd delivers one gradient per consumer, and this entry
+ * point adds them while its statistics pass reads them - the separate add over the activation (8 per ResNet-18 step) disappears. */
+int obman_bnact_bwd2(const float* x, const float* y, const float* dy, const float* dy2, const float* gamma, const float* stats, long R, int C,
+                     int training, int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream);
 
 /* Stem variant: y_pool = MaxPool2d(3, stride 2, pad 1)(relu(bn(x))) (bases/resnet.py:156-163) without materialising the
  * full-resolution activation.  x [B,H,W,C] NHWC, y_pool / d_pool [B,(H-1)/2+1,(W-1)/2+1,C]; stats as above;
@@ -211,6 +216,9 @@ int obman_bnact_fwd_bf16(const uint16_t* x, const uint16_t* skip, const float* g
 int obman_bnact_bwd_bf16(const uint16_t* x, const uint16_t* y, const uint16_t* dy, const float* gamma, const float* stats, long R, int C,
                          int training, int relu, int has_skip, uint16_t* dx, float* dgamma, float* dbeta, uint16_t* dskip, float* ws,
                          obman_stream_t stream);
+int obman_bnact_bwd2_bf16(const uint16_t* x, const uint16_t* y, const uint16_t* dy, const uint16_t* dy2, const float* gamma, const float* stats,
+                          long R, int C, int training, int relu, int has_skip, uint16_t* dx, float* dgamma, float* dbeta, uint16_t* dskip,
+                          float* ws, obman_stream_t stream);
 /* The stem's forward additionally writes amax [B,Ho,Wo,C] bytes: the 3x3 window tap (0..8, row-major; 255 = none, all taps <= 0) of
  * the FIRST maximum - torch's max_pool2d arg-max - and the backward routes d_pool by it.  (The fp32 entry points route to the taps
  * that equal the pooled value; bf16 inputs tie far too often for that.) */

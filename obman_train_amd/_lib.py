@@ -9,7 +9,7 @@ import os
 from .build import LIB
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); 'p' pointer, 'i' int, 'l' long, 'f' float
 _SIGNATURES = {
@@ -34,10 +34,12 @@ _SIGNATURES = {
     "obman_bnact_ws_floats": (_c_long, "li"),
     "obman_bnact_fwd": (_c_int, "pppppp" "li" "iffi" "ppp" "p"),
     "obman_bnact_bwd": (_c_int, "ppppp" "li" "iii" "ppppp" "p"),
+    "obman_bnact_bwd2": (_c_int, "pppppp" "li" "iii" "ppppp" "p"),
     "obman_bnpool_fwd": (_c_int, "ppppp" "iiii" "iff" "ppp" "p"),
     "obman_bnpool_bwd": (_c_int, "ppppp" "iiii" "i" "pppp" "p"),
     "obman_bnact_fwd_bf16": (_c_int, "pppppp" "li" "iffi" "ppp" "p"),
     "obman_bnact_bwd_bf16": (_c_int, "ppppp" "li" "iii" "ppppp" "p"),
+    "obman_bnact_bwd2_bf16": (_c_int, "pppppp" "li" "iii" "ppppp" "p"),
     "obman_bnpool_fwd_bf16": (_c_int, "ppppp" "iiii" "iff" "pppp" "p"),
     "obman_bnpool_bwd_bf16": (_c_int, "ppppp" "iiii" "i" "pppp" "p"),
     "obman_imgstream_ws_bytes": (_c_long, "iii"),

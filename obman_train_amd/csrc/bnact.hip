@@ -58,7 +58,8 @@ __device__ __forceinline__ double wsum64(double v) {
 
 // accumulate two per-channel quantities over a chunk of rows; partial[blk][C][2]
 template <int MODE, class T>  // 0: (x, x^2)   1: (dz, dz*xhat) mask from s*x+t   2: same, mask from y, optional dz store   3: no relu
-__global__ __launch_bounds__(256) void sums_kernel(const T* __restrict__ X, const T* __restrict__ DY, const T* __restrict__ Y,
+                              // DY2 (mode 2 only, may be null): a second incoming gradient, added to DY before the mask
+__global__ __launch_bounds__(256) void sums_kernel(const T* __restrict__ X, const T* __restrict__ DY, const T* __restrict__ DY2, const T* __restrict__ Y,
                                                    const float* __restrict__ sc, const float* __restrict__ sh,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, Geo g,
                                                    T* __restrict__ DZ, double* __restrict__ partial) {
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(256) void sums_kernel(const T* __restrict__ X, cons
     vr = *reinterpret_cast<const float4*>(rstd + c);
     if (MODE == 1) { vs = *reinterpret_cast<const float4*>(sc + c); vt = *reinterpret_cast<const float4*>(sh + c); }
   }
-  // one row of the thread's stripe; `d` = dy (modes 1-3), `y` only in mode 2
-  auto row = [&](size_t o, const float4 x, float4 d, const float4 y) {
+  // one row of the thread's stripe; `d` = dy (modes 1-3), `y` and `d2` only in mode 2
+  auto row = [&](size_t o, const float4 x, float4 d, const float4 d2, const float4 y) {
+    if (MODE == 2) { d.x += d2.x; d.y += d2.y; d.z += d2.z; d.w += d2.w; }  // (+ 0 without a second gradient)
     if (MODE == 0) {
       a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
       b.x = __fmaf_rn(x.x, x.x, b.x); b.y = __fmaf_rn(x.y, x.y, b.y); b.z = __fmaf_rn(x.z, x.z, b.z); b.w = __fmaf_rn(x.w, x.w, b.w);
@@ -96,21 +98,22 @@ __global__ __launch_bounds__(256) void sums_kernel(const T* __restrict__ X, cons
   // statistics pass at 2.8 TB/s (the 268 MB stem activation in 97 us); rows are still accumulated in their original order
   for (; r + 48 < r1; r += 64) {
     size_t o[4];
-    float4 x[4], d[4], y[4];
+    float4 x[4], d[4], d2[4], y[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (size_t)(r + 16 * j) * g.C + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       x[j] = Act<T>::ld(X + o[j]);
       d[j] = MODE != 0 ? Act<T>::ld(DY + o[j]) : z4;
+      d2[j] = (MODE == 2 && DY2) ? Act<T>::ld(DY2 + o[j]) : z4;
       y[j] = MODE == 2 ? Act<T>::ld(Y + o[j]) : z4;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) row(o[j], x[j], d[j], y[j]);
+    for (int j = 0; j < 4; ++j) row(o[j], x[j], d[j], d2[j], y[j]);
   }
   for (; r < r1; r += 16) {
     const size_t o = (size_t)r * g.C + c;
-    row(o, Act<T>::ld(X + o), MODE != 0 ? Act<T>::ld(DY + o) : z4, MODE == 2 ? Act<T>::ld(Y + o) : z4);
+    row(o, Act<T>::ld(X + o), MODE != 0 ? Act<T>::ld(DY + o) : z4, (MODE == 2 && DY2) ? Act<T>::ld(DY2 + o) : z4, MODE == 2 ? Act<T>::ld(Y + o) : z4);
   }
   __shared__ float red[16][CT][2];
   red[rl][cl * 4 + 0][0] = a.x; red[rl][cl * 4 + 1][0] = a.y; red[rl][cl * 4 + 2][0] = a.z; red[rl][cl * 4 + 3][0] = a.w;
@@ -464,7 +467,7 @@ int bnact_fwd(const T* x, const T* skip, const float* gamma, const float* beta, 
   double* partial = reinterpret_cast<double*>(ws);
   float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   if (training) {
-    bnact::sums_kernel<0, T><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
+    bnact::sums_kernel<0, T><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
     OBMAN_LAUNCH_CHECK();
   }
   bnact::fwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, eps, momentum, gamma, beta, rmean, rvar, mean,
@@ -477,12 +480,14 @@ int bnact_fwd(const T* x, const T* skip, const float* gamma, const float* beta, 
 
 /* dy -> dx, dgamma, dbeta [, dskip].  y is needed only with a skip connection (mask of the post-add ReLU).  dskip (the
  * gradient flowing into the skip branch = masked dy) is written when non-NULL; it doubles as the dz scratch, so it is
- * required whenever relu && has_skip. */
+ * required whenever relu && has_skip.  dy2 (relu && has_skip only, may be NULL): the output had two consumers and their gradients
+ * arrive separately; the sums pass adds them while it reads (instead of a separate add kernel over the activation). */
 template <class T>
-int bnact_bwd(const T* x, const T* y, const T* dy, const float* gamma, const float* stats, long R, int C, int training,
+int bnact_bwd(const T* x, const T* y, const T* dy, const T* dy2, const float* gamma, const float* stats, long R, int C, int training,
               int relu, int has_skip, T* dx, float* dgamma, float* dbeta, T* dskip, float* ws, obman_stream_t stream) {
   if (!x || !dy || !stats || !ws || !dx || !dgamma || !dbeta || R <= 0 || C % bnact::CT) return -1;
   if (relu && has_skip && (!y || !dskip)) return -2;
+  if (dy2 && !(relu && has_skip)) return -3;
   hipStream_t st = (hipStream_t)stream;
   const bnact::Geo g = bnact::geo(R, C);
   dim3 grid(g.nblk, C / bnact::CT);
@@ -490,9 +495,9 @@ int bnact_bwd(const T* x, const T* y, const T* dy, const float* gamma, const flo
   float* k = ws + (size_t)g.nblk * C * 2 * 2;  // 3*C coefficients live behind the partials
   const float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   const int mode = !relu ? 3 : (has_skip ? 2 : 1);
-  if (mode == 1) bnact::sums_kernel<1, T><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
-  else if (mode == 2) bnact::sums_kernel<2, T><<<grid, 256, 0, st>>>(x, dy, y, sc, sh, mean, rstd, g, dskip, partial);
-  else bnact::sums_kernel<3, T><<<grid, 256, 0, st>>>(x, dy, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
+  if (mode == 1) bnact::sums_kernel<1, T><<<grid, 256, 0, st>>>(x, dy, nullptr, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
+  else if (mode == 2) bnact::sums_kernel<2, T><<<grid, 256, 0, st>>>(x, dy, dy2, y, sc, sh, mean, rstd, g, dskip, partial);
+  else bnact::sums_kernel<3, T><<<grid, 256, 0, st>>>(x, dy, nullptr, nullptr, sc, sh, mean, rstd, g, nullptr, partial);
   OBMAN_LAUNCH_CHECK();
   bnact::bwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, gamma, rstd, dgamma, dbeta, k);
   OBMAN_LAUNCH_CHECK();
@@ -517,7 +522,7 @@ int bnpool_fwd(const T* x, const float* gamma, const float* beta, float* rmean, 
   double* partial = reinterpret_cast<double*>(ws);
   float *mean = stats, *rstd = stats + C, *sc = stats + 2 * C, *sh = stats + 3 * C;
   if (training) {
-    bnact::sums_kernel<0, T><<<dim3(g.nblk, C / bnact::CT), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
+    bnact::sums_kernel<0, T><<<dim3(g.nblk, C / bnact::CT), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, partial);
     OBMAN_LAUNCH_CHECK();
   }
   bnact::fwd_finalize_kernel<<<obman_cdiv(C, 4), 256, 0, st>>>(partial, g.nblk, R, C, training, eps, momentum, gamma, beta, rmean, rvar, mean,
@@ -562,7 +567,11 @@ int obman_bnact_fwd(const float* x, const float* skip, const float* gamma, const
 }
 int obman_bnact_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats, long R, int C, int training,
                     int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream) {
-  return bnact_bwd<float>(x, y, dy, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
+  return bnact_bwd<float>(x, y, dy, nullptr, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
+}
+int obman_bnact_bwd2(const float* x, const float* y, const float* dy, const float* dy2, const float* gamma, const float* stats, long R, int C,
+                     int training, int relu, int has_skip, float* dx, float* dgamma, float* dbeta, float* dskip, float* ws, obman_stream_t stream) {
+  return bnact_bwd<float>(x, y, dy, dy2, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
 }
 int obman_bnpool_fwd(const float* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
                      int training, float eps, float momentum, float* y_pool, float* stats, float* ws, obman_stream_t stream) {
@@ -581,7 +590,12 @@ int obman_bnact_fwd_bf16(const uint16_t* x, const uint16_t* skip, const float* g
 int obman_bnact_bwd_bf16(const uint16_t* x, const uint16_t* y, const uint16_t* dy, const float* gamma, const float* stats, long R, int C,
                          int training, int relu, int has_skip, uint16_t* dx, float* dgamma, float* dbeta, uint16_t* dskip, float* ws,
                          obman_stream_t stream) {
-  return bnact_bwd<bnact::bfraw>(x, y, dy, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
+  return bnact_bwd<bnact::bfraw>(x, y, dy, nullptr, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
+}
+int obman_bnact_bwd2_bf16(const uint16_t* x, const uint16_t* y, const uint16_t* dy, const uint16_t* dy2, const float* gamma, const float* stats,
+                          long R, int C, int training, int relu, int has_skip, uint16_t* dx, float* dgamma, float* dbeta, uint16_t* dskip,
+                          float* ws, obman_stream_t stream) {
+  return bnact_bwd<bnact::bfraw>(x, y, dy, dy2, gamma, stats, R, C, training, relu, has_skip, dx, dgamma, dbeta, dskip, ws, stream);
 }
 int obman_bnpool_fwd_bf16(const uint16_t* x, const float* gamma, const float* beta, float* rmean, float* rvar, int B, int H, int W, int C,
                           int training, float eps, float momentum, uint16_t* y_pool, uint8_t* amax, float* stats, float* ws,

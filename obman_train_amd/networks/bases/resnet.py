@@ -30,6 +30,7 @@ def _conv(cin, cout, k, stride=1):
 class BasicBlock(nn.Module):
     expansion = 1
     _count = True  # False while ResNet.forward bumps every num_batches_tracked in one foreach launch
+    _dual = False  # True while ResNet.forward runs a block that is followed by another one: output as a pair, see ops.bn_act
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
@@ -41,17 +42,19 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        x, xs = x if isinstance(x, tuple) else (x, x)  # the previous block's output, once per consumer (ops.bn_act, dual)
         if self.downsample is None:
-            skip = x
+            skip = xs
         else:
-            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False, count=self._count)
+            skip = ops.bn_act(self.downsample[1], self.downsample[0](xs), relu=False, count=self._count)
         y = ops.bn_act(self.bn1, self.conv1(x), count=self._count)
-        return ops.bn_act(self.bn2, self.conv2(y), skip=skip, count=self._count)
+        return ops.bn_act(self.bn2, self.conv2(y), skip=skip, count=self._count, dual=self._dual)
 
 
 class Bottleneck(nn.Module):
     expansion = 4
     _count = True
+    _dual = False
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
@@ -65,13 +68,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        x, xs = x if isinstance(x, tuple) else (x, x)
         if self.downsample is None:
-            skip = x
+            skip = xs
         else:
-            skip = ops.bn_act(self.downsample[1], self.downsample[0](x), relu=False, count=self._count)
+            skip = ops.bn_act(self.downsample[1], self.downsample[0](xs), relu=False, count=self._count)
         y = ops.bn_act(self.bn1, self.conv1(x), count=self._count)
         y = ops.bn_act(self.bn2, self.conv2(y), count=self._count)
-        return ops.bn_act(self.bn3, self.conv3(y), skip=skip, count=self._count)
+        return ops.bn_act(self.bn3, self.conv3(y), skip=skip, count=self._count, dual=self._dual)
 
 
 class ResNet(nn.Module):
@@ -122,22 +126,24 @@ class ResNet(nn.Module):
                 feats, extra = self.forward(x)
             return feats.float(), extra
         batched = x.is_cuda and self.training
+        dual = x.is_cuda and torch.is_grad_enabled()  # block outputs as (conv consumer, skip consumer) pairs: ops.bn_act
+        if not hasattr(self, "_blocks"):
+            self._blocks = [m for m in self.modules() if isinstance(m, (BasicBlock, Bottleneck))]
         if batched:  # one multi-tensor add instead of one tiny kernel per BatchNorm layer
             if not hasattr(self, "_nbt") or self._nbt[0] is not self.bn1.num_batches_tracked:  # rebuilt after .to()/.cuda()
                 self._nbt = [m.num_batches_tracked for m in self.modules()
                              if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
-                self._blocks = [m for m in self.modules() if isinstance(m, (BasicBlock, Bottleneck))]
             with torch.no_grad():
                 torch._foreach_add_(self._nbt, 1)
-            for blk in self._blocks:
-                blk._count = False
+        for blk in self._blocks:
+            blk._count = not batched
+            blk._dual = dual and blk is not self._blocks[-1]
         try:
             x = ops.bn_relu_maxpool(self.bn1, self.conv1(x), self.maxpool, count=not batched)
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         finally:
-            if batched:
-                for blk in self._blocks:
-                    blk._count = True
+            for blk in self._blocks:
+                blk._count, blk._dual = True, False
         if x.is_cuda and x.is_contiguous(memory_format=torch.channels_last):
             # global average pool: the NHWC tensor as [B, H W, C], ONE coalesced reduction, and a backward that writes the
             # NHWC gradient directly (the two-step form of resnet.py:179 below costs two strided reductions, two divisions

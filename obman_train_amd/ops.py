@@ -416,7 +416,7 @@ class _BNAct(torch.autograd.Function):
     """BatchNorm2d (+ skip) (+ ReLU) on a channels_last fp32 or bf16 tensor (csrc/bnact.hip; parameters and statistics fp32)."""
 
     @staticmethod
-    def forward(ctx, x, skip, weight, bias, rmean, rvar, training, eps, momentum, relu):
+    def forward(ctx, x, skip, weight, bias, rmean, rvar, training, eps, momentum, relu, dual=False):
         B, C, H, W = x.shape
         R = B * H * W
         lib = _lib.lib()
@@ -428,33 +428,52 @@ class _BNAct(torch.autograd.Function):
                                                          y.data_ptr(), stats.data_ptr(), ws.data_ptr(), _stream()), "obman_bnact_fwd")
         ctx.save_for_backward(x, y if (relu and skip is not None) else None, weight, stats)
         ctx.cfg = (R, C, int(training), int(relu), skip is not None)
+        if dual:
+            # the output twice (one storage): a residual block's output has two consumers - the next block's first convolution
+            # and its skip branch - and with one output object per consumer autograd hands backward() their gradients
+            # separately instead of adding them with a kernel of its own; obman_bnact_bwd2 adds them while it reads
+            ctx.set_materialize_grads(False)
+            return y, y.detach()
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, y, weight, stats = ctx.saved_tensors
         R, C, training, relu, has_skip = ctx.cfg
         lib = _lib.lib()
-        if dy.dtype != x.dtype:
-            dy = dy.to(x.dtype)
-        if not _is_nhwc(dy):
-            dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:  # neither output was used
+            return (None,) * 11
+
+        def _norm(d):
+            if d.dtype != x.dtype:
+                d = d.to(x.dtype)
+            return d if _is_nhwc(d) else d.contiguous(memory_format=torch.channels_last)
+
+        dy = _norm(dy)
+        if dy2 is not None:
+            dy2 = _norm(dy2)
+            if not (has_skip and relu):  # the kernel adds two gradients only in the form the residual blocks use
+                dy, dy2 = dy + dy2, None
         dx = torch.empty_like(x)
         dgamma = torch.empty_like(weight)
         dbeta = torch.empty_like(weight)
         dskip = torch.empty_like(x) if (has_skip and relu) else None
         ws = torch.empty(lib.obman_bnact_ws_floats(R, C), dtype=torch.float32, device=x.device)
-        _lib.check(_bn_entry("obman_bnact_bwd", x.dtype)(x.data_ptr(), _ptr(y), dy.data_ptr(), weight.data_ptr(), stats.data_ptr(), R, C,
-                                                         training, relu, int(has_skip), dx.data_ptr(), dgamma.data_ptr(),
-                                                         dbeta.data_ptr(), _ptr(dskip), ws.data_ptr(), _stream()), "obman_bnact_bwd")
+        _lib.check(_bn_entry("obman_bnact_bwd2", x.dtype)(x.data_ptr(), _ptr(y), dy.data_ptr(), _ptr(dy2), weight.data_ptr(), stats.data_ptr(),
+                                                          R, C, training, relu, int(has_skip), dx.data_ptr(), dgamma.data_ptr(),
+                                                          dbeta.data_ptr(), _ptr(dskip), ws.data_ptr(), _stream()), "obman_bnact_bwd2")
         if has_skip and not relu:
             dskip = dy
-        return dx, dskip, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dskip, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_act(bn, x, skip=None, relu=True, count=True):
+def bn_act(bn, x, skip=None, relu=True, count=True, dual=False):
     """``relu(bn(x) [+ skip])`` for an ``nn.BatchNorm2d`` module ``bn``.  Fused HIP path for channels_last fp32 or bf16 (autocast
-    encoder) ROCm tensors whose channel count is a multiple of 64 (every ResNet-18/50 stage); anything else takes the stock ops."""
+    encoder) ROCm tensors whose channel count is a multiple of 64 (every ResNet-18/50 stage); anything else takes the stock ops.
+    ``dual=True`` (fused path only; the stock path returns one tensor): the result as a pair of tensors on one storage, one per
+    consumer, so that their gradients reach the fused backward un-added (``_BNAct.forward``)."""
     fused = (x.is_cuda and x.dtype in _BN_DTYPES and _is_nhwc(x) and x.shape[1] % 64 == 0 and bn.affine
              and bn.weight.dtype == torch.float32
              and (skip is None or (_is_nhwc(skip) and skip.dtype == x.dtype and skip.shape == x.shape)))
@@ -474,7 +493,8 @@ def bn_act(bn, x, skip=None, relu=True, count=True):
         if skip is not None:
             y = y + skip
         return torch.relu(y) if relu else y
-    return _BNAct.apply(x, skip, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum, relu)
+    return _BNAct.apply(x, skip, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, momentum, relu,
+                        bool(dual and torch.is_grad_enabled()))
 
 
 _TERM_WEIGHTS = {}  # (device, weights) -> fp32 tensor on the device; a handful of entries (the lambdas change once per decay epoch)

@@ -61,6 +61,58 @@ def test_bn_act_matches_torch(shape, relu, has_skip, training):
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (2, 128, 9, 7), (16, 64, 32, 32)])
+@pytest.mark.parametrize("relu,has_skip,use", [(True, True, "both"), (True, True, "first"), (True, True, "second"), (True, False, "both"),
+                                               (False, True, "both")])
+def test_bn_act_dual_output_takes_one_gradient_per_consumer(shape, relu, has_skip, use, dtype):
+    """``ops.bn_act(..., dual=True)``: the output as two tensors on one storage; the gradients of their consumers reach the fused
+    backward separately (obman_bnact_bwd2 adds them in its statistics pass for the residual form, relu + skip; other forms add them
+    with a torch op).  Same bounds as the single-output test against BatchNorm2d + add + relu with the consumers' gradients added by
+    autograd; bf16 activations: bounds of test_bn_act_bf16_activations."""
+    from obman_train_amd import ops
+
+    torch.manual_seed(1)
+    B, C, H, W = shape
+    bn = nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    bn_ref = copy.deepcopy(bn)
+
+    def nhwc(t):
+        return t.contiguous(memory_format=torch.channels_last)
+
+    x = nhwc((torch.randn(shape, device="cuda") * 2 + 0.7).to(dtype))
+    skip = nhwc(torch.randn(shape, device="cuda").to(dtype)) if has_skip else None
+    w1, w2 = nhwc(torch.randn(shape, device="cuda")), nhwc(torch.randn(shape, device="cuda"))
+    xa, xb = x.clone().requires_grad_(), x.float().clone().requires_grad_()
+    sa = skip.clone().requires_grad_() if has_skip else None
+    sb = skip.float().clone().requires_grad_() if has_skip else None
+    y1, y2 = ops.bn_act(bn, xa, skip=sa, relu=relu, dual=True)
+    assert y1.data_ptr() == y2.data_ptr() and y1 is not y2 and y2.is_contiguous(memory_format=torch.channels_last)
+    yb = _ref(bn_ref, xb, sb, relu)
+    tol = dict(rtol=1e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1.6e-2)
+    torch.testing.assert_close(y1.float(), yb, **tol)
+    la = (y1.float() * w1).sum() * (use != "second") + (y2.float() * w2).sum() * (use != "first")
+    lb = (yb * w1).sum() * (use != "second") + (yb * w2).sum() * (use != "first")
+    la.backward()
+    lb.backward()
+    rel = 2e-4 if dtype == torch.float32 else 2e-2
+
+    def check(a, b, name):
+        err = (a.float() - b).abs().max().item()
+        assert err <= rel * b.abs().max().item() + 1e-6, (name, err, b.abs().max().item())
+
+    check(xa.grad, xb.grad, "dx")
+    check(bn.weight.grad, bn_ref.weight.grad, "dgamma")
+    check(bn.bias.grad, bn_ref.bias.grad, "dbeta")
+    if has_skip:
+        check(sa.grad, sb.grad, "dskip")
+    with torch.no_grad():  # no graph: one tensor
+        assert torch.is_tensor(ops.bn_act(bn, x, skip=skip, relu=relu, dual=True))
+
+
 @pytest.mark.parametrize("shape,training", [((2, 64, 16, 16), True), ((3, 64, 13, 9), True), ((2, 128, 8, 8), False), ((8, 64, 64, 64), True)])
 def test_bn_relu_maxpool_matches_torch(shape, training):
     from obman_train_amd import ops
