@@ -62,6 +62,11 @@ def parse():
     ap.add_argument("--secondary-steps", type=int, default=10,
                     help="timed steps of each secondary leg run after the headline (configs[2] and configs[4] in bf16, configs[1] as "
                          "one hipGraph); 0 disables them.  Only with the default --config c2")
+    ap.add_argument("--leg", default=None, metavar="CFG:ENC:DEC:GRAPH",
+                    help="internal: run ONE secondary leg (e.g. c3:bf16:bf16:0) in this process and print its JSON record as the last "
+                         "line.  The headline run starts its secondary legs this way, each in its own process, so that a GPU fault, "
+                         "an out-of-memory condition or an exception in a leg cannot lose the headline line")
+    ap.add_argument("--leg-timeout", type=float, default=420.0, help="wall-clock limit of one secondary-leg process, seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget (all legs together)")
     ap.add_argument("--precondition-max", type=int, default=60,
@@ -500,8 +505,50 @@ def describe_workload(args, cfg, n_pred, n_gt):
                 " + contact/penetration losses" if contact else "", args.batch, args.image_size, args.image_size, prec))
 
 
+def run_leg_process(spec, args):
+    """Secondary leg in a child process (the legs used to run in-process BEFORE the headline line was printed).
+    Returns the leg's record, or {"leg": spec, "error": ...} - never raises."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", spec, "--batch", str(args.batch), "--image-size", str(args.image_size),
+           "--secondary-steps", str(args.secondary_steps)]
+    try:
+        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=args.leg_timeout, cwd=REPO)
+    except subprocess.TimeoutExpired:
+        return {"leg": spec, "error": "timeout after %.0f s" % args.leg_timeout}
+    except Exception as exc:  # noqa: BLE001 - the headline line must survive anything a leg does
+        return {"leg": spec, "error": "%s: %s" % (type(exc).__name__, exc)}
+    lines = [ln for ln in proc.stdout.strip().splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"leg": spec, "error": "exit code %d" % proc.returncode, "stderr_tail": proc.stderr[-600:]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as exc:
+        return {"leg": spec, "error": "unparsable record: %s" % exc}
+
+
+def guarded(name, fn, *a, **kw):
+    """Post-headline probes must not lose the line either: an exception becomes {"error": ...}."""
+    try:
+        return fn(*a, **kw)
+    except Exception as exc:  # noqa: BLE001
+        _say("%s failed: %s" % (name, exc))
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def main():
     args = parse()
+    if args.leg:
+        cfg_name, enc, dec, graph = args.leg.split(":")
+        torch.cuda.set_device(0)
+        rec = secondary_leg(cfg_name, enc, dec, args.batch, args.image_size, max(args.secondary_steps, 1), torch.device("cuda", 0),
+                            graph=graph == "1")
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(rec), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -705,24 +752,27 @@ def main():
                                                     for r in ranks_info})}
         if world == 1:
             _say("chamfer_throughput_probe")
-            roof["throughput_bound_point"] = chamfer_throughput_probe(args.batch)
+            roof["throughput_bound_point"] = guarded("chamfer_throughput_probe", chamfer_throughput_probe, args.batch)
             _say("input_stream_probe")
-            out["input_stream"] = input_stream_probe(args.batch, args.image_size)
+            out["input_stream"] = guarded("input_stream_probe", input_stream_probe, args.batch, args.image_size)
             _say("pcie_inclusive_probe")
-            out["pcie_inclusive"] = pcie_inclusive_probe(model, opt, sample, args.batch, args.image_size, train_step)
+            out["pcie_inclusive"] = guarded("pcie_inclusive_probe", pcie_inclusive_probe, model, opt, sample, args.batch,
+                                            args.image_size, train_step)
             _say("probes done")
-        if world == 1 and args.secondary_steps > 0 and args.config == "c2" and not args.graph:
-            sec = []
-            for cfg_name, bs in (("c3", args.batch), ("c5", args.batch)):
-                _say("secondary leg %s" % cfg_name)
-                sec.append(secondary_leg(cfg_name, "bf16", "bf16", bs, args.image_size, args.secondary_steps, dev))
-            _say("secondary leg c2 as one hipGraph")
-            sec.append(secondary_leg("c2", "f32", "f32", args.batch, args.image_size, args.secondary_steps, dev, graph=True))
-            out["secondary"] = {"note": "other BASELINE.json configurations, timed after the headline's timed region with the same rules "
-                                        "(inputs resident, settle phase, whole train step); never part of `value`", "legs": sec}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, args.image_size, args.config)
-            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline, cfg, args.cpu_seconds, args.image_size, args.config)
+            if "value" in out["cpu_baseline"]:
+                out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and args.secondary_steps > 0 and args.config == "c2" and not args.graph:
+            # Each leg in its own process, AFTER everything the headline needs has been computed: a fault in a leg leaves an
+            # {"error": ...} entry, never a missing line.  This process's model stays resident meanwhile (a few GB of 288).
+            sec = []
+            for spec in ("c3:bf16:bf16:0", "c5:bf16:bf16:0", "c2:f32:f32:1"):
+                _say("secondary leg %s (child process)" % spec)
+                sec.append(run_leg_process(spec, args))
+            out["secondary"] = {"note": "other BASELINE.json configurations, each timed in its own child process after the headline's "
+                                        "timed region with the same rules (inputs resident, settle phase, whole train step); never part "
+                                        "of `value`; a failed leg is recorded as {\"error\": ...}", "legs": sec}
     else:
         out = None
     if use_dist:

@@ -108,6 +108,12 @@ int obman_mesh_contains_fwd(const float* points, const float* verts, const int* 
  * contactutils.py:158; the parity of the TOTAL count would call a point inside two overlapping patches exterior). */
 int obman_mesh_contains_groups_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
                                    int F, int group_faces, int* parity_bits, obman_stream_t stream);
+/* The same outputs from the ALL-PAIRS kernel (every (point, triangle) pair evaluated, the formulation of
+ * contactutils.py:62-159 itself; group_faces = 0: hit counts, > 0: per-patch parity bits).  The two entry points above cull
+ * pairs with a 2-D grid in the plane normal to the fixed ray (contactutils.py:65) and must return bit-identical words; this one
+ * is the checker they are tested against (tests/test_contains_binned_gpu.py), not a fallback - the product never calls it. */
+int obman_mesh_contains_bruteforce_fwd(const float* points, const float* verts, const int* faces, int B, int P, int Nv,
+                                       int F, int group_faces, int* hits, obman_stream_t stream);
 
 /* ---- K5: contact / penetration loss tail ---------------------------------------------------------
  * Replaces contactloss.py:173-308 (after pair-min and inside test).  hand [B,V,3], obj [B,N,3],

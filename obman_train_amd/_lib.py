@@ -9,7 +9,7 @@ import os
 from .build import LIB
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); 'p' pointer, 'i' int, 'l' long, 'f' float
 _SIGNATURES = {
@@ -22,6 +22,7 @@ _SIGNATURES = {
     "obman_chamfer_bwd": (_c_int, "ppiiipppppp" "p"),
     "obman_mesh_contains_fwd": (_c_int, "ppp" "iiii" "pp"),
     "obman_mesh_contains_groups_fwd": (_c_int, "ppp" "iiii" "i" "pp"),
+    "obman_mesh_contains_bruteforce_fwd": (_c_int, "ppp" "iiii" "i" "pp"),
     "obman_contact_fwd": (_c_int, "ppppp" "iii" "pp" "ii" "ifif" "ppppp" "p"),
     "obman_contact_bwd": (_c_int, "pppppppp" "iii" "ifif" "i" "pp" "p"),
     "obman_pointgen_ws_floats": (_c_long, "pi"),

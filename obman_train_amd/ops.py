@@ -222,11 +222,14 @@ def project_rotations(mats):
     return (u * fix.unsqueeze(-2)) @ vh
 
 
-def mesh_contains_hits(points, verts, faces, patches=1):
+def mesh_contains_hits(points, verts, faces, patches=1, all_pairs=False, raw_bits=False):
     """points [B,P,3], verts [B,Nv,3], faces [F,3] int32 (device) -> hits [B,P] int32 whose PARITY is the inside test
     (exterior <=> even).  ``patches == 1`` (the reference's single closed mesh): ray/triangle crossings along the
     reference's fixed direction.  ``patches > 1`` (multi-patch template, faces = ``patches`` equal consecutive groups, each a
-    closed surface): 1 where the point is inside ANY patch (OR of the per-patch parities), else 0.  No gradient."""
+    closed surface): 1 where the point is inside ANY patch (OR of the per-patch parities), else 0 (``raw_bits``: the
+    per-patch parity word itself).  No gradient.  ``all_pairs`` runs the all-pairs checker kernel
+    (``obman_mesh_contains_bruteforce_fwd``) instead of the grid-culled product kernel: same words, ~100x the pair tests -
+    for tests and A/B measurements only."""
     points, verts = _dev(points.detach(), "points"), _dev(verts.detach(), "verts")
     faces = _dev(faces, "faces", torch.int32)
     if points.dim() != 3 or verts.dim() != 3 or faces.dim() != 2 or faces.shape[1] != 3:
@@ -234,15 +237,22 @@ def mesh_contains_hits(points, verts, faces, patches=1):
     B, P, Nv, F = points.shape[0], points.shape[1], verts.shape[1], faces.shape[0]
     hits = torch.empty((B, P), dtype=torch.int32, device=points.device)
     patches = int(patches)
-    if patches <= 1:
+    if patches > 1 and (F % patches != 0 or patches > 32):
+        raise ValueError("multi-patch inside test needs <= 32 equal face groups, got F=%d patches=%d" % (F, patches))
+    group_faces = F // patches if patches > 1 else 0
+    if all_pairs:
+        _lib.check(_lib.lib().obman_mesh_contains_bruteforce_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P,
+                                                                 Nv, F, group_faces, hits.data_ptr(), _stream()),
+                   "obman_mesh_contains_bruteforce_fwd")
+    elif patches <= 1:
         _lib.check(_lib.lib().obman_mesh_contains_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P, Nv, F,
                                                       hits.data_ptr(), _stream()), "obman_mesh_contains_fwd")
+    else:
+        _lib.check(_lib.lib().obman_mesh_contains_groups_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P, Nv,
+                                                             F, group_faces, hits.data_ptr(), _stream()),
+                   "obman_mesh_contains_groups_fwd")
+    if patches <= 1 or raw_bits:
         return hits
-    if F % patches != 0 or patches > 32:
-        raise ValueError("multi-patch inside test needs <= 32 equal face groups, got F=%d patches=%d" % (F, patches))
-    _lib.check(_lib.lib().obman_mesh_contains_groups_fwd(points.data_ptr(), verts.data_ptr(), faces.data_ptr(), B, P, Nv, F,
-                                                         F // patches, hits.data_ptr(), _stream()),
-               "obman_mesh_contains_groups_fwd")
     return (hits != 0).to(torch.int32)
 
 

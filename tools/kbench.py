@@ -106,21 +106,42 @@ def bench_mano():
 
 
 def bench_contains():
+    """Inside test at the configs[2] / configs[4] shapes, grid-culled product kernel vs the all-pairs checker kernel, on three
+    geometries: `blob` = 25 patches of a 40 mm blob around a 35 mm point cloud (rounds 1-4 bench), `hand` = an anisotropic
+    hand-sized cloud next to a 60 mm multi-patch object (what a trained model looks like), `init` = the whole object inside
+    a few mm (what the random-initialised decoder of bench.py produces)."""
     import numpy as np
 
     from obman_train_amd import ops
     from obman_train_amd.icosphere import multi_patch
 
-    for B, patches in ((64, 1), (64, 25)):
-        v, f = multi_patch(3, patches)
-        verts = torch.from_numpy(v.astype(np.float32)).cuda().unsqueeze(0).repeat(B, 1, 1) * 40
-        verts = verts + torch.randn(B, 1, 3, device="cuda") * 5
+    rng = np.random.RandomState(0)
+    for B, subdiv, patches in ((64, 3, 1), (64, 3, 25), (64, 4, 25)):
+        v, f = multi_patch(subdiv, patches)
         faces = torch.from_numpy(f.astype(np.int32)).cuda()
-        pts = torch.randn(B, 778, 3, device="cuda") * 35
-        t = kernel_us(lambda: ops.mesh_contains_hits(pts, verts, faces), 3)
-        pairs = B * 778.0 * f.shape[0]
-        print(json.dumps(dict(kernel="contains", B=B, F=int(f.shape[0]), us=round(t, 2),
-                              Gpairs_per_s=round(pairs / t / 1e3, 1), valu_TFLOPs=round(pairs * 50 / t / 1e6, 1))), flush=True)
+        n = v.shape[0] // patches
+        for geom in ("blob", "hand", "init"):
+            if geom == "blob":
+                verts = torch.from_numpy(v.astype(np.float32)).cuda().unsqueeze(0).repeat(B, 1, 1) * 40
+                verts = verts + torch.randn(B, 1, 3, device="cuda") * 5
+                pts = torch.randn(B, 778, 3, device="cuda") * 35
+            else:
+                scale = 60.0 if geom == "hand" else 0.5
+                vv = (v[None] * scale * rng.uniform(0.7, 1.3, size=(B, 1, 3))).astype(np.float32)
+                for p in range(patches):
+                    vv[:, p * n:(p + 1) * n] += rng.normal(0, scale * 0.4, size=(B, 1, 3)).astype(np.float32)
+                hand = rng.normal(0, 45, size=(B, 778, 3)).astype(np.float32) * np.array([1.0, 0.5, 0.25], np.float32)
+                hand += rng.normal(0, 20, size=(B, 1, 3)).astype(np.float32)
+                verts, pts = torch.from_numpy(vv).cuda(), torch.from_numpy(hand).cuda()
+            for grouped in ((1,) if patches == 1 else (1, patches)):
+                t = kernel_us(lambda: ops.mesh_contains_hits(pts, verts, faces, patches=grouped, raw_bits=True), 3)
+                t_all = kernel_us(lambda: ops.mesh_contains_hits(pts, verts, faces, patches=grouped, raw_bits=True, all_pairs=True), 3)
+                same = torch.equal(ops.mesh_contains_hits(pts, verts, faces, patches=grouped, raw_bits=True),
+                                   ops.mesh_contains_hits(pts, verts, faces, patches=grouped, raw_bits=True, all_pairs=True))
+                pairs = B * 778.0 * f.shape[0]
+                print(json.dumps(dict(kernel="contains", geometry=geom, B=B, F=int(f.shape[0]), patches=grouped, us=round(t, 2),
+                                      all_pairs_us=round(t_all, 2), speedup=round(t_all / t, 1), identical=bool(same),
+                                      all_pairs_Gpairs_per_s=round(pairs / t_all / 1e3, 1))), flush=True)
 
 
 def bench_imgstream():
