@@ -191,6 +191,8 @@ constexpr int MB_PPT = MB_PT / MC_THREADS;
 constexpr int MB_MAXCELL = 1024;  // grid cells per tile (Gx * Gy <= MB_MAXCELL, Gx, Gy <= 64)
 constexpr float MB_EPS = 5.9604645e-8f;  // 2^-24
 constexpr float MB_QMAX = 1.0e4f;
+constexpr int MB_DEFER = 512;       // capacity of the per-block list of wide triangles
+constexpr int MB_DEFER_POINTS = 48; // a lane keeps a triangle whose cells hold at most this many points
 // Orthonormal basis of the plane normal to the ray (fp32 roundings of the exact vectors: |dir . ax|, |dir . ay| < 1e-8).
 constexpr float AX_X = -0.814752659671f, AX_Y = 0.579808678409f, AX_Z = 0.f;
 constexpr float AY_X = -0.378169522731f, AY_Y = -0.531407403727f, AY_Z = 0.758019777672f;
@@ -213,6 +215,9 @@ struct MbShared {
   float red[4][16];          // block reductions (one row per wave)
   int wsum[4];
   float grid[14];            // g0x, g0y, inv_cell_x, inv_cell_y, Gx-1, Gy-1, Gx, centre xyz, radius, Cmax, g1x, g1y
+  int ndefer;                // triangles whose box covers many points: done by the whole block after the lane loop
+  int defer[MB_DEFER];       // (triangle index, packed cell box)
+  int defer_box[MB_DEFER];
 };
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
                                                                      const float* __restrict__ verts,
                                                                      const int* __restrict__ faces, int P, int Nv, int F,
                                                                      int ptiles, int tchunk, int tsplit, int group_faces,
-                                                                     int* __restrict__ hits) {
+                                                                     int dbg_stop, int* __restrict__ hits) {
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int pt = blockIdx.x % ptiles, ts = blockIdx.x / ptiles;
   const float* __restrict__ pb = points + (size_t)b * P * 3;
@@ -273,7 +278,9 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
   }
   for (int c = tid; c < MB_MAXCELL; c += MC_THREADS) sh.fill[c] = 0;
   for (int i = tid; i < MB_PT; i += MC_THREADS) sh.hit[i] = 0;
+  if (tid == 0) sh.ndefer = 0;
   __syncthreads();
+  if (dbg_stop == 1) return;  // measurement only (OBMAN_MC_DBG): wrong results
   if (tid == 0) {
     float lo[5], hi[5];
     bool ok = true;
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
     }
   }
   __syncthreads();
+  if (dbg_stop == 2) return;
 
   // ---- phase C: one triangle per lane against the cells its inflated box touches -----------------------------------------
   const float tcx = sh.grid[7], tcy = sh.grid[8], tcz = sh.grid[9], trad = sh.grid[10], cmax = sh.grid[11];
@@ -402,6 +410,22 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
       cx0 = grid_cell(xlo, g0x, icx, lastx); cx1 = grid_cell(xhi, g0x, icx, lastx);
       cy0 = grid_cell(ylo, g0y, icy, lasty); cy1 = grid_cell(yhi, g0y, icy, lasty);
     }
+    if (dbg_stop == 3) continue;
+    // A triangle whose cells hold many points (a wide box: large triangle, edge-on triangle with a large margin, or no box at
+    // all) would keep its lane - and so its wave - busy for hundreds of tests: the block does those together afterwards.
+    if (cy1 > cy0 || cx1 - cx0 > 3) {
+      int cand = 0;
+      for (int cy = cy0; cy <= cy1; ++cy) cand += sh.start[cy * Gx + cx1 + 1] - sh.start[cy * Gx + cx0];
+      if (cand == 0) continue;
+      if (cand > MB_DEFER_POINTS) {
+        const int slot = atomicAdd(&sh.ndefer, 1);
+        if (slot < MB_DEFER) {
+          sh.defer[slot] = t;
+          sh.defer_box[slot] = cx0 | (cx1 << 8) | (cy0 << 16) | (cy1 << 24);
+          continue;
+        }
+      }
+    }
     for (int cy = cy0; cy <= cy1; ++cy) {
       const int i0 = sh.start[cy * Gx + cx0], i1 = sh.start[cy * Gx + cx1 + 1];
       for (int i = i0; i < i1; ++i) {
@@ -409,6 +433,27 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
         if (ray_hit(q.x, q.y, q.z, s.A, s.PU, s.PW, s.PN)) {
           if (GROUPED) atomicXor(&sh.hit[i], bit);
           else atomicAdd(&sh.hit[i], 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (dbg_stop == 4) return;
+  {  // the wide triangles: one wave per triangle, the lanes stride over the candidate points of each grid row
+    const int nd = min(sh.ndefer, MB_DEFER);
+    for (int k = wid; k < nd; k += MC_THREADS / 64) {
+      const int t = sh.defer[k], box = sh.defer_box[k];
+      const int cx0 = box & 255, cx1 = (box >> 8) & 255, cy0 = (box >> 16) & 255, cy1 = (box >> 24) & 255;
+      const TriSetup s = tri_setup(vb, faces + (size_t)t * 3);
+      const int bit = GROUPED ? 1 << (t / group_faces) : 1;
+      for (int cy = cy0; cy <= cy1; ++cy) {
+        const int i0 = sh.start[cy * Gx + cx0], i1 = sh.start[cy * Gx + cx1 + 1];
+        for (int i = i0 + lane; i < i1; i += 64) {
+          const float4 q = sh.pts[i];
+          if (ray_hit(q.x, q.y, q.z, s.A, s.PU, s.PW, s.PN)) {
+            if (GROUPED) atomicXor(&sh.hit[i], bit);
+            else atomicAdd(&sh.hit[i], 1);
+          }
         }
       }
     }
@@ -498,11 +543,12 @@ int contains_binned_launch(const float* points, const float* verts, const int* f
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid(ptiles * tsplit, B);
+  static const int dbg = [] { const char* e = std::getenv("OBMAN_MC_DBG"); return e ? atoi(e) : 0; }();  // measurement only
   ObmanProfScope prof(OBMAN_K_CONTAINS, st);
   if (group_faces)
-    contains_binned_kernel<true><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, group_faces, hits);
+    contains_binned_kernel<true><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, group_faces, dbg, hits);
   else
-    contains_binned_kernel<false><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, 0, hits);
+    contains_binned_kernel<false><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, 0, dbg, hits);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
