@@ -767,6 +767,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 
 #include "decoder_bf16.h"
 #include "decoder_rows2.h"
+#include "decoder_rows3.h"
 #include "decoder_tn2.h"
 #include "decoder_rows2f.h"
 #include "decoder_tn3.h"
@@ -1254,6 +1255,163 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   k2[c] = (float)(-(double)kk * rs * m3);                      // kb
   k3[c] = (float)((double)kk * ((double)mean[c] * rs * m3 - m2));  // kc
   if (g_bias) g_bias[c] = training ? 0.f : kk * (float)s1;
+}
+
+// ---- layer 4, C3 == 128 (the production width), round 5: SIXTEEN lanes per row, each moving its 8 consecutive channels as one
+// 16-byte (bf16) / two 16-byte (fp32) loads, so a wave-level load carries four whole rows; the cross-lane sums stay inside a
+// 16-lane DPP row (quad_perm / row_half_mirror / row_mirror adds - no ds_bpermute).  The kernels above move 8 / 4 bytes per
+// lane and reduce a row with 15 LDS-crossbar shuffles (l4_fwd: a third of its cycles stalled on LDS issue) or issue one
+// 256-byte load instruction per row (l4_bwd: 3 M load instructions at 16 050 x 64 rows): 110 + 121 us against ~50 + 50 us of
+// HBM time (profiles/r05_kernels.md).  Same arithmetic per element; the backward's per-channel sums are fp32 per lane (at most 64 rows) and fp64 across lanes and blocks instead of fp64 per row.
+__device__ __forceinline__ void ld8act(const float* p, float* o) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void ld8act(const bfraw* p, float* o) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  o[0] = bf_lo(v.x); o[1] = bf_hi(v.x); o[2] = bf_lo(v.y); o[3] = bf_hi(v.y);
+  o[4] = bf_lo(v.z); o[5] = bf_hi(v.z); o[6] = bf_lo(v.w); o[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, every lane gets it
+  v += obman_dpp<0xB1>(v);
+  v += obman_dpp<0x4E>(v);
+  v += obman_dpp<0x141>(v);
+  v += obman_dpp<0x140>(v);
+  return v;
+}
+constexpr int L4W_C = 128;
+template <class HT>
+__global__ __launch_bounds__(256) void l4w_fwd_kernel(const HT* __restrict__ H3, const float* __restrict__ s3, const float* __restrict__ t3,
+                                                      const float* __restrict__ W4, const float* __restrict__ b4, float f, long R,
+                                                      float* __restrict__ out) {
+  const int tid = threadIdx.x, sub = tid & 15, c0 = sub * 8;
+  float cs[8], ct[8], w0[8], w1[8], w2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cs[j] = s3[c0 + j]; ct[j] = t3[c0 + j];
+    w0[j] = W4[c0 + j]; w1[j] = W4[L4W_C + c0 + j]; w2[j] = W4[2 * L4W_C + c0 + j];
+  }
+  const float bb0 = b4[0], bb1 = b4[1], bb2 = b4[2];
+  const long r0 = ((long)blockIdx.x * 256 + tid) >> 4, stride = ((long)gridDim.x * 256) >> 4;
+  for (long rq = r0; rq < R; rq += 4 * stride) {  // four rows per lane and step, every load issued before the first use
+    float hq[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = rq + u * stride;
+      ld8act(H3 + (size_t)(rr < R ? rr : rq) * L4W_C + c0, hq[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long r = rq + u * stride;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = fmaxf(__fmaf_rn(cs[j], hq[u][j], ct[j]), 0.f);
+        a0 = __fmaf_rn(a, w0[j], a0); a1 = __fmaf_rn(a, w1[j], a1); a2 = __fmaf_rn(a, w2[j], a2);
+      }
+      a0 = row16_sum(a0); a1 = row16_sum(a1); a2 = row16_sum(a2);
+      if (sub < 3 && r < R) out[r * 3 + sub] = f * ((sub == 0 ? a0 : (sub == 1 ? a1 : a2)) + (sub == 0 ? bb0 : (sub == 1 ? bb1 : bb2)));
+    }
+  }
+}
+// sums [blocks][128][2] fp64 (S1 = sum gy3, S2 = sum gy3 * xhat3), gw [blocks][3 * 128 + 4] as l4_bwd_kernel.  Block = 256 threads =
+// 16 row lanes x 16 channel octets; rows [blockIdx.x * rows_per_blk, + rows_per_blk), rows_per_blk <= L4W_MAX_ROWS so that a lane adds
+// at most 64 rows in fp32 before the fixed-order fp64 sum over the block's 16 row lanes (and, outside, over the blocks).
+constexpr int L4W_MAX_ROWS = 1024;
+__device__ __forceinline__ void unpack8act(const u32x4& v, float* o) {
+  o[0] = bf_lo(v.x); o[1] = bf_hi(v.x); o[2] = bf_lo(v.y); o[3] = bf_hi(v.y);
+  o[4] = bf_lo(v.z); o[5] = bf_hi(v.z); o[6] = bf_lo(v.w); o[7] = bf_hi(v.w);
+}
+template <class HT> struct L4Raw;
+template <> struct L4Raw<bfraw> {
+  u32x4 v;
+  __device__ __forceinline__ void load(const bfraw* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void get(float* o) const { unpack8act(v, o); }
+};
+template <> struct L4Raw<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void get(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+template <class HT>
+__global__ __launch_bounds__(256, 2) void l4w_bwd_kernel(const float* __restrict__ G, const HT* __restrict__ H3, const float* __restrict__ s3,
+                                                         const float* __restrict__ t3, const float* __restrict__ mean3,
+                                                         const float* __restrict__ rstd3, const float* __restrict__ W4, float f, long R,
+                                                         int rows_per_blk, double* __restrict__ sums, float* __restrict__ gw) {
+  const int tid = threadIdx.x, sub = tid & 15, rl = tid >> 4, c0 = sub * 8;
+  const long rbeg = (long)blockIdx.x * rows_per_blk, rend = min(R, rbeg + rows_per_blk);
+  float cs[8], ct[8], cm[8], cr[8], w0[8], w1[8], w2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cs[j] = s3[c0 + j]; ct[j] = t3[c0 + j]; cm[j] = mean3[c0 + j]; cr[j] = rstd3[c0 + j];
+    w0[j] = W4[c0 + j]; w1[j] = W4[L4W_C + c0 + j]; w2[j] = W4[2 * L4W_C + c0 + j];
+  }
+  float p1[8], p2[8], ga[8][3], gb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { p1[j] = 0.f; p2[j] = 0.f; ga[j][0] = ga[j][1] = ga[j][2] = 0.f; }
+  for (long rq = rbeg + rl; rq < rend; rq += 64) {  // four rows per lane and step (16 apart), loads first
+    float gq[4][3];
+    L4Raw<HT> hq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long r = rq + 16 * u;
+      const bool ok = r < rend;
+      const long rr = ok ? r : rq;
+      gq[u][0] = ok ? G[rr * 3] : 0.f; gq[u][1] = ok ? G[rr * 3 + 1] : 0.f; gq[u][2] = ok ? G[rr * 3 + 2] : 0.f;  // g = 0: the row adds nothing
+      hq[u].load(H3 + (size_t)rr * L4W_C + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float g0 = f * gq[u][0], g1 = f * gq[u][1], g2 = f * gq[u][2];
+      float hv[8];
+      hq[u].get(hv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float y = __fmaf_rn(cs[j], hv[j], ct[j]);
+        const float a = fmaxf(y, 0.f);
+        const float gy = y > 0.f ? (g0 * w0[j] + g1 * w1[j] + g2 * w2[j]) : 0.f;
+        p1[j] += gy;
+        p2[j] = __fmaf_rn(gy, (hv[j] - cm[j]) * cr[j], p2[j]);
+        ga[j][0] = __fmaf_rn(g0, a, ga[j][0]); ga[j][1] = __fmaf_rn(g1, a, ga[j][1]); ga[j][2] = __fmaf_rn(g2, a, ga[j][2]);
+      }
+      gb[0] += g0; gb[1] += g1; gb[2] += g2;
+    }
+  }
+  // 16 row lanes hold partials of the same channels: fixed-order sum through LDS (row lane 0 adds 1 .. 15 in order), fp64 for S1 / S2
+  __shared__ float sp[15][16][16];  // [row lane - 1][octet][p1[8] | p2[8]]
+  __shared__ float sf[15][16][24];
+  __shared__ float sg[16][3];
+  if (rl > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sp[rl - 1][sub][j] = p1[j]; sp[rl - 1][sub][8 + j] = p2[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sf[rl - 1][sub][3 * j] = ga[j][0]; sf[rl - 1][sub][3 * j + 1] = ga[j][1]; sf[rl - 1][sub][3 * j + 2] = ga[j][2]; }
+  }
+  if (sub == 0) { sg[rl][0] = gb[0]; sg[rl][1] = gb[1]; sg[rl][2] = gb[2]; }
+  __syncthreads();
+  if (rl == 0) {
+    double S1[8], S2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { S1[j] = (double)p1[j]; S2[j] = (double)p2[j]; }
+    for (int w = 0; w < 15; ++w) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { S1[j] += (double)sp[w][sub][j]; S2[j] += (double)sp[w][sub][8 + j]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ga[j][0] += sf[w][sub][3 * j]; ga[j][1] += sf[w][sub][3 * j + 1]; ga[j][2] += sf[w][sub][3 * j + 2]; }
+    }
+    float* dst = gw + (size_t)blockIdx.x * (3 * L4W_C + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sums[((size_t)blockIdx.x * L4W_C + c0 + j) * 2] = S1[j];
+      sums[((size_t)blockIdx.x * L4W_C + c0 + j) * 2 + 1] = S2[j];
+      dst[c0 + j] = ga[j][0]; dst[L4W_C + c0 + j] = ga[j][1]; dst[2 * L4W_C + c0 + j] = ga[j][2];
+    }
+    if (sub < 3) {
+      float e = 0.f;
+      for (int w = 0; w < 16; ++w) e += sg[w][sub];
+      dst[3 * L4W_C + sub] = e;
+    }
+  }
 }
 
 // partial layer-4 weight gradients [blocks][3*C3+4] -> gW4 [3][C3], gb4 [3].  One wave per output element.
@@ -1856,6 +2014,19 @@ __global__ __launch_bounds__(256) void prescale_l1_kernel(const float* __restric
   else { const long j = i - (long)(N + 1) * ld; Fy[j] = ok ? __fmaf_rn(gamma[c], Fx[j], beta[c]) : 0.f; }
 }
 
+// layer 4: the 16-lanes-per-row kernels (l4w_*) serve the production width; OBMAN_DEC_L4W=0 = the first-generation kernels (A/B)
+bool l4_wide(const Dims& d) {
+  static const int on = [] { const char* e = getenv("OBMAN_DEC_L4W"); return e ? atoi(e) : 1; }();
+  return on != 0 && d.C3 == L4W_C && d.ld3 == L4W_C;
+}
+// rows per block of the layer-4 backward: L4_ROWS for the first-generation kernel (the workspace is sized for it); the wide kernel
+// takes >= 64 rows (one pass of its 16 row lanes x 4) and ~1024 blocks on large problems - fewer, larger partial rows
+int l4_rows(const Dims& d) {
+  if (!l4_wide(d)) return L4_ROWS;
+  long rows = (d.R + 1023) / 1024;
+  rows = (rows + 63) / 64 * 64;
+  return (int)(rows < 64 ? 64 : (rows > L4W_MAX_ROWS ? L4W_MAX_ROWS : rows));
+}
 // ---- second-generation rows GEMMs (decoder_rows2.h): persistent blocks, weights stationary in LDS
 int device_cus() {
   static std::atomic<int> cus[MAX_DEVICES];
@@ -1908,7 +2079,7 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
     granted[dev].store((int)lds, std::memory_order_relaxed);
   }
 #ifdef OBMAN_ABLATION  // tools/ablate_gemm.sh build: the product library holds no measurement-only kernel
-  if constexpr (std::is_same<AOp, BGridFeatPre>::value) {
+  if constexpr (std::is_same<AOp, BGridFeatPre>::value || std::is_same<AOp, BPlain>::value) {
     // measurement-only ablations of the k loop (wrong results; tools/r03_abl.sh): where does a k-step's time go?
     static const int abl = [] { const char* v = getenv("OBMAN_R2_ABL"); return v ? atoi(v) : 0; }();
     if (abl) {
@@ -1934,8 +2105,8 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
             const int nw = (int)(g < 1024 ? g : 1024) * R2_WAVES;
             for (int i = 0; i < nw; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)host[(size_t)i * 8 + k];
             const double st_ = sum[5] > 0 ? sum[5] : 1, tl = sum[7] > 0 ? sum[7] : 1;
-            fprintf(stderr, "R2DBG waves %d steps/wave %.0f tiles/wave %.1f | per k-step ticks: lds %.1f transform+vmwait %.1f mfma %.1f rest %.1f | per tile: epilogue %.0f | per wave total %.0f\n",
-                    nw, st_ / nw, tl / nw, sum[0] / st_, sum[1] / st_, sum[2] / st_, sum[3] / st_, sum[4] / tl, sum[6] / nw);
+            fprintf(stderr, "R2DBG %s waves %d steps/wave %.0f tiles/wave %.1f | per k-step ticks: lds %.1f transform+vmwait %.1f mfma %.1f rest %.1f | per tile: epilogue %.0f | per wave total %.0f\n",
+                    std::is_same<AOp, BPlain>::value ? "dA" : "h2", nw, st_ / nw, tl / nw, sum[0] / st_, sum[1] / st_, sum[2] / st_, sum[3] / st_, sum[4] / tl, sum[6] / nw);
           }
           break;
         }
@@ -1949,6 +2120,42 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
   rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, aop_floats);
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- third generation of the single-array rows GEMMs: A tile by LDS-DMA into a wave-private ring (decoder_rows3.h)
+bool rows3_enabled() {
+  static const int on = [] { const char* e = getenv("OBMAN_DEC_ROWS3"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = rows2
+  return on != 0;
+}
+template <class AOp, class Epi>
+size_t r3_lds_bytes(int Kp, const R2Geo& geo, int nb) {
+  return r2_lds_bytes<AOp, Epi>(Kp, geo) + (size_t)R2_WAVES * nb * R3_BLOCK_BYTES;
+}
+// ring depth (4 KB blocks per wave) that fits next to the weight slice and the epilogue's scratch: 3, 2, or 0 = take the rows2 kernel
+template <class AOp, class Epi>
+int r3_depth(int Kp, const R2Geo& geo) {
+  if (!rows3_enabled() || (Kp & 15)) return 0;
+  if (r3_lds_bytes<AOp, Epi>(Kp, geo, 3) <= R2_LDS_LIMIT) return 3;
+  if (r3_lds_bytes<AOp, Epi>(Kp, geo, 2) <= R2_LDS_LIMIT) return 2;
+  return 0;
+}
+template <class AOp, class Epi, int NB>
+int launch_rows3_nb(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, hipStream_t st) {
+  const size_t lds = r3_lds_bytes<AOp, Epi>(Kp, geo, NB);
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if ((int)lds > granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)rows3_bf16_kernel<AOp, Epi, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store((int)lds, std::memory_order_relaxed);
+  }
+  rows3_bf16_kernel<AOp, Epi, NB><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, R2Lds<AOp>::floats(Kp));
+  OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+template <class AOp, class Epi>
+int launch_rows3(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, int depth, hipStream_t st) {
+  return depth == 3 ? launch_rows3_nb<AOp, Epi, 3>(a, Wb, Kp, Nc, geo, e, st) : launch_rows3_nb<AOp, Epi, 2>(a, Wb, Kp, Nc, geo, e, st);
 }
 
 // ---- second-generation fp32 rows GEMMs (decoder_rows2f.h)
@@ -2158,7 +2365,10 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
       const R2Geo g2 = r2_geo(d, d.C3);
       EpiStoreB2 e2{H3, p->b3, tr ? moments : nullptr, d.ld3, d.C3};
       if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st, Kp))) return rc;
-      if ((rc = launch_rows2<BBnRelu, EpiStoreB2>(a, wb, Kp, d.C3, g2, e2, st))) return rc;
+      const int depth = r3_depth<BBnRelu, EpiStoreB2>(Kp, g2);
+      if (depth) rc = launch_rows3<BBnRelu, EpiStoreB2>(a, wb, Kp, d.C3, g2, e2, depth, st);
+      else rc = launch_rows2<BBnRelu, EpiStoreB2>(a, wb, Kp, d.C3, g2, e2, st);
+      if (rc) return rc;
       mrows = g2.slots;
     } else {
       if ((rc = launch_wcast(p->w3, d.C2, d.C3, d.C2, 0, wb, st))) return rc;
@@ -2170,7 +2380,8 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
     OBMAN_LAUNCH_CHECK();
   }
-  l4_fwd_kernel<bfraw><<<2048, 256, 0, st>>>(H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
+  if (l4_wide(d)) l4w_fwd_kernel<bfraw><<<2048, 256, 0, st>>>(H3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, out);
+  else l4_fwd_kernel<bfraw><<<2048, 256, 0, st>>>(H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -2188,9 +2399,13 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
   const RowGeo lin{(int)d.R, d.N, d.B, 0, 0};
   int rc;
   // ---- layer 4 + BN-3 statistics
-  const int l4b = obman_cdiv(d.R, L4_ROWS);
-  l4_bwd_kernel<bfraw><<<l4b, 128, 0, st>>>(g_out, H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3, L4_ROWS,
-                                             sums, ws2 + v.l4p);
+  const int l4rows = l4_rows(d);
+  const int l4b = obman_cdiv(d.R, l4rows);
+  if (l4_wide(d))
+    l4w_bwd_kernel<bfraw><<<l4b, 256, 0, st>>>(g_out, H3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, l4rows, sums, ws2 + v.l4p);
+  else
+    l4_bwd_kernel<bfraw><<<l4b, 128, 0, st>>>(g_out, H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3, l4rows,
+                                               sums, ws2 + v.l4p);
   OBMAN_LAUNCH_CHECK();
   {
     const float* lp = ws2 + v.l4p;
@@ -2384,7 +2599,8 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
                                                                p->bn_rm[2], p->bn_rv[2], ws + w.mean3, ws + w.rstd3, ws + w.s3, ws + w.t3);
     OBMAN_LAUNCH_CHECK();
   }
-  l4_fwd_kernel<float><<<2048, 256, 0, st>>>(ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
+  if (l4_wide(d)) l4w_fwd_kernel<float><<<2048, 256, 0, st>>>(ws + w.H3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, out);
+  else l4_fwd_kernel<float><<<2048, 256, 0, st>>>(ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, p->w4, p->b4, p->out_factor, d.R, d.C3, out);
   OBMAN_LAUNCH_CHECK();
   return 0;
 }
@@ -2407,9 +2623,14 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     float *k1 = ws2 + v.k, *k2 = k1 + d.ld1, *k3 = k2 + d.ld1;
     const float f = p->out_factor;
     // ---- layer 4 + BN-3 statistics
-    const int l4b = obman_cdiv(d.R, L4_ROWS);
-    l4_bwd_kernel<float><<<l4b, 128, 0, st>>>(g_out, ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3,
-                                               L4_ROWS, sums, ws2 + v.l4p);
+    const int l4rows = l4_rows(d);
+    const int l4b = obman_cdiv(d.R, l4rows);
+    if (l4_wide(d))
+      l4w_bwd_kernel<float><<<l4b, 256, 0, st>>>(g_out, ws + w.H3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, l4rows, sums,
+                                                  ws2 + v.l4p);
+    else
+      l4_bwd_kernel<float><<<l4b, 128, 0, st>>>(g_out, ws + w.H3, d.ld3, ws + w.s3, ws + w.t3, ws + w.mean3, ws + w.rstd3, p->w4, f, d.R, d.C3,
+                                                 l4rows, sums, ws2 + v.l4p);
     OBMAN_LAUNCH_CHECK();
     {
       const float* lp = ws2 + v.l4p;

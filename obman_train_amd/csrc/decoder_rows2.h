@@ -276,6 +276,9 @@ template <>
 struct R2Fin<BPlain> {
   static constexpr bool PACKED = true;
   static __device__ __forceinline__ u32x4 finp(const BPlain&, const BPlain::Row&, const float*, int, int, const BPlain::Raw& q) { return q.v; }
+  struct Pref {};  // no LDS constants (the timing / pipelined measurement variants of the kernel ask for them)
+  static __device__ __forceinline__ Pref pre(const BPlain&, const BPlain::Row&, const float*, int, int) { return Pref{}; }
+  static __device__ __forceinline__ u32x4 finq(const Pref&, const BPlain::Raw& q) { return q.v; }
 };
 template <>
 struct R2Fin<BBnRelu> {
@@ -791,6 +794,10 @@ struct EpiL1B2 {
 // grid = ngroups * slots blocks (1-D, XCD-aware virtual ids: the column groups of one slot are neighbours on one XCD - they
 // stream the same activation rows).  Dynamic LDS: weight slice [(R2_COLS + geo.wside)][Kp + 8] bf16, then the generator's
 // per-channel constants [AOp::NC][Kp] fp32.
+// (Round 5, measured and dropped: a PING-PONG k loop - waves 0-3 and 4-7 held half a k-step apart by raw s_barriers so that one
+// group's MFMAs run beside the other group's fragment reads / transform / requests - was 30 - 40 % SLOWER on all four kernels
+// (h2 539 -> 726 us, dA 611 -> 872 us): these kernels are bound by VALU ISSUE, not by idle matrix pipes waiting for operands, and
+// a barrier interval costs the slower of the two phases; profiles/r05_kernels.md section 2.)
 // ABL != 0: measurement-only variants, instantiated only with -DOBMAN_ABLATION (tools/ablate_gemm.sh build, then tools/r03_abl.sh /
 // tools/r03_dbg.sh with OBMAN_R2_ABL; wrong results): 1 no operand requests inside the k loop,
 // 2 weight fragments read once, 3 no epilogue, 4 no MFMAs, 5 = 2 + the generator's LDS constants read once
