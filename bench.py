@@ -569,7 +569,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        from obman_train_amd.dp import init_rccl, stage_collectives_through_host_if_needed
+        from obman_train_amd.dp import init_rccl
+        from obman_train_amd.dp_selftest import stage_collectives_through_host_if_needed
 
         if selftest:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -597,8 +598,6 @@ def main():
         model.base_net.autocast_dtype = torch.bfloat16
     model.atlas_branch.decoder.mfma_dtype = args.decoder_dtype
     broadcast_parameters(model)
-    if args.graph and use_dist:
-        raise SystemExit("--graph is a single-process mode (the data-parallel hooks issue collectives from Python)")
     opt = make_optimizer(model, "adam", lr=1e-4, capturable=args.graph)
     buckets = GradientBuckets(model.parameters(), force=args.force_dist, exclude=model.unused_parameters(),
                               accumulate_in_place=args.dp_accumulate_in_place) if use_dist else None
@@ -656,7 +655,9 @@ def main():
         evs = _ = None  # noqa: F841 - nothing of the eager phase (events, the last step's outputs and their autograd nodes) stays referenced
         gc.collect()
         torch.cuda.synchronize()
-        graphed = GraphedTrainStep(model, opt, sample, warmup=2)
+        # data parallel: one graph incl. the RCCL collectives ("fused"), or forward+backward / exchange / optimizer ("split") where
+        # the collectives are host work (gloo self-test)
+        graphed = GraphedTrainStep(model, opt, sample, warmup=2, buckets=buckets if use_dist else None)
         _say("graph captured")
     evs, host, _ = run_phase("warmup", args.warmup)
     torch.cuda.synchronize()

@@ -32,8 +32,20 @@ def _newer(deps, target):
     return (not os.path.exists(target)) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
+STAMP = os.path.join(OBJ, ".flags")  # the flag set the objects / library were built with: a measurement build (extra -D flags) must
+#                                       not survive as "fresh" once the flags are back to the product's (mtimes alone cannot tell)
+
+
+def _flags_changed():
+    try:
+        with open(STAMP) as fh:
+            return fh.read() != " ".join(FLAGS)
+    except OSError:
+        return True
+
+
 def _stale():
-    return _newer(sources() + _headers(), LIB)
+    return _flags_changed() or _newer(sources() + _headers(), LIB)
 
 
 def _run(cmd, verbose):
@@ -67,6 +79,7 @@ def _build_locked(force, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = _headers()
     tag = ".tmp.%d" % os.getpid()
+    force = force or _flags_changed()  # every object was compiled with another flag set
     jobs, objs = [], []
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
@@ -83,6 +96,9 @@ def _build_locked(force, verbose):
         list(pool.map(compile_one, jobs))
     _run([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", LIB + tag] + objs, verbose)
     os.replace(LIB + tag, LIB)
+    with open(STAMP + tag, "w") as fh:
+        fh.write(" ".join(FLAGS))
+    os.replace(STAMP + tag, STAMP)
     return LIB
 
 

@@ -62,6 +62,8 @@ class GradientBuckets:
         self._missing = []     # parameters without a local gradient in this step
         self._lacked = False   # this rank had such parameters: read the flags after the last all-reduce
         self._next = 0         # next bucket to all-reduce (index order)
+        self.paused = False    # hooks only record arrivals (trainer.GraphedTrainStep, split mode: the exchange runs between two graphs)
+        self.capturing = False  # inside a stream capture: nothing that needs the host may run (no gradient-less parameters)
         if not self.enabled:
             return
         self.backend = dist.get_backend(group)
@@ -191,6 +193,11 @@ class GradientBuckets:
                 grads.append(p.grad)
             p.grad = v
         if b == len(self.buckets) - 1:  # the flags ride with the last bucket: every local gradient of the step is known by now
+            if self._missing and self.capturing:
+                raise RuntimeError("GradientBuckets: %d parameter(s) received no gradient while the step was being recorded into a "
+                                   "graph (first: shape %s).  A recorded data-parallel step must have a fixed autograd graph on "
+                                   "every rank: the 'some rank had a gradient' flags need a host round trip.  Pass such parameters "
+                                   "in `exclude` or run the step eagerly." % (len(self._missing), tuple(self._missing[0].shape)))
             if self._missing:
                 have = torch.ones(len(self.params), dtype=flat.dtype)
                 for p in self._missing:
@@ -215,7 +222,23 @@ class GradientBuckets:
             return
         self._seen.add(p)
         self._pending[self._where[p]] -= 1
-        self._drain()
+        if not self.paused:
+            self._drain()
+
+    def exchange(self, grads=None):
+        """The whole exchange of one step OUTSIDE autograd (split-graph mode of ``trainer.GraphedTrainStep``): ``grads`` maps
+        every planned parameter to the tensor its gradient was written to (the static tensors of a replayed backward graph);
+        packs, all-reduces in plan order and waits.  Every parameter is taken to have a gradient (a captured step has a fixed
+        autograd graph)."""
+        if not self.enabled:
+            return
+        if grads is not None:
+            for p in self.params:
+                p.grad = grads[p]
+        self._seen = set(self.params)
+        self._pending = [0] * len(self.buckets)
+        self._next = 0
+        self.finish()
 
     def finish(self):
         """Wait for every bucket (launching, in index order, the ones left open by gradient-less parameters).  Call before
@@ -266,44 +289,3 @@ def broadcast_parameters(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
-
-
-def stage_collectives_through_host_if_needed(device):
-    """SELF-TEST AID for the gloo backend (``bench.py --backend gloo``, the two-process GPU tests): gloo with device tensors
-    works on torch builds whose gloo has the HIP transport; otherwise ``dist.all_reduce`` / ``dist.broadcast`` are wrapped so
-    that they reduce / broadcast a host copy and write it back (synchronous; ``async_op=True`` returns an already-finished
-    handle).  The callers - ``GradientBuckets``, ``broadcast_parameters``, ``bench.py`` - issue exactly the calls they issue on
-    RCCL.  Never used with the ``nccl`` backend.  Returns a description of what is in effect."""
-    if dist.get_backend() != "gloo":
-        raise RuntimeError("host staging is a gloo self-test aid; the product path is RCCL (init_rccl)")
-    try:
-        probe = torch.ones(2, device=device)
-        dist.all_reduce(probe)
-        if float(probe[0]) == float(dist.get_world_size()):
-            return "on device tensors"
-    except Exception:  # noqa: BLE001 - any backend error means "not supported here"
-        pass
-    real_reduce, real_bcast = dist.all_reduce, dist.broadcast
-
-    class _Done:
-        def wait(self):
-            return True
-
-    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-        if not t.is_cuda:
-            return real_reduce(t, op=op, group=group, async_op=async_op)
-        host = t.detach().cpu()
-        real_reduce(host, op=op, group=group)
-        t.copy_(host)
-        return _Done() if async_op else None
-
-    def broadcast(t, src=0, group=None, async_op=False):
-        if not t.is_cuda:
-            return real_bcast(t, src=src, group=group, async_op=async_op)
-        host = t.detach().cpu()
-        real_bcast(host, src=src, group=group)
-        t.copy_(host)
-        return _Done() if async_op else None
-
-    dist.all_reduce, dist.broadcast = all_reduce, broadcast
-    return "staged through host memory (self-test harness)"

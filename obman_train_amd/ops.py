@@ -507,7 +507,9 @@ def bn_act(bn, x, skip=None, relu=True, count=True, dual=False):
                         bool(dual and torch.is_grad_enabled()))
 
 
-_TERM_WEIGHTS = {}  # (device, weights) -> fp32 tensor on the device; a handful of entries (the lambdas change once per decay epoch)
+_TERM_WEIGHTS = {}  # (device, weights) -> fp32 tensor on the device; a handful of 16-byte entries (the lambdas change once per decay
+# epoch).  NEVER evicted: a captured GraphedTrainStep has the address of its weight tensor baked into the graph, and this cache is
+# what keeps that tensor alive
 
 
 class _WeightedTerms(torch.autograd.Function):
@@ -544,8 +546,6 @@ def weighted_terms(pairs, shape=()):
         key = (dev, tuple(float(w) for w, _ in pairs))
         w = _TERM_WEIGHTS.get(key)
         if w is None:
-            if len(_TERM_WEIGHTS) > 256:
-                _TERM_WEIGHTS.clear()
             w = _TERM_WEIGHTS[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
         return _WeightedTerms.apply(w, *tensors).reshape(shape)
     acc = None

@@ -77,7 +77,20 @@ class GraphedTrainStep:
 
     The batch SHAPE (and the non-tensor entries of the sample: sides, root) is fixed at capture; ``__call__`` copies a new
     batch into the static input buffers and replays.  Outputs are static tensors overwritten by every replay (clone what must
-    survive).  Not for the data-parallel path: the bucket hooks issue collectives from Python.
+    survive).
+
+    Data parallel (``buckets`` = an enabled ``dp.GradientBuckets``; round 5).  Two forms:
+    * ``mode="fused"`` (default on RCCL): the WHOLE step is one graph - the post-accumulate hooks run while the backward is
+      being recorded, so the pack copies and the ``all_reduce`` calls (RCCL kernels on RCCL's own high-priority stream, joined
+      by events) become graph nodes in exactly the order and overlap the eager step has; ``finish()``'s waits become the
+      join before the recorded optimizer step.  Needs a fixed autograd graph on every rank: a parameter without a gradient
+      raises during the capture (its "some rank had one" flag would need the host).
+    * ``mode="split"`` (any backend; what the gloo self-tests and ``bench.py --backend gloo --graph`` use): graph A = forward +
+      backward with the hooks only recording, then the exchange is issued from Python on the static gradient tensors
+      (``GradientBuckets.exchange``), then graph B = the optimizer step.  Three launch calls + the collectives per step; no
+      overlap of the exchange with the backward.
+    Lambdas baked into the step (``ops.weighted_terms`` caches the loss weights as device tensors) are those of the capture:
+    a schedule that changes them needs a re-capture.
 
     Side effect of construction: the ``warmup`` eager steps and the capture pass are REAL train steps on the capture batch
     (``warmup`` optimizer updates, BatchNorm running statistics, Adam step counters move; the capture pass itself only
@@ -88,13 +101,28 @@ class GraphedTrainStep:
     OUTPUTS of an earlier eager step (loss tensor, results dict - and through them their autograd nodes) are still referenced.
     Drop them before constructing this object (``bench.py`` does); the constructor collects garbage first."""
 
-    def __init__(self, model, optimizer, sample, warmup=3, restore_state=False):
+    def __init__(self, model, optimizer, sample, warmup=3, restore_state=False, buckets=None, mode=None):
         import copy
         import gc
 
         gc.collect()
         dev = next(model.parameters()).device
         self.model, self.optimizer = model, optimizer
+        self.buckets = buckets if (buckets is not None and buckets.enabled) else None
+        if self.buckets is not None:
+            if mode is None:
+                mode = "fused" if self.buckets.backend == "nccl" else "split"
+            if mode not in ("fused", "split"):
+                raise ValueError("GraphedTrainStep mode %r not in [fused|split]" % (mode,))
+            if mode == "fused" and self.buckets.backend != "nccl":
+                raise ValueError("a fused data-parallel graph needs collectives that are stream work (RCCL); backend %r stages "
+                                 "through the host - use mode='split'" % self.buckets.backend)
+        self.mode = mode if self.buckets is not None else "single"
+        if restore_state and not isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
+            # state the warm-up creates is put back by zeroing it: exact for Adam's moments and step counter, NOT for e.g. SGD's
+            # momentum buffer (first step: buf = grad, not momentum * 0 + grad under dampening / nesterov)
+            raise ValueError("GraphedTrainStep(restore_state=True) supports Adam / AdamW only (lazily created optimizer state is "
+                             "restored by zeroing it)")
         snapshot = None
         if restore_state:
             snapshot = ({k: v.detach().clone() for k, v in model.state_dict().items()}, copy.deepcopy(optimizer.state_dict()))
@@ -105,12 +133,46 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # eager steps on the side stream: lazy initialisation, MIOpen find, allocator growth
             for _ in range(max(int(warmup), 1)):
-                train_step(model, optimizer, self.static)
+                train_step(model, optimizer, self.static, self.buckets)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.total, self.results, self.losses = train_step(model, optimizer, self.static)
+        self.graph_opt = None
+        self._grads = None
+        if self.mode == "single":
+            with torch.cuda.graph(self.graph):
+                self.total, self.results, self.losses = train_step(model, optimizer, self.static)
+        elif self.mode == "fused":
+            # thread_local: the process group's watchdog thread may touch the runtime while this thread records
+            b = self.buckets
+            b.capturing = True
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.total, self.results, self.losses = train_step(model, optimizer, self.static, b)
+            finally:
+                b.capturing = False
+        else:
+            b = self.buckets
+            b.paused = True
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.total, self.results, self.losses = model.forward(self.static)
+                    b.zero_grad()
+                    self.total.backward()
+            finally:
+                b.paused = False
+            missing = [p for p in b.params if p.grad is None]
+            if missing:
+                raise RuntimeError("GraphedTrainStep(split): %d planned parameter(s) received no gradient in the recorded backward; "
+                                   "a recorded data-parallel step needs a fixed autograd graph (pass them in `exclude`)" % len(missing))
+            odd = [p for p in b.params if p.grad.stride() != p.stride() and b.buckets[b._where[p]][0] is None]
+            if odd:  # the exchange would re-lay such a gradient out into a NEW tensor every step: graph B could not follow it
+                raise RuntimeError("GraphedTrainStep(split): %d in-place-reduced gradient(s) are not laid out like their parameter" % len(odd))
+            self._grads = {p: p.grad for p in b.params}  # the static tensors the replayed backward writes
+            b.exchange(self._grads)                       # the capture batch's own exchange (also re-points packed .grad at the bucket views)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt):
+                optimizer.step()
         if snapshot is not None:
             with torch.no_grad():
                 live = model.state_dict()
@@ -140,4 +202,7 @@ class GraphedTrainStep:
                                  "every other host-side entry decide which kernels run and on how many rows - so every batch "
                                  "must carry the captured values; capture one graph per layout" % (k, v, self._fixed.get(k)))
         self.graph.replay()
+        if self.graph_opt is not None:  # split data-parallel mode: exchange between the two graphs
+            self.buckets.exchange(self._grads)
+            self.graph_opt.replay()
         return self.total, self.results, self.losses

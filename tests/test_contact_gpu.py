@@ -27,8 +27,11 @@ def _blob(subdiv, B, seed, radius=40.0, patches=1):
     return T(pts.astype(np.float32)), f.astype(np.int32)
 
 
-def _margin_ok(origins, verts, faces):
-    """fp64 mask of points whose ray does not graze any triangle border (|u|,|v|,|1-u-v|,|t| > 1e-4)."""
+GRAZE = 1e-5  # r05: was 1e-4.  fp32 round-off of u, v, t at these scales is ~1e-6 (three 3-term dot products of O(1) factors)
+
+
+def _margin_ok(origins, verts, faces, margin=GRAZE):
+    """fp64 mask of points whose ray does not graze any triangle border (|u|,|v|,|1-u-v|,|t| > margin)."""
     o = origins.double()
     tri = verts.double()[:, T(faces.astype(np.int64))]
     a, e1, e2 = tri[:, :, 0], tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0]
@@ -42,7 +45,7 @@ def _margin_ok(origins, verts, faces):
     v = (q * d).sum(3) * inv[:, None]
     t = (q * e2[:, None]).sum(3) * inv[:, None]
     near_plane_hit = (u > -1e-3) & (u < 1 + 1e-3) & (v > -1e-3) & (u + v < 1 + 1e-3) & (t > -1e-3)
-    graze = near_plane_hit & ((u.abs() < 1e-4) | (v.abs() < 1e-4) | ((1 - u - v).abs() < 1e-4) | (t.abs() < 1e-4))
+    graze = near_plane_hit & ((u.abs() < margin) | (v.abs() < margin) | ((1 - u - v).abs() < margin) | (t.abs() < margin))
     return ~graze.any(2)
 
 
@@ -69,8 +72,17 @@ def test_contains_matches_oracle(B, P, subdiv, patches):
     want = ocontact.mesh_contains_points(origins, tri)
     ok = _margin_ok(origins, verts, faces)
     got = (hits & 1) == 0
-    assert ok.float().mean() > 0.98
+    assert ok.float().mean() > 0.995
     np.testing.assert_array_equal(got[ok].numpy(), want[ok].numpy())
+    # inside the margin both sides are arbitrary - but COUNT what differs there: the kernel's arithmetic is the reference's up to
+    # the association of the triple products, so even grazing points almost always agree
+    from tests.conftest import record_measurement
+
+    n_in = int((~ok).sum())
+    n_diff = int((got != want)[~ok].sum())
+    record_measurement("contains_graze[%d,%d,%d,%d]" % (B, P, subdiv, patches), {"margin": GRAZE, "points": int(ok.numel()),
+                                                                                "in_margin": n_in, "in_margin_disagree": n_diff})
+    assert n_diff <= max(1, ok.numel() // 1000), (n_diff, n_in)
     assert 0.02 < (~want).float().mean() < 0.98 or P == 1  # both classes present
     if patches > 1:  # grouped mode: interior = inside ANY patch (OR of the per-patch parities)
         inside_any = ops.mesh_contains_hits(origins.cuda(), verts.cuda(), T(faces).cuda(), patches=patches).cpu()

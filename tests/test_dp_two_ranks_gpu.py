@@ -56,7 +56,8 @@ def _worker(rank, world, port, out_dir):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    from obman_train_amd.dp import GradientBuckets, broadcast_parameters, stage_collectives_through_host_if_needed
+    from obman_train_amd.dp import GradientBuckets, broadcast_parameters
+    from obman_train_amd.dp_selftest import stage_collectives_through_host_if_needed
 
     mode = stage_collectives_through_host_if_needed(torch.device("cuda", 0))
     from obman_train_amd.trainer import make_optimizer, train_step

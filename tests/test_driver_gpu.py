@@ -135,7 +135,8 @@ def test_graphed_train_step_replays_the_eager_step():
     # (eight runs, round 4).  Replays have to track the eager step within 4 x the eager-vs-eager difference (floor 2e-3, the
     # bound of rounds 2 - 3, when find still picked non-atomic kernels on every box).
     noise = max(abs(a - b) / abs(a) for a, b in zip(eager, again))
-    np.testing.assert_allclose(replay, eager, rtol=max(2e-3, 4.0 * noise))
+    # ... capped at 1e-2: a capture / replay defect must not hide inside a noisy box's scatter
+    np.testing.assert_allclose(replay, eager, rtol=min(1e-2, max(2e-3, 4.0 * noise)))
     assert int(m_g.base_net.bn1.num_batches_tracked) == int(m_e.base_net.bn1.num_batches_tracked) == 7
     for (k, a), (_, b) in zip(m_e.named_parameters(), m_g.named_parameters()):
         assert torch.isfinite(b).all(), k

@@ -1,0 +1,208 @@
+"""GPU: the parity caveats VERDICT r04 left open, closed with measurements instead of explanations.
+
+(a) configs[2] - the WHOLE model at bs 64 / 256 x 256 in fp32 (25 patches = 16 050 object vertices, 32 000 faces, trans + scale
+    heads, shape, contact + penetration) against one host step of `oracle.handnet_forward` on the same weights and batch.  The
+    oracle's multi-patch inside test already runs patch by patch and its pairwise tensors are a few GB at this size, so the host
+    step needs no chunking by hand (~2 - 4 min on the GPU box's cores); BatchNorm statistics and the batch-global masked means
+    (contactloss.py:50-57) are those of the full batch on both sides.
+(b) which loss term carries the 3e-4 of the B = 2 run (tests/test_fullsize_gpu.py, real encoder): every term's relative error is
+    recorded (profiles/r05_parity_measured.md) by the same helper, at B = 2 / 64 x 64 and at bs 64.
+(d) where the whole-model GRADIENT differences of configs[1] at bs 64 come from (2.4e-2 of the largest entry, 7e-3 in L2: bounds
+    6e-2 / 2e-2 in tests/test_benchsize_gpu.py).  Two runs split the model at the encoder output:
+      downstream - the oracle's features injected on both sides: every gradient below the encoder (decoder, heads, MANO branch,
+                   and d loss / d features itself) must agree to 1e-3 in relative L2 - the kernels, the Chamfer arg-mins and the
+                   ReLU masks are the oracle's when they see the oracle's features;
+      encoder    - the same cotangent d loss / d features pushed through both encoders (MIOpen vs oneDNN convolutions, fused
+                   BatchNorm kernels vs torch): weight gradients to 2e-3 in relative L2.
+    What is left of the whole-model difference is the 1e-5 feature round-off of the real encoder, amplified downstream (a
+    Chamfer arg-min or a ReLU mask flips on it) - not an error of either half.
+"""
+import warnings
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from obman_train_amd.contactzones import load_contacts
+
+pytestmark = pytest.mark.gpu
+
+
+def _keys():
+    from obman_train_amd.queries import BaseQueries, TransQueries
+
+    return SimpleNamespace(images=TransQueries.images, verts3d=TransQueries.verts3d, joints3d=TransQueries.joints3d,
+                           objpoints3d=TransQueries.objpoints3d, sides=BaseQueries.sides)
+
+
+class _FixedFeatures(torch.nn.Module):
+    """Encoder stand-in returning a given feature tensor (a Parameter, so its gradient can be compared)."""
+
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = torch.nn.Parameter(feats.clone())
+        self.fc = torch.nn.Linear(1, 1)  # HandNet.unused_parameters() looks for the classifier head
+
+    def forward(self, image):
+        return self.feats, {}
+
+
+def _l2(g, w):
+    g, w = g.detach().cpu().double(), w.detach().double()
+    return float((g - w).norm() / w.norm().clamp_min(1e-30))
+
+
+def _mx(g, w):
+    g, w = g.detach().cpu(), w.detach()
+    return float((g - w).abs().max() / w.abs().max().clamp_min(1e-30))
+
+
+def _run_both(cfg_name, B, res, inject, grad_names):
+    """One train-mode forward + backward of HandNet(**CONFIGS[cfg_name]) on the GPU and of the oracle on the host, same weights and
+    batch (the batch bench.py times, seed 0).  inject: the encoder is replaced by fixed features on both sides."""
+    from oracle import handnet as ohandnet
+    from oracle import mano as omano
+    from obman_train_amd.mano_params import synthetic_mano
+    from obman_train_amd.networks.bases import resnet
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.queries import BaseQueries
+    from obman_train_amd.synthetic import CONFIGS, make_batch
+
+    warnings.simplefilter("ignore")
+    cfg = dict(CONFIGS[cfg_name])
+    torch.manual_seed(0)
+    model = HandNet(**cfg).train()
+    named = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, v in named.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_()
+    sample = make_batch(B, "cpu", seed=0, image_size=res)
+    sample[BaseQueries.sides] = ["left", "right"] * (B // 2)
+    packs = {s: omano.pack_to_torch(synthetic_mano(s)) for s in ("right", "left")}
+    feats = f_o = None
+    if inject:
+        feats = torch.randn(B, 512, generator=torch.Generator().manual_seed(5)) * 0.5
+        f_o = feats.clone().requires_grad_()
+    o_total, o_res, o_losses = ohandnet.handnet_forward(
+        named, cfg, dict(sample), _keys(), packs, model.atlas_branch.test_verts.clone(), model.atlas_branch.test_faces,
+        zones=load_contacts()[1], resnet_shell=resnet.resnet18(), training=True, features=f_o)
+    o_total.backward()
+    if inject:
+        model.base_net = _FixedFeatures(feats)
+    model.cuda()
+    total, out, losses = model.forward(sample)
+    total.backward()
+    torch.cuda.synchronize()
+
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)  # noqa: E731
+    m = {"total": rel(total, o_total), "terms": {}}
+    for k, v in o_losses.items():
+        if v is None:
+            assert losses[k] is None, k
+        elif abs(float(v)) > 1e-5:
+            m["terms"][k] = rel(losses[k], v)
+    m["worst_term"] = max(m["terms"], key=m["terms"].get)
+    m["worst_loss"] = m["terms"][m["worst_term"]]
+    for k in ("verts", "joints", "objpoints3d"):
+        w = o_res[k].detach()
+        m[k + "_of_scale"] = float((out[k].detach().cpu() - w).abs().max() / w.abs().max())
+    if "contact_info" in o_res:
+        gi, oi = out["contact_info"], o_res["contact_info"]
+        n = oi["repulsion_masks"].numel()
+        m["repulsion_hamming"] = int((gi["repulsion_masks"].cpu() != oi["repulsion_masks"]).sum()) / n
+        m["attraction_hamming"] = int(((gi["attraction_masks"].cpu() != 0) != (oi["attraction_masks"] != 0)).sum()) / n
+        m["min_dists_rel"] = float(((gi["min_dists"].detach().cpu() - oi["min_dists"].detach()).abs()
+                                    / oi["min_dists"].detach().abs().clamp_min(1e-3)).max())
+    got = dict(model.named_parameters())
+    m["grads_l2"], m["grads_max"] = {}, {}
+    for name in grad_names:
+        if name in got and got[name].grad is not None and named[name].grad is not None:
+            m["grads_l2"][name], m["grads_max"][name] = _l2(got[name].grad, named[name].grad), _mx(got[name].grad, named[name].grad)
+    if inject:
+        m["grads_l2"]["features"], m["grads_max"]["features"] = _l2(model.base_net.feats.grad, f_o.grad), _mx(model.base_net.feats.grad, f_o.grad)
+    return m, (total, out, losses), (o_total, o_res, o_losses)
+
+
+_DOWNSTREAM = ("mano_branch.pose_reg.weight", "mano_branch.shape_reg.0.weight", "mano_branch.base_layer.0.weight",
+               "atlas_branch.decoder.conv1.weight", "atlas_branch.decoder.conv2.weight", "atlas_branch.decoder.conv3.weight",
+               "atlas_branch.decoder.conv4.weight", "atlas_branch.decoder.bn2.weight", "atlas_branch.decode_scale.2.weight",
+               "atlas_branch.decode_trans.2.weight")
+_ENCODER = ("base_net.layer4.1.conv2.weight", "base_net.layer2.0.conv1.weight", "base_net.conv1.weight", "base_net.bn1.weight")
+
+
+def test_configs2_model_bs64_256_matches_cpu_oracle():
+    """(a) + (b) at bs 64."""
+    from tests.conftest import record_measurement
+
+    m, _, _ = _run_both("c3", 64, 256, False, _DOWNSTREAM + _ENCODER)
+    record_measurement("configs2_bs64_256_vs_oracle", m)
+    # north_star: loss scalars and outputs within 1e-4 relative.  Frozen at small multiples of the MI355X measurement
+    # (profiles/r05_parity_measured.md); the contact terms sit on hard thresholds (a vertex entering / leaving a mask moves a
+    # batch-global masked mean by 1 / count), so their bound is the mask Hamming distance, asserted separately
+    assert m["total"] <= 2e-5, m
+    assert m["verts_of_scale"] <= 1e-4 and m["joints_of_scale"] <= 1e-4 and m["objpoints3d_of_scale"] <= 1e-4, m
+    assert m["repulsion_hamming"] <= 2e-4 and m["attraction_hamming"] <= 2e-4, m
+    soft = {k: v for k, v in m["terms"].items() if k not in ("penetration_loss", "attraction_loss", "contact_loss", "max_penetr",
+                                                               "mean_penetr", "contact_auc")}
+    assert max(soft.values()) <= 1e-4, m
+    assert m["worst_loss"] <= 1e-3, m
+    assert max(m["grads_l2"].values()) <= 3e-2, m
+
+
+def test_configs2_b2_names_the_loose_term():
+    """(b) the B = 2 / 64 x 64 run of tests/test_fullsize_gpu.py with every term recorded: the 3e-4 belongs to ONE term."""
+    from tests.conftest import record_measurement
+
+    m, _, _ = _run_both("c3", 2, 64, False, _DOWNSTREAM)
+    record_measurement("configs2_b2_64_terms", m)
+    loose = {k: v for k, v in m["terms"].items() if v > 1e-4}
+    # whatever is above north_star's 1e-4 must be a contact-side term (hard thresholds on 2 x 778 vertices), never a smooth one
+    assert set(loose) <= {"penetration_loss", "attraction_loss", "contact_loss", "max_penetr", "mean_penetr", "contact_auc"}, m
+
+
+def test_configs1_gradients_downstream_of_the_encoder_bs64():
+    """(d) downstream half: injected features."""
+    from tests.conftest import record_measurement
+
+    m, _, _ = _run_both("c2", 64, 256, True, _DOWNSTREAM)
+    record_measurement("configs1_bs64_downstream_injected", m)
+    assert m["total"] <= 1e-5 and m["worst_loss"] <= 1e-4, m
+    assert len(m["grads_l2"]) >= 6, m
+    bad = {k: v for k, v in m["grads_l2"].items() if not v <= 1e-3}
+    assert not bad, (bad, m)
+
+
+def test_configs1_gradients_through_the_encoder_bs64():
+    """(d) encoder half: one cotangent through both encoders (train-mode BatchNorm, bs 64, 256 x 256)."""
+    from obman_train_amd.networks.bases import resnet
+    from obman_train_amd.synthetic import make_batch
+    from obman_train_amd.queries import TransQueries
+    from tests.conftest import record_measurement
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    enc = resnet.resnet18().train()
+    ref = resnet.resnet18().train()
+    ref.load_state_dict(enc.state_dict())
+    images = make_batch(64, "cpu", seed=0, image_size=256)[TransQueries.images]
+    cot = torch.randn(64, 512, generator=torch.Generator().manual_seed(9))
+    f_ref, _ = ref(images)
+    (f_ref * cot).sum().backward()
+    enc.cuda()
+    f_gpu, _ = enc(images.cuda())
+    (f_gpu * cot.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    m = {"features_of_scale": float((f_gpu.detach().cpu() - f_ref.detach()).abs().max() / f_ref.detach().abs().max()),
+         "grads_l2": {}, "grads_max": {}}
+    want = dict(ref.named_parameters())
+    for name, p in enc.named_parameters():
+        if p.grad is None or want[name].grad is None or name.startswith("fc."):
+            continue
+        m["grads_l2"][name], m["grads_max"][name] = _l2(p.grad, want[name].grad), _mx(p.grad, want[name].grad)
+    m["worst_l2"] = max(m["grads_l2"].values())
+    m["worst_l2_name"] = max(m["grads_l2"], key=m["grads_l2"].get)
+    record_measurement("configs1_bs64_encoder_cotangent", {k: v for k, v in m.items() if k not in ("grads_max",)})
+    assert len(m["grads_l2"]) >= 60, len(m["grads_l2"])
+    assert m["features_of_scale"] <= 1e-4, m["features_of_scale"]
+    assert m["worst_l2"] <= 2e-3, (m["worst_l2_name"], m["worst_l2"])
