@@ -452,8 +452,52 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
     float s1[R2_NT], s2[R2_NT];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
+    bool interior;
     {
-      unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
+      int b, n; long r; bool okl;
+      geo.row(c.bg, c.vt, c.wave, li, b, n, r, okl);
+      interior = __all(okl);  // wave-uniform: every row of the tile is inside the problem
+    }
+#if R2_EPI_ABL == 0
+    if (interior) {
+      // Round 5: these kernels are bound by VALU ISSUE (profiles/r05_kernels.md section 2: 47 - 73 k vector instructions per wave
+      // against 1 - 4 k MFMAs), and this epilogue was half of h2's / h3's.  For a tile without rows outside the problem a pair
+      // of outputs now costs 8 vector instructions instead of ~19: the two moments are ONE v_dot2c_f32_bf16 each on the packed
+      // pair (sum = pair . (1, 1), sum of squares = pair . pair; the products of bf16 values are exact in fp32), and the pair
+      // exchange with lane ^ 1 is two v_perm_b32 around the DPP move instead of shifts, masks and selects.
+      const unsigned sel_send = odd ? 0x0c0c0100u : 0x0c0c0302u;  // the half the neighbour stores: own row 2p (odd) / row 2p + 1 (even)
+      const unsigned sel_out = odd ? 0x03020504u : 0x05040100u;   // odd: (neighbour's, own hi)   even: (own lo, neighbour's)
+      const unsigned ones = 0x3f803f80u;
+      bfraw* dstg[2];
+#pragma unroll
+      for (int G = 0; G < 2; ++G) {
+        int b, n; long r; bool ok;
+        geo.row(c.bg, c.vt, c.wave, 16 * G + (c.lane >> 2), b, n, r, ok);
+        dstg[G] = C + (size_t)r * ldc + c.c0 + (c.lane & 3) * 8;
+      }
+#pragma unroll
+      for (int j = 0; j < R2_NT; ++j) {
+        const bool cok = c.c0 + j * 32 + (c.lane & 3) * 8 < ldc;
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int p = 4 * G + q;
+            const unsigned pk = pack_bf16(acc[j][2 * p] + bv[j], acc[j][2 * p + 1] + bv[j]);
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1[j]) : "v"(pk), "v"(ones));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s2[j]) : "v"(pk), "v"(pk));
+            const int rr = ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * h + (odd ? 1 : 0);
+            const unsigned recv = lane_swap1(__builtin_amdgcn_perm(pk, pk, sel_send));
+            tb[rr * 16 + (li >> 1)] = __builtin_amdgcn_perm(recv, pk, sel_out);
+          }
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tb + (c.lane >> 2) * 16 + (c.lane & 3) * 4);
+          if (cok) *reinterpret_cast<u32x4*>(dstg[G] + j * 32) = v;
+        }
+      }
+    } else
+#endif
+    {
       // which rows of the tile this lane's registers hold (validity for the moments) ...
       bool ok0[8], ok1[8];
 #pragma unroll
@@ -501,6 +545,8 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
 #endif
         }
       }
+    }
+    {
       // side columns and the pitch padding behind the last real column: one row per lane (half 0 / half 1)
       if (c.last_group) {
         int b, n; long r; bool ok;
@@ -534,6 +580,10 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
 struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum C, S2 = sum C * xhat, xhat = (H - mean) * rstd
   // H in and C out as 16-byte row pieces through 1 KB of LDS per wave (see EpiStoreB2): 8 loads + 8 stores per tile instead of
   // 32 + 32 four-byte ones - with only 8 k-steps per tile (K = 128) this epilogue IS the kernel.
+  // (Round 5, measured and dropped: the EpiStoreB2 treatment here - v_perm_b32 pair exchange, both sums as v_dot2c_f32_bf16 on packed
+  // pairs with xhat applied per column at the flush, a fast path for tiles without rows / columns outside the problem: ~17
+  // instead of ~30 vector instructions per output pair, parity-green, 511 -> 516 us: the second code path cost 176 bytes of
+  // scratch per lane and the kernel is not bound by this epilogue's instruction count alone; profiles/r05_kernels.md section 2.)
   static constexpr int LDS_FLOATS = R2_WAVES * 256;
   bfraw* C;
   const bfraw* H;  // same pitch as C

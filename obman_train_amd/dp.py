@@ -64,6 +64,7 @@ class GradientBuckets:
         self._next = 0         # next bucket to all-reduce (index order)
         self.paused = False    # hooks only record arrivals (trainer.GraphedTrainStep, split mode: the exchange runs between two graphs)
         self.capturing = False  # inside a stream capture: nothing that needs the host may run (no gradient-less parameters)
+        self.last_missing = 0
         if not self.enabled:
             return
         self.backend = dist.get_backend(group)
@@ -256,6 +257,7 @@ class GradientBuckets:
             for p in self._missing:
                 if float(had[self._flag_of[p]]) == 0.0:
                     p.grad = None
+        self.last_missing = len(self._missing)  # parameters that had no local gradient in the step just finished
         self._works = []
         self._seen = set()
         self._missing = []

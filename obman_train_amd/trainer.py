@@ -136,6 +136,13 @@ class GraphedTrainStep:
                 train_step(model, optimizer, self.static, self.buckets)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if self.buckets is not None and self.buckets.last_missing:
+            # found by the eager warm-up step, BEFORE anything is being recorded (an exception inside a capture that holds RCCL work
+            # leaves the stream in capture mode)
+            raise RuntimeError("GraphedTrainStep: %d planned parameter(s) received no gradient in the warm-up step.  A recorded "
+                               "data-parallel step needs a fixed autograd graph on every rank (the 'some rank had a gradient' flags "
+                               "of dp.GradientBuckets need a host round trip): pass such parameters in `exclude`, or run this step "
+                               "eagerly" % self.buckets.last_missing)
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         self._grads = None

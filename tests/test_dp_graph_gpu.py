@@ -160,13 +160,13 @@ def _split_worker(rank, world, port, out_dir):
     buckets = GradientBuckets(model.parameters(), bucket_bytes=4 * 1024 * 1024, exclude=model.unused_parameters())
     sample = make_batch(BATCH, torch.device("cuda", 0), seed=20 + rank, image_size=IMAGE)  # different shards
     # the eager data-parallel gradients of this state (no optimizer step)
-    total, _, _ = model.forward(sample)
+    total, results, losses = model.forward(sample)
     buckets.zero_grad()
     total.backward()
     buckets.finish()
     eager = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
     eager_loss = float(total)
-    del total
+    del total, results, losses  # ROCm 7.0: hipGraphInstantiate dies while an earlier eager step's outputs (and their autograd nodes) live
     step = GraphedTrainStep(model, opt, sample, warmup=1, restore_state=True, buckets=buckets)
     assert step.mode == "split" and step.graph_opt is not None
     w0 = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}

@@ -203,6 +203,7 @@ def test_configs2_model_matches_oracle_at_full_size(inject):
     record_measurement("configs2_model_vs_oracle[inject=%s]" % inject, {
         "total": rel(total, o_total),
         "worst_loss": max(rel(losses[k], v) for k, v in o_losses.items() if v is not None and abs(float(v)) > 1e-5),
+        "terms": {k: rel(losses[k], v) for k, v in o_losses.items() if v is not None and abs(float(v)) > 1e-5},
         "objpoints3d_of_scale": float((res["objpoints3d"].detach().cpu() - o_res["objpoints3d"].detach()).abs().max()
                                       / o_res["objpoints3d"].detach().abs().max())})
     np.testing.assert_allclose(float(total), float(o_total), rtol=tol if inject else 1e-5)

@@ -12,10 +12,10 @@
       downstream - the oracle's features injected on both sides: every gradient below the encoder (decoder, heads, MANO branch,
                    and d loss / d features itself) must agree to 1e-3 in relative L2 - the kernels, the Chamfer arg-mins and the
                    ReLU masks are the oracle's when they see the oracle's features;
-      encoder    - the same cotangent d loss / d features pushed through both encoders (MIOpen vs oneDNN convolutions, fused
-                   BatchNorm kernels vs torch): weight gradients to 2e-3 in relative L2.
-    What is left of the whole-model difference is the 1e-5 feature round-off of the real encoder, amplified downstream (a
-    Chamfer arg-min or a ReLU mask flips on it) - not an error of either half.
+      encoder    - the same cotangent d loss / d features pushed through the encoder on the GPU, on the host in fp32 and on the
+                   host in fp64: GPU and host-fp32 are EQUALLY far (3 - 6e-3 in relative L2, every layer) from fp64 - ReLU
+                   masks that flip on 3e-6 of forward round-off; a fraction f of flipped elements is sqrt(f) in L2.
+    So the whole-model difference is the fp32 floor of a ReLU network's backward at this size, not an error of either half.
 """
 import warnings
 from types import SimpleNamespace
@@ -174,7 +174,15 @@ def test_configs1_gradients_downstream_of_the_encoder_bs64():
 
 
 def test_configs1_gradients_through_the_encoder_bs64():
-    """(d) encoder half: one cotangent through both encoders (train-mode BatchNorm, bs 64, 256 x 256)."""
+    """(d) encoder half: one cotangent through the encoder (train-mode BatchNorm, bs 64, 256 x 256) three times - the GPU path
+    (MIOpen convolutions + the fused BatchNorm kernels, fp32), the same modules on the host in fp32 (oneDNN) and in fp64.
+
+    Measured (profiles/r05_parity_measured.md): the features agree to 3e-6 of scale, yet the weight gradients of GPU and host-fp32
+    differ by 3 - 6e-3 in relative L2 in EVERY layer below layer4 - and so does each of them from the fp64 run.  A ReLU network's
+    backward is discontinuous: an activation within round-off of zero takes the other branch, the whole incoming gradient of that
+    element appears or disappears, and a fraction f of flipped elements shows as sqrt(f) in L2 (1e-5 of the elements -> 3e-3).
+    That is the floor of ANY fp32 evaluation at this size, not an error of these kernels: the assertion is that the GPU is no
+    further from fp64 than the host's own fp32 run is (x 2), plus an absolute cap."""
     from obman_train_amd.networks.bases import resnet
     from obman_train_amd.synthetic import make_batch
     from obman_train_amd.queries import TransQueries
@@ -183,26 +191,37 @@ def test_configs1_gradients_through_the_encoder_bs64():
     warnings.simplefilter("ignore")
     torch.manual_seed(0)
     enc = resnet.resnet18().train()
-    ref = resnet.resnet18().train()
-    ref.load_state_dict(enc.state_dict())
+    ref32 = resnet.resnet18().train()
+    ref32.load_state_dict(enc.state_dict())
+    ref64 = resnet.resnet18().double().train()
+    ref64.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in enc.state_dict().items()})
     images = make_batch(64, "cpu", seed=0, image_size=256)[TransQueries.images]
     cot = torch.randn(64, 512, generator=torch.Generator().manual_seed(9))
-    f_ref, _ = ref(images)
-    (f_ref * cot).sum().backward()
+    f64, _ = ref64(images.double())
+    (f64 * cot.double()).sum().backward()
+    f32, _ = ref32(images)
+    (f32 * cot).sum().backward()
     enc.cuda()
     f_gpu, _ = enc(images.cuda())
     (f_gpu * cot.cuda()).sum().backward()
     torch.cuda.synchronize()
-    m = {"features_of_scale": float((f_gpu.detach().cpu() - f_ref.detach()).abs().max() / f_ref.detach().abs().max()),
-         "grads_l2": {}, "grads_max": {}}
-    want = dict(ref.named_parameters())
+    scale = float(f64.detach().abs().max())
+    m = {"features_gpu_vs_f64_of_scale": float((f_gpu.detach().cpu().double() - f64.detach()).abs().max()) / scale,
+         "features_host32_vs_f64_of_scale": float((f32.detach().double() - f64.detach()).abs().max()) / scale,
+         "gpu_vs_f64_l2": {}, "host32_vs_f64_l2": {}, "gpu_vs_host32_l2": {}}
+    w64, w32 = dict(ref64.named_parameters()), dict(ref32.named_parameters())
     for name, p in enc.named_parameters():
-        if p.grad is None or want[name].grad is None or name.startswith("fc."):
+        if p.grad is None or w64[name].grad is None or name.startswith("fc."):
             continue
-        m["grads_l2"][name], m["grads_max"][name] = _l2(p.grad, want[name].grad), _mx(p.grad, want[name].grad)
-    m["worst_l2"] = max(m["grads_l2"].values())
-    m["worst_l2_name"] = max(m["grads_l2"], key=m["grads_l2"].get)
-    record_measurement("configs1_bs64_encoder_cotangent", {k: v for k, v in m.items() if k not in ("grads_max",)})
-    assert len(m["grads_l2"]) >= 60, len(m["grads_l2"])
-    assert m["features_of_scale"] <= 1e-4, m["features_of_scale"]
-    assert m["worst_l2"] <= 2e-3, (m["worst_l2_name"], m["worst_l2"])
+        m["gpu_vs_f64_l2"][name] = _l2(p.grad, w64[name].grad)
+        m["host32_vs_f64_l2"][name] = _l2(w32[name].grad, w64[name].grad)
+        m["gpu_vs_host32_l2"][name] = _l2(p.grad, w32[name].grad)
+    worst = lambda d: max(d.values())  # noqa: E731
+    m["worst"] = {k: worst(m[k]) for k in ("gpu_vs_f64_l2", "host32_vs_f64_l2", "gpu_vs_host32_l2")}
+    record_measurement("configs1_bs64_encoder_cotangent", m)
+    assert len(m["gpu_vs_f64_l2"]) >= 60, len(m["gpu_vs_f64_l2"])
+    assert m["features_gpu_vs_f64_of_scale"] <= 2e-5, m["features_gpu_vs_f64_of_scale"]
+    assert m["worst"]["gpu_vs_f64_l2"] <= 2.0 * m["worst"]["host32_vs_f64_l2"] + 1e-4, m["worst"]
+    assert m["worst"]["gpu_vs_f64_l2"] <= 1.5e-2, m["worst"]
+    # the last layers, where few ReLU decisions lie upstream, are tight
+    assert m["gpu_vs_f64_l2"]["layer4.1.bn2.weight"] <= 1e-3, m["gpu_vs_f64_l2"]["layer4.1.bn2.weight"]
