@@ -67,6 +67,10 @@ def parse():
                          "line.  The headline run starts its secondary legs this way, each in its own process, so that a GPU fault, "
                          "an out-of-memory condition or an exception in a leg cannot lose the headline line")
     ap.add_argument("--leg-timeout", type=float, default=420.0, help="wall-clock limit of one secondary-leg process, seconds")
+    ap.add_argument("--in-process", action="store_true",
+                    help="internal: run the headline in THIS process.  By default a single-GPU run with secondary legs is orchestrated: "
+                         "this process never touches the GPU, the headline and every leg run one after the other in child processes "
+                         "of their own (a leg timed while the headline's process still held its context ran 10 - 19 % slow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget (all legs together)")
     ap.add_argument("--precondition-max", type=int, default=60,
@@ -533,6 +537,38 @@ def run_leg_process(spec, args):
         return {"leg": spec, "error": "unparsable record: %s" % exc}
 
 
+def wants_legs(args):
+    return args.secondary_steps > 0 and args.config == "c2" and not args.graph
+
+
+def orchestrate(args):
+    """Single-GPU run with secondary legs: the headline (this command line + --in-process --secondary-steps 0) and then every leg,
+    each in a child process of its own; this process only merges their records into the ONE JSON line.  Nothing of one
+    measurement is resident while another runs, and a fault in a leg leaves an {"error": ...} entry, never a missing line."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--in-process", "--secondary-steps", "0"]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, cwd=os.getcwd())
+    lines = proc.stdout.splitlines()
+    recs = [ln for ln in lines if ln.startswith("{")]
+    if proc.returncode != 0 or not recs:
+        sys.stdout.write(proc.stdout)
+        raise SystemExit(proc.returncode or 1)
+    for ln in lines:
+        if ln is not recs[-1]:
+            print(ln)  # library banners of the child, ahead of the record as before
+    out = json.loads(recs[-1])
+    sec = []
+    for spec in ("c3:bf16:bf16:0", "c5:bf16:bf16:0", "c2:f32:f32:1"):
+        _say("secondary leg %s (child process)" % spec)
+        sec.append(run_leg_process(spec, args))
+    out["secondary"] = {"note": "other BASELINE.json configurations, each timed in its own process after the headline's process has "
+                                "exited, with the same rules (inputs resident, settle phase, whole train step); never part of `value`; "
+                                "a failed leg is recorded as {\"error\": ...}", "legs": sec}
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def guarded(name, fn, *a, **kw):
     """Post-headline probes must not lose the line either: an exception becomes {"error": ...}."""
     try:
@@ -558,6 +594,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus == 1 and not args.in_process and not args.force_dist and wants_legs(args):
+        return orchestrate(args)
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
@@ -746,6 +784,7 @@ def main():
             "roofline": roof,
             "decoder_roofline": decoder,
             "host_enqueue_ms": {"median": sorted(host)[len(host) // 2], "max": max(host), "hipgraph": bool(args.graph),
+                                "hipgraph_mode": graphed.mode if graphed is not None else None,
                                 "note": "host time per step inside the timed region (launch enqueue; the GPU runs asynchronously)"},
         }
         if use_dist:
@@ -770,16 +809,6 @@ def main():
             out["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline, cfg, args.cpu_seconds, args.image_size, args.config)
             if "value" in out["cpu_baseline"]:
                 out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        if world == 1 and args.secondary_steps > 0 and args.config == "c2" and not args.graph:
-            # Each leg in its own process, AFTER everything the headline needs has been computed: a fault in a leg leaves an
-            # {"error": ...} entry, never a missing line.  This process's model stays resident meanwhile (a few GB of 288).
-            sec = []
-            for spec in ("c3:bf16:bf16:0", "c5:bf16:bf16:0", "c2:f32:f32:1"):
-                _say("secondary leg %s (child process)" % spec)
-                sec.append(run_leg_process(spec, args))
-            out["secondary"] = {"note": "other BASELINE.json configurations, each timed in its own child process after the headline's "
-                                        "timed region with the same rules (inputs resident, settle phase, whole train step); never part "
-                                        "of `value`; a failed leg is recorded as {\"error\": ...}", "legs": sec}
     else:
         out = None
     if use_dist:

@@ -227,10 +227,10 @@ class GradientBuckets:
             self._drain()
 
     def exchange(self, grads=None):
-        """The whole exchange of one step OUTSIDE autograd (split-graph mode of ``trainer.GraphedTrainStep``): ``grads`` maps
-        every planned parameter to the tensor its gradient was written to (the static tensors of a replayed backward graph);
-        packs, all-reduces in plan order and waits.  Every parameter is taken to have a gradient (a captured step has a fixed
-        autograd graph)."""
+        """The whole exchange of one step OUTSIDE autograd (split-graph mode of ``trainer.GraphedTrainStep``): packs, all-reduces in
+        plan order and waits.  ``grads`` (optional) maps every planned parameter to the tensor its gradient was written to; without
+        it every ``.grad`` is taken as it is (a packed parameter whose ``.grad`` already is its bucket view is not copied).  Every
+        parameter is taken to have a gradient (a captured step has a fixed autograd graph)."""
         if not self.enabled:
             return
         if grads is not None:

@@ -159,24 +159,36 @@ class GraphedTrainStep:
             finally:
                 b.capturing = False
         else:
+            # Gradients of graph A must outlive it as plain addresses: PERSISTENT buffers allocated here, outside any graph pool (the
+            # packed ones are the bucket views, each in-place-reduced one a tensor laid out like its parameter), zeroed inside
+            # the graph and ACCUMULATED into by autograd.  (Leaf gradients that autograd allocates from the graph's private pool
+            # were overwritten by later eager allocations on ROCm 7.0 / torch 2.10 once anything of that pool had been freed -
+            # tools/r05/dp_split_dbg2.py.)
             b = self.buckets
+            static, zero = {}, []
+            for flat, slots in b.buckets:
+                if flat is None:
+                    static[slots] = torch.zeros_like(slots)
+                    zero.append(static[slots])
+                else:
+                    zero.append(flat)
+                    for slot in slots:
+                        static[slot[0]] = b._slot_view(flat, slot)
+            for p in b.params:
+                p.grad = static[p]
             b.paused = True
             try:
                 with torch.cuda.graph(self.graph):
                     self.total, self.results, self.losses = model.forward(self.static)
-                    b.zero_grad()
+                    torch._foreach_zero_(zero)
                     self.total.backward()
             finally:
                 b.paused = False
-            missing = [p for p in b.params if p.grad is None]
-            if missing:
-                raise RuntimeError("GraphedTrainStep(split): %d planned parameter(s) received no gradient in the recorded backward; "
-                                   "a recorded data-parallel step needs a fixed autograd graph (pass them in `exclude`)" % len(missing))
-            odd = [p for p in b.params if p.grad.stride() != p.stride() and b.buckets[b._where[p]][0] is None]
-            if odd:  # the exchange would re-lay such a gradient out into a NEW tensor every step: graph B could not follow it
-                raise RuntimeError("GraphedTrainStep(split): %d in-place-reduced gradient(s) are not laid out like their parameter" % len(odd))
-            self._grads = {p: p.grad for p in b.params}  # the static tensors the replayed backward writes
-            b.exchange(self._grads)                       # the capture batch's own exchange (also re-points packed .grad at the bucket views)
+            moved = [p for p in b.params if p.grad is not static[p]]
+            if moved:
+                raise RuntimeError("GraphedTrainStep(split): autograd replaced %d gradient buffer(s) instead of accumulating into them" % len(moved))
+            self._grads = static
+            b.exchange()  # the capture batch's own exchange (values are whatever the buffers held: the capture pass only records)
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt):
                 optimizer.step()
@@ -210,6 +222,6 @@ class GraphedTrainStep:
                                  "must carry the captured values; capture one graph per layout" % (k, v, self._fixed.get(k)))
         self.graph.replay()
         if self.graph_opt is not None:  # split data-parallel mode: exchange between the two graphs
-            self.buckets.exchange(self._grads)
+            self.buckets.exchange()  # the gradients already sit in the persistent buffers the plan reduces
             self.graph_opt.replay()
         return self.total, self.results, self.losses
