@@ -370,11 +370,11 @@ def chamfer_roofline(batch, n_pred, n_gt, steps, prof):
     (f_ms, f_n), (b_ms, b_n), (y_ms, y_n) = prof[10], prof[11], prof[12]
     flop = 10.0 * n_pred * n_gt * batch
 
-    def entry(kernel, alg_bytes, ms, n, flop_launch):
+    def entry(kernel, alg_bytes, ms, n, flop_launch, direction="both"):
         if not n:
             return None
         t = ms / n * 1e-3
-        return {"kernel": kernel, "avg_launch_us": t * 1e6, "launches": n, "alg_bytes_per_launch": alg_bytes,
+        return {"kernel": kernel, "direction": direction, "avg_launch_us": t * 1e6, "launches": n, "alg_bytes_per_launch": alg_bytes,
                 "achieved": alg_bytes / t / 1e9, "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBPS,
                 "valu_tflops": flop_launch / t / 1e12, "valu_frac": flop_launch / t / 1e12 / VALU_PEAK_TFLOPS}
 
@@ -383,10 +383,10 @@ def chamfer_roofline(batch, n_pred, n_gt, steps, prof):
                           20.0 * (n_pred + n_gt) * batch, f_ms, f_n, flop)]
     elif y_n:
         launches = [entry("pairmin_fwd_kernel, predicted -> ground truth (%d x %d queries against %d references each)" % (batch, n_pred, n_gt),
-                          (20.0 * n_pred + 12.0 * n_gt) * batch, f_ms, f_n, flop / 2),
+                          (20.0 * n_pred + 12.0 * n_gt) * batch, f_ms, f_n, flop / 2, "pred_to_gt"),
                     entry("pairmin_fwd_kernel, ground truth -> predicted (%d x %d queries against %d references each%s)"
                           % (batch, n_gt, n_pred, ", reference set split over blocks + merge" if n_pred >= 8192 else ""),
-                          (20.0 * n_gt + 12.0 * n_pred) * batch, y_ms, y_n, flop / 2)]
+                          (20.0 * n_gt + 12.0 * n_pred) * batch, y_ms, y_n, flop / 2, "gt_to_pred")]
     else:
         launches = [entry("pairmin_fwd_kernel (both directions in one launch, %d samples)" % batch, 20.0 * (n_pred + n_gt) * batch,
                           f_ms, f_n, flop)]
@@ -403,6 +403,33 @@ def chamfer_roofline(batch, n_pred, n_gt, steps, prof):
                      "frac": head["valu_frac"] if head else None,
                      "note": "binding bound (10 flop per pair evaluation, the launch's own pairs): intensity N*M/(2(N+M)) = %.0f flop/B "
                              ">> 20 flop/B ridge" % (n_pred * n_gt / (2.0 * (n_pred + n_gt)))}}
+    return roof
+
+
+def attach_traffic(roof, cfg_name):
+    """PMC cannot run inside this process: `traffic` is the committed per-launch figure of a labelled PMC run (profiles/chamfer_traffic.json),
+    per direction where a configuration runs one launch per direction."""
+    path = os.path.join(REPO, "profiles", "chamfer_traffic.json")
+    if not os.path.exists(path) or roof is None:
+        return roof
+    with open(path) as fh:
+        entry = json.load(fh).get(cfg_name)
+    if not isinstance(entry, dict):
+        roof["traffic"] = entry
+        return roof
+    if "bytes_per_launch" in entry:  # one launch per call
+        roof["traffic"] = entry.get("bytes_per_launch")
+        roof["traffic_source"] = {k: v for k, v in entry.items() if k != "bytes_per_launch"}
+        return roof
+    meta = {k: v for k, v in entry.items() if not isinstance(v, dict)}
+    for e in roof.get("per_launch") or []:
+        d = entry.get(e.get("direction"))
+        if isinstance(d, dict):
+            e["traffic"] = d.get("bytes_per_launch")
+            e["traffic_over_algorithmic"] = d["bytes_per_launch"] / e["alg_bytes_per_launch"] if e.get("alg_bytes_per_launch") else None
+            if roof.get("kernel") == e.get("kernel"):
+                roof["traffic"] = e["traffic"]
+                roof["traffic_source"] = dict(meta, direction=e.get("direction"), **{k: v for k, v in d.items() if k != "bytes_per_launch"})
     return roof
 
 
@@ -478,7 +505,7 @@ def secondary_leg(cfg_name, encoder_dtype, decoder_dtype, batch, image_size, ste
            "precondition_steps": pre, "hipgraph": bool(graph), "final_loss": float(total),
            "dtype": "%s encoder / %s decoder MFMA / f32 heads, losses, optimizer" % (encoder_dtype, decoder_dtype)}
     if not graph:
-        out["roofline"] = chamfer_roofline(batch, n_pred, n_gt, steps, prof)
+        out["roofline"] = attach_traffic(chamfer_roofline(batch, n_pred, n_gt, steps, prof), cfg_name)
         out["decoder_roofline"] = decoder_roofline(model, batch, n_pred, decoder_dtype, prof)
     del model, opt, sample, step, total
     gc.collect()
@@ -583,6 +610,7 @@ def main():
     if args.leg:
         cfg_name, enc, dec, graph = args.leg.split(":")
         torch.cuda.set_device(0)
+        torch.backends.cudnn.benchmark = True  # MIOpen find mode, as for the headline (without it: heuristic picks, c3 11.3 instead of 9.5 ms)
         rec = secondary_leg(cfg_name, enc, dec, args.batch, args.image_size, max(args.secondary_steps, 1), torch.device("cuda", 0),
                             graph=graph == "1")
         import ctypes
@@ -756,16 +784,7 @@ def main():
         n_gt = sample[TransQueries.objpoints3d].shape[1]
         roof = chamfer_roofline(args.batch, n_pred, n_gt, args.steps, prof)
         decoder = decoder_roofline(model, args.batch, n_pred, args.decoder_dtype, prof)
-        traffic_file = os.path.join(REPO, "profiles", "chamfer_traffic.json")
-        if os.path.exists(traffic_file):  # PMC cannot run inside this process: the committed per-launch figure of a labelled PMC run
-            with open(traffic_file) as fh:
-                tr = json.load(fh)
-            entry = tr.get(args.config)
-            if isinstance(entry, dict):
-                roof["traffic"] = entry.get("bytes_per_launch")
-                roof["traffic_source"] = {k: v for k, v in entry.items() if k != "bytes_per_launch"}
-            else:
-                roof["traffic"] = entry
+        roof = attach_traffic(roof, args.config)
         out = {
             "metric": "train images/sec (fwd+bwd+Adam, bs=%d/GPU)" % args.batch,
             "value": args.batch * world * args.steps / dt, "unit": "images/sec", "n_gpus": world,
