@@ -670,6 +670,8 @@ def main():
         model.base_net.autocast_dtype = torch.bfloat16
     model.atlas_branch.decoder.mfma_dtype = args.decoder_dtype
     broadcast_parameters(model)
+    if args.graph and use_dist and selftest:
+        raise SystemExit("--graph with a process group needs RCCL (--backend nccl): gloo's collectives are host work, a hipGraph cannot hold them")
     opt = make_optimizer(model, "adam", lr=1e-4, capturable=args.graph)
     buckets = GradientBuckets(model.parameters(), force=args.force_dist, exclude=model.unused_parameters(),
                               accumulate_in_place=args.dp_accumulate_in_place) if use_dist else None
@@ -727,8 +729,7 @@ def main():
         evs = _ = None  # noqa: F841 - nothing of the eager phase (events, the last step's outputs and their autograd nodes) stays referenced
         gc.collect()
         torch.cuda.synchronize()
-        # data parallel: one graph incl. the RCCL collectives ("fused"), or forward+backward / exchange / optimizer ("split") where
-        # the collectives are host work (gloo self-test)
+        # data parallel: ONE graph incl. the RCCL collectives
         graphed = GraphedTrainStep(model, opt, sample, warmup=2, buckets=buckets if use_dist else None)
         _say("graph captured")
     evs, host, _ = run_phase("warmup", args.warmup)

@@ -62,7 +62,6 @@ class GradientBuckets:
         self._missing = []     # parameters without a local gradient in this step
         self._lacked = False   # this rank had such parameters: read the flags after the last all-reduce
         self._next = 0         # next bucket to all-reduce (index order)
-        self.paused = False    # hooks only record arrivals (trainer.GraphedTrainStep, split mode: the exchange runs between two graphs)
         self.capturing = False  # inside a stream capture: nothing that needs the host may run (no gradient-less parameters)
         self.last_missing = 0
         if not self.enabled:
@@ -223,23 +222,7 @@ class GradientBuckets:
             return
         self._seen.add(p)
         self._pending[self._where[p]] -= 1
-        if not self.paused:
-            self._drain()
-
-    def exchange(self, grads=None):
-        """The whole exchange of one step OUTSIDE autograd (split-graph mode of ``trainer.GraphedTrainStep``): packs, all-reduces in
-        plan order and waits.  ``grads`` (optional) maps every planned parameter to the tensor its gradient was written to; without
-        it every ``.grad`` is taken as it is (a packed parameter whose ``.grad`` already is its bucket view is not copied).  Every
-        parameter is taken to have a gradient (a captured step has a fixed autograd graph)."""
-        if not self.enabled:
-            return
-        if grads is not None:
-            for p in self.params:
-                p.grad = grads[p]
-        self._seen = set(self.params)
-        self._pending = [0] * len(self.buckets)
-        self._next = 0
-        self.finish()
+        self._drain()
 
     def finish(self):
         """Wait for every bucket (launching, in index order, the ones left open by gradient-less parameters).  Call before

@@ -79,16 +79,15 @@ class GraphedTrainStep:
     batch into the static input buffers and replays.  Outputs are static tensors overwritten by every replay (clone what must
     survive).
 
-    Data parallel (``buckets`` = an enabled ``dp.GradientBuckets``; round 5).  Two forms:
-    * ``mode="fused"`` (default on RCCL): the WHOLE step is one graph - the post-accumulate hooks run while the backward is
-      being recorded, so the pack copies and the ``all_reduce`` calls (RCCL kernels on RCCL's own high-priority stream, joined
-      by events) become graph nodes in exactly the order and overlap the eager step has; ``finish()``'s waits become the
-      join before the recorded optimizer step.  Needs a fixed autograd graph on every rank: a parameter without a gradient
-      raises during the capture (its "some rank had one" flag would need the host).
-    * ``mode="split"`` (any backend; what the gloo self-tests and ``bench.py --backend gloo --graph`` use): graph A = forward +
-      backward with the hooks only recording, then the exchange is issued from Python on the static gradient tensors
-      (``GradientBuckets.exchange``), then graph B = the optimizer step.  Three launch calls + the collectives per step; no
-      overlap of the exchange with the backward.
+    Data parallel (``buckets`` = an enabled ``dp.GradientBuckets`` on RCCL; round 5): the WHOLE step is one graph - the
+    post-accumulate hooks run while the backward is being recorded, so the pack copies and the ``all_reduce`` calls (RCCL kernels
+    on RCCL's own high-priority stream, joined by events) become graph nodes in exactly the order and overlap the eager step
+    has; ``finish()``'s waits become the join before the recorded optimizer step.  Needs a fixed autograd graph on every rank: a
+    parameter without a gradient in the eager warm-up step is refused before anything is recorded (its "some rank had one" flag
+    would need the host).  A host-driven backend (gloo) cannot be recorded.  (A split form for such backends - forward +
+    backward graph, exchange from Python, optimizer graph - was built and REMOVED: on ROCm 7.0 / torch 2.10 a recorded backward that
+    ends its graph produced garbage gradients for the encoder's early layers in most two-process runs, with autograd-allocated
+    and with persistent gradient buffers alike; tools/r05/dp_split_dbg*.py are the reproducers.)
     Lambdas baked into the step (``ops.weighted_terms`` caches the loss weights as device tensors) are those of the capture:
     a schedule that changes them needs a re-capture.
 
@@ -101,7 +100,7 @@ class GraphedTrainStep:
     OUTPUTS of an earlier eager step (loss tensor, results dict - and through them their autograd nodes) are still referenced.
     Drop them before constructing this object (``bench.py`` does); the constructor collects garbage first."""
 
-    def __init__(self, model, optimizer, sample, warmup=3, restore_state=False, buckets=None, mode=None):
+    def __init__(self, model, optimizer, sample, warmup=3, restore_state=False, buckets=None):
         import copy
         import gc
 
@@ -109,15 +108,10 @@ class GraphedTrainStep:
         dev = next(model.parameters()).device
         self.model, self.optimizer = model, optimizer
         self.buckets = buckets if (buckets is not None and buckets.enabled) else None
-        if self.buckets is not None:
-            if mode is None:
-                mode = "fused" if self.buckets.backend == "nccl" else "split"
-            if mode not in ("fused", "split"):
-                raise ValueError("GraphedTrainStep mode %r not in [fused|split]" % (mode,))
-            if mode == "fused" and self.buckets.backend != "nccl":
-                raise ValueError("a fused data-parallel graph needs collectives that are stream work (RCCL); backend %r stages "
-                                 "through the host - use mode='split'" % self.buckets.backend)
-        self.mode = mode if self.buckets is not None else "single"
+        if self.buckets is not None and self.buckets.backend != "nccl":
+            raise ValueError("a data-parallel step can only be recorded when its collectives are stream work (RCCL); backend %r drives "
+                             "them from the host - run that step eagerly" % self.buckets.backend)
+        self.mode = "fused" if self.buckets is not None else "single"
         if restore_state and not isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
             # state the warm-up creates is put back by zeroing it: exact for Adam's moments and step counter, NOT for e.g. SGD's
             # momentum buffer (first step: buf = grad, not momentum * 0 + grad under dampening / nesterov)
@@ -144,12 +138,10 @@ class GraphedTrainStep:
                                "of dp.GradientBuckets need a host round trip): pass such parameters in `exclude`, or run this step "
                                "eagerly" % self.buckets.last_missing)
         self.graph = torch.cuda.CUDAGraph()
-        self.graph_opt = None
-        self._grads = None
         if self.mode == "single":
             with torch.cuda.graph(self.graph):
                 self.total, self.results, self.losses = train_step(model, optimizer, self.static)
-        elif self.mode == "fused":
+        else:
             # thread_local: the process group's watchdog thread may touch the runtime while this thread records
             b = self.buckets
             b.capturing = True
@@ -158,40 +150,6 @@ class GraphedTrainStep:
                     self.total, self.results, self.losses = train_step(model, optimizer, self.static, b)
             finally:
                 b.capturing = False
-        else:
-            # Gradients of graph A must outlive it as plain addresses: PERSISTENT buffers allocated here, outside any graph pool (the
-            # packed ones are the bucket views, each in-place-reduced one a tensor laid out like its parameter), zeroed inside
-            # the graph and ACCUMULATED into by autograd.  (Leaf gradients that autograd allocates from the graph's private pool
-            # were overwritten by later eager allocations on ROCm 7.0 / torch 2.10 once anything of that pool had been freed -
-            # tools/r05/dp_split_dbg2.py.)
-            b = self.buckets
-            static, zero = {}, []
-            for flat, slots in b.buckets:
-                if flat is None:
-                    static[slots] = torch.zeros_like(slots)
-                    zero.append(static[slots])
-                else:
-                    zero.append(flat)
-                    for slot in slots:
-                        static[slot[0]] = b._slot_view(flat, slot)
-            for p in b.params:
-                p.grad = static[p]
-            b.paused = True
-            try:
-                with torch.cuda.graph(self.graph):
-                    self.total, self.results, self.losses = model.forward(self.static)
-                    torch._foreach_zero_(zero)
-                    self.total.backward()
-            finally:
-                b.paused = False
-            moved = [p for p in b.params if p.grad is not static[p]]
-            if moved:
-                raise RuntimeError("GraphedTrainStep(split): autograd replaced %d gradient buffer(s) instead of accumulating into them" % len(moved))
-            self._grads = static
-            b.exchange()  # the capture batch's own exchange (values are whatever the buffers held: the capture pass only records)
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt):
-                optimizer.step()
         if snapshot is not None:
             with torch.no_grad():
                 live = model.state_dict()
@@ -221,7 +179,4 @@ class GraphedTrainStep:
                                  "every other host-side entry decide which kernels run and on how many rows - so every batch "
                                  "must carry the captured values; capture one graph per layout" % (k, v, self._fixed.get(k)))
         self.graph.replay()
-        if self.graph_opt is not None:  # split data-parallel mode: exchange between the two graphs
-            self.buckets.exchange()  # the gradients already sit in the persistent buffers the plan reduces
-            self.graph_opt.replay()
         return self.total, self.results, self.losses

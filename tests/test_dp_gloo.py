@@ -225,48 +225,3 @@ def test_direct_gradient_is_normalised_to_the_parameter_layout(tmp_path):
         got = torch.load(os.path.join(str(tmp_path), "layout_%d.pt" % rank))
         torch.testing.assert_close(got["w"], want, rtol=0, atol=0)
         torch.testing.assert_close(got["small"], torch.full((5,), 2.0), rtol=0, atol=0)
-
-
-def _exchange_worker(rank, world, port, out_dir):
-    """The split-graph form of the data-parallel step (trainer.GraphedTrainStep mode="split") without the graphs: the hooks only
-    RECORD (``paused``), the gradients stay where autograd put them, and ``exchange(grads)`` runs the whole plan afterwards."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from obman_train_amd.dp import GradientBuckets, broadcast_parameters
-
-    net = _model()
-    for p in net.dormant.parameters():
-        p.requires_grad_(False)  # a recorded step has a fixed autograd graph: nothing planned may lack a gradient
-    broadcast_parameters(net)
-    buckets = GradientBuckets(net.parameters(), bucket_bytes=256, exclude=net.unused.parameters(), direct_bytes=1024)
-    x, y = _data()
-    shard = slice(rank * 4, rank * 4 + 4)
-    out = {}
-    for step in range(3):
-        buckets.paused = True
-        buckets.zero_grad()
-        ((net(x[shard]) - y[shard]) ** 2).mean().backward()
-        buckets.paused = False
-        assert buckets._works == [] and buckets._next == 0  # nothing was put on the wire by the hooks
-        held = {p: p.grad for p in buckets.params}            # "static" gradient tensors of a replayed backward
-        local = {p: p.grad.clone() for p in buckets.params}
-        buckets.exchange(held)
-        for p in buckets.params:  # a big gradient is reduced where it was; a small one now lives in its bucket
-            flat = buckets.buckets[buckets._where[p]][0]
-            assert (p.grad is held[p]) == (flat is None)
-        out[step] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
-        out["local_%d" % step] = {k: local[p] for k, p in net.named_parameters() if p in local}
-    torch.save(out, os.path.join(out_dir, "exchange_%d.pt" % rank))
-    dist.destroy_process_group()
-
-
-def test_exchange_after_paused_hooks_equals_the_hooked_path(tmp_path):
-    world, port = 2, _free_port()
-    mp.start_processes(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, start_method="spawn")
-    got = [torch.load(os.path.join(str(tmp_path), "exchange_%d.pt" % r)) for r in range(world)]
-    for step in range(3):
-        for k in got[0][step]:
-            want = (got[0]["local_%d" % step][k] + got[1]["local_%d" % step][k]) / 2
-            for r in range(world):
-                torch.testing.assert_close(got[r][step][k], want, rtol=1e-6, atol=1e-7)
-            assert torch.equal(got[0][step][k], got[1][step][k]), k  # the same bits on every rank

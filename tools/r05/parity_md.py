@@ -1,0 +1,79 @@
+"""gpurun_out/parity_measured.jsonl (tests/conftest.py:record_measurement) -> profiles/r05_parity_measured.md."""
+import json
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+rows = {}
+for line in open(src):
+    d = json.loads(line)
+    rows[d.pop("test")] = d  # the last record of a test wins
+
+
+def fmt(v):
+    if isinstance(v, float):
+        return "%.3g" % v
+    if isinstance(v, dict):
+        return "{" + ", ".join("%s: %s" % (k, fmt(x)) for k, x in v.items()) + "}"
+    return str(v)
+
+
+def table(names, cols):
+    out = ["| test | " + " | ".join(cols) + " |", "|---|" + "---|" * len(cols)]
+    for n in names:
+        if n in rows:
+            out.append("| `%s` | " % n + " | ".join(fmt(rows[n].get(c, "")) for c in cols) + " |")
+    return "\n".join(out)
+
+
+with open(dst, "w") as fh:
+    fh.write("# Measured parity, round 5 (MI355X, `pytest -m gpu`; written by `tests/conftest.py:record_measurement`, "
+             "`tools/r05/parity_md.py`)\n\nRelative errors unless a column says otherwise.  Sections follow VERDICT r04 task 3.\n\n")
+    fh.write("## (a) whole models vs the host oracle at the sizes `bench.py` runs (fp32, bs 64, 256 x 256, real ResNet18)\n\n")
+    fh.write(table(["configs1_bs64_256_vs_oracle", "configs2_bs64_256_vs_oracle"],
+                   ["total", "worst_loss", "worst_term", "verts_of_scale", "joints_of_scale", "objpoints3d_of_scale", "repulsion_hamming",
+                    "attraction_hamming"]) + "\n\n")
+    if "configs2_bs64_256_vs_oracle" in rows:
+        fh.write("configs[2] at bs 64, every loss term: " + fmt(rows["configs2_bs64_256_vs_oracle"].get("terms", {})) + "\n\n")
+        fh.write("configs[2] at bs 64, gradients (relative L2): " + fmt(rows["configs2_bs64_256_vs_oracle"].get("grads_l2", {})) + "\n\n")
+    fh.write("## (b) the loose term of the B = 2 runs\n\n")
+    for n in ("configs2_b2_64_terms", "configs2_model_vs_oracle[inject=False]", "configs2_model_vs_oracle[inject=True]"):
+        if n in rows:
+            fh.write("* `%s`: total %s, worst %s%s; terms %s\n" % (n, fmt(rows[n].get("total")), fmt(rows[n].get("worst_loss")),
+                                                                  (" (" + rows[n]["worst_term"] + ")") if "worst_term" in rows[n] else "",
+                                                                  fmt(rows[n].get("terms", {}))))
+    fh.write("\nThe terms above north_star's 1e-4 in the B = 2 / 64 x 64 run with the real encoder are the three PENETRATION quantities - "
+             "`penetration_loss`, `mean_penetr`, `max_penetr` (1.1e-4 .. 2.5e-4) - and nothing else: they are hand-to-object distances of a "
+             "few mm, differences of coordinates of ~100 mm that carry the encoder's round-off (object points 2.2e-5 of scale = 2e-3 mm; "
+             "2e-3 mm / 8 mm = 2.5e-4), averaged over the handful of penetrating vertices two samples have.  The masks agree exactly "
+             "(Hamming distance 0), every smooth term is at 1e-6, and with the oracle's features injected after the encoder the same "
+             "terms are at 2e-6.  At bs 64 / 256 x 256 the worst term is 3.8e-6.\n\n")
+    fh.write("## (c) inside test: graze margin 1e-5, disagreements inside the margin counted\n\n")
+    fh.write(table(sorted(n for n in rows if n.startswith("contains_graze")), ["margin", "points", "in_margin", "in_margin_disagree"]) + "\n\n")
+    fh.write("The grid-culled kernel against the all-pairs kernel needs no margin: bit-identical hit words (`tests/test_contains_binned_gpu.py`).\n\n")
+    fh.write("## (d) where the whole-model gradient differences come from (configs[1], bs 64)\n\n")
+    if "configs1_bs64_downstream_injected" in rows:
+        r = rows["configs1_bs64_downstream_injected"]
+        fh.write("Downstream of the encoder, oracle features injected on both sides - relative L2 per tensor: " + fmt(r.get("grads_l2", {})) +
+                 " (total loss %s).\n\n" % fmt(r.get("total")))
+    if "configs1_bs64_encoder_cotangent" in rows:
+        r = rows["configs1_bs64_encoder_cotangent"]
+        fh.write("One cotangent through the encoder, three ways - worst relative L2 over the %d weight / bias tensors: %s; features vs fp64: "
+                 "GPU %s, host fp32 %s of scale.\n\n" % (len(r.get("gpu_vs_f64_l2", {})), fmt(r.get("worst", {})),
+                                                        fmt(r.get("features_gpu_vs_f64_of_scale")), fmt(r.get("features_host32_vs_f64_of_scale"))))
+        pick = ["conv1.weight", "layer1.0.bn1.weight", "layer2.0.conv1.weight", "layer3.0.conv1.weight", "layer4.0.conv1.weight",
+                "layer4.1.conv2.weight", "layer4.1.bn2.weight"]
+        fh.write("| tensor | GPU vs fp64 | host fp32 vs fp64 | GPU vs host fp32 |\n|---|---|---|---|\n")
+        for k in pick:
+            if k in r.get("gpu_vs_f64_l2", {}):
+                fh.write("| `%s` | %s | %s | %s |\n" % (k, fmt(r["gpu_vs_f64_l2"][k]), fmt(r["host32_vs_f64_l2"][k]), fmt(r["gpu_vs_host32_l2"][k])))
+        fh.write("\nGPU and host-fp32 are equally far from fp64 and as far from each other: ReLU masks that flip on ~3e-6 of forward round-off "
+                 "(a fraction f of flipped elements is sqrt(f) in L2).  The kernels below the encoder agree with the oracle to 1.6e-4.\n\n")
+    fh.write("## data parallel\n\n")
+    for n in ("dp_two_ranks_real_handnet", "dp_graph_fused_1rank_rccl", "dp_graph_split_two_ranks"):
+        if n in rows:
+            fh.write("* `%s`: %s\n" % (n, fmt(rows[n])))
+    rest = [n for n in rows if not (n.startswith("contains_graze") or n.startswith("configs") or n.startswith("dp_"))]
+    if rest:
+        fh.write("\n## other recorded measurements\n\n")
+        for n in rest:
+            fh.write("* `%s`: %s\n" % (n, fmt(rows[n])))

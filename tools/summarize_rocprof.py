@@ -6,7 +6,7 @@
 import csv
 import sys
 
-OURS = ("pairmin", "rowmean2", "mano_", "contains_kernel", "contact_", "dec::", "edge_", "laplacian", "bnact::", "imgstream", "blur_kernel",
+OURS = ("pairmin", "rowmean2", "mano_", "contains_", "contact_", "dec::", "edge_", "laplacian", "bnact::", "imgstream", "blur_kernel",
         "warp_kernel", "mean_kernel")
 
 
