@@ -832,6 +832,12 @@ def main():
     else:
         out = None
     if use_dist:
+        if graphed is not None:  # the graph holds RCCL work: it goes before the communicator does
+            import gc
+
+            graphed = None
+            gc.collect()
+            torch.cuda.synchronize()
         dist.destroy_process_group()
     if out is not None:
         # the JSON line must be the LAST line on stdout: RCCL writes its version banner through C stdio, whose buffer would
