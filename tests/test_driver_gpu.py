@@ -143,3 +143,43 @@ def test_graphed_train_step_replays_the_eager_step():
     w_e = dict(m_e.named_parameters())["mano_branch.pose_reg.weight"]
     w_g = dict(m_g.named_parameters())["mano_branch.pose_reg.weight"]
     assert float((w_e - w_g).abs().max()) <= 2e-2 * float(w_e.abs().max())  # seven Adam steps from the same start
+
+
+def test_graphed_train_step_restore_state_puts_everything_back():
+    """`GraphedTrainStep(..., restore_state=True)` runs real train steps while it warms up and records; afterwards
+    parameters, BatchNorm buffers and the optimizer state must be what they were - bit for bit - and a non-Adam optimizer
+    (whose lazily created state is not zero-initialised) is refused."""
+    import warnings
+
+    from obman_train_amd.networks.handnet import HandNet
+    from obman_train_amd.synthetic import CONFIGS, make_batch
+    from obman_train_amd.trainer import GraphedTrainStep, make_optimizer, train_step
+
+    warnings.simplefilter("ignore")
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = HandNet(**CONFIGS["c3p1"]).to(dev).train()
+    opt = make_optimizer(model, "adam", lr=1e-3, capturable=True)
+    sample = make_batch(4, dev, seed=41, image_size=64)
+    train_step(model, opt, sample)  # a used optimizer: its moments and step counters hold values that must survive
+    total = None
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    order = [p for g in opt.param_groups for p in g["params"]]
+    opt_before = {i: {n: t.detach().clone() for n, t in opt.state[p].items() if torch.is_tensor(t)} for i, p in enumerate(order) if p in opt.state}
+    assert len(opt_before) > 50
+    step = GraphedTrainStep(model, opt, sample, warmup=2, restore_state=True)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k  # weights, running_mean / running_var, num_batches_tracked
+    for i, p in enumerate(order):
+        for n, t in opt.state.get(p, {}).items():
+            if torch.is_tensor(t):
+                if i in opt_before:
+                    assert torch.equal(t, opt_before[i][n]), (i, n)
+                else:  # state the warm-up created for a parameter that had none: back to Adam's initial zeros
+                    assert float(t.abs().sum()) == 0.0, (i, n)
+    first = float(step(sample)[0])
+    assert first == first  # finite; the replay starts from the restored state
+    sgd = make_optimizer(model, "sgd", lr=1e-3)
+    with pytest.raises(ValueError, match="Adam"):
+        GraphedTrainStep(model, sgd, sample, warmup=1, restore_state=True)
+    del step, total
