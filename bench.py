@@ -169,13 +169,18 @@ def cpu_baseline(cfg, seconds, image_size, cfg_name):
         # at least three timed steps behind one DISCARDED step (the first bs-64 step pays oneDNN primitive
         # creation and the allocator's growth: the 2-step samples of rounds 2 - 4 scattered 6.0 .. 8.6 img/s between boxes).  The
         # discarded step also tells what fits: the leg takes at most ~1.5 x --cpu-seconds (about 10 - 30 s of CPU work in all).
+        # Warm steps run ~20 % faster than the discarded one, so three timed steps are taken whenever three COLD ones would fit
+        # 2.5 x --cpu-seconds (EPYC 9575F box: 15 s discarded + 3 x 12 s); more than three only inside 1.5 x.
         probe = leg(64, 0.0, 0, 1)
-        fit = int((1.5 * seconds) // max(probe["s_per_step"], 1e-3))
+        cold = max(probe["s_per_step"], 1e-3)
+        fit = int((1.5 * seconds) // cold)
+        if fit < 3 and 3 * cold <= 2.5 * seconds:
+            fit = 3
         if fit >= 1:
-            big = leg(64, 1e9, 0, max(1, min(8, max(3, fit)) if fit >= 3 else fit))
+            big = leg(64, 1e9, 0, min(8, fit))
             big["discarded_first_step_s"] = probe["s_per_step"]
             if big["steps"] < 3:
-                big["note"] = "%d timed step(s) only: three would not fit 1.5 x --cpu-seconds" % big["steps"]
+                big["note"] = "%d timed step(s) only: three would not fit 2.5 x --cpu-seconds" % big["steps"]
         else:
             big = probe
             big["note"] = "single cold step (a second one would not fit 1.5 x --cpu-seconds)"
