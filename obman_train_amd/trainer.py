@@ -60,6 +60,19 @@ def _same_entry(a, b):
         return False
 
 
+def _let_the_watchdog_reap(dev, seconds=0.5):
+    """Before a capture that will hold RCCL work.  ProcessGroupNCCL's watchdog thread polls the end events of the outstanding
+    EAGER collectives (``hipEventQuery``, every 100 ms) until it has seen them complete.  Once the recorded step pulls RCCL's stream
+    into the capture, HIP answers such a query - on an event last recorded on that stream, eagerly, by the warm-up steps - with
+    ``hipErrorCapturedEvent``; the watchdog rethrows and the process aborts (measured: 1 of 8 runs of the 1-rank bench command, always
+    inside the capture window, ``tools/r05/fused_flake.sh``).  After the synchronize every eager collective has finished, so ONE
+    poll empties the watchdog's list; there is no call that waits for that poll, hence a few poll periods of sleep."""
+    import time
+
+    torch.cuda.synchronize(dev)
+    time.sleep(seconds)
+
+
 class GraphedTrainStep:
     """One training step (forward -> zero_grad -> backward -> optimizer.step) recorded ONCE into a hipGraph and replayed.
 
@@ -137,6 +150,8 @@ class GraphedTrainStep:
                                "data-parallel step needs a fixed autograd graph on every rank (the 'some rank had a gradient' flags "
                                "of dp.GradientBuckets need a host round trip): pass such parameters in `exclude`, or run this step "
                                "eagerly" % self.buckets.last_missing)
+        if self.mode == "fused":
+            _let_the_watchdog_reap(dev)
         self.graph = torch.cuda.CUDAGraph()
         if self.mode == "single":
             with torch.cuda.graph(self.graph):

@@ -205,3 +205,41 @@ def test_contact_empty_masks_give_zero_loss_and_zero_grad():
         compute_contact_loss(hand, tf, obj, f, contact_mode="nope")
     with pytest.raises(ValueError):
         compute_contact_loss(hand, tf, obj, f, contact_zones="palm")
+
+
+@pytest.mark.parametrize("subdiv,patches", [(1, 1), (3, 1), (3, 25)])
+def test_contact_backward_object_side_is_the_ordered_scatter_of_the_hand_side(subdiv, patches):
+    """d/d(obj) of the contact tail = for every object point the sum, in ASCENDING hand-vertex order, of the g_delta of the vertices
+    whose closest point it is (``contactloss.py:173-180``: ``batch_index_select`` backward), and d/d(hand) = -g_delta.  The kernel's
+    owner walk must reproduce a sequential fp32 scatter of the hand-side gradient bit for bit - 42 points (every point shared by
+    ~19 vertices), 642, and 16 050 (eight 2 048-point slices per sample)."""
+    from obman_train_amd import ops
+    from obman_train_amd.networks.branches.contactloss import compute_contact_loss
+
+    B = 3
+    tv, tf = hand_template()
+    rng = np.random.RandomState(5)
+    hand0 = (T(tv) * 1000).unsqueeze(0).repeat(B, 1, 1) + T(rng.normal(0, 2.0, size=(B, 1, 3)).astype(np.float32))
+    obj0, faces = _blob(subdiv, B, seed=11, patches=patches)
+    grads = {}
+    for target in ("all", "obj", "hand"):
+        hand = hand0.clone().cuda().requires_grad_()
+        obj = obj0.clone().cuda().requires_grad_()
+        missed, penetr, info, _ = compute_contact_loss(hand, tf, obj, faces, contact_mode="dist_tanh", collision_mode="dist_tanh",
+                                                       contact_target=target, obj_patches=patches)
+        (1.7 * missed + 0.6 * penetr).backward()
+        grads[target] = (hand.grad.cpu().numpy(), obj.grad.cpu().numpy())
+        if target == "all":
+            assert bool(info["repulsion_masks"].any()) and bool(info["attraction_masks"].any())
+    _, idx, _, _ = ops.pairmin(hand0.cuda(), obj0.cuda(), want_y=False)
+    idx = idx.cpu().numpy()
+    gh, go = grads["all"]
+    want = np.zeros_like(go)
+    for b in range(B):
+        for v in range(gh.shape[1]):
+            want[b, idx[b, v]] += -gh[b, v]  # float32 adds, ascending v
+    assert np.count_nonzero(want.any(axis=2)) < gh.shape[0] * gh.shape[1]  # several vertices share a closest point
+    assert np.array_equal(go.view(np.uint32), want.view(np.uint32))
+    # contact_target only selects the side that receives the gradient (contactloss.py:187-196)
+    assert np.array_equal(grads["obj"][1].view(np.uint32), go.view(np.uint32)) and not grads["obj"][0].any()
+    assert np.array_equal(grads["hand"][0].view(np.uint32), gh.view(np.uint32)) and not grads["hand"][1].any()
