@@ -5,7 +5,7 @@
 // arg-min), the two batch-global masked means and the penetration-depth metrics - ~40 small torch
 // kernels and two host syncs (`if valid_vals > 0`) in the reference, here one per-sample kernel plus
 // a one-block finalize that keeps every scalar on the device.
-// Backward: d/d(hand) directly, d/d(obj) by an owner scan over the 778 hand vertices (deterministic,
+// Backward: d/d(hand) directly, d/d(obj) by in-order sums over sorted closest-point groups (deterministic,
 // no float atomics).  contact_target (all|obj|hand) only selects which side receives gradient.
 // Quirks kept: `dist` mode thresholds SQUARED distances with the unsquared threshold,
 // `dist_tanh` attracts everything, empty mask => loss 0.
@@ -153,18 +153,20 @@ __device__ __forceinline__ void contact_gdelta(const float* hb, const float* ob,
   gx = coef * dx; gy = coef * dy; gz = coef * dz;
 }
 
-// Backward, one block per (slice of <= CB_SLICE object points, sample).  Every block evaluates the 778 per-vertex gradients (a
-// gather, a square root and a tanh each: cheap next to anything that scales with N); slice 0 also writes the hand side.  Object
-// side: the gradient of point n is the sum, in ascending hand-vertex order, of the g_delta of the vertices whose closest point is n.
-//   1. every vertex whose point lies in the slice enters its number into the point's slot with an LDS atomicMin (integers: the
-//      result does not depend on the order of arrival) - the lowest vertex of a group becomes the point's OWNER;
-//   2. the owners are compacted into a list (its order is irrelevant: every owner works alone);
-//   3. an owner walks the (g_delta, point) records of all vertices - one broadcast 16-byte LDS read each - and adds those of its
-//      group from itself upwards, i.e. in ascending order, with the same select-and-add the point-major scan of rounds 1-4 used;
-//   4. the slice's LDS image goes out as one coalesced write (points nobody maps to: zeros).
-// Cost per sample O(V * owners / 64 + N) instead of O(V * N) (114 us at 16 050 points, ~4 x that at 64 050); same additions in the
-// same order => bit-identical results (tests/test_contact_gpu.py compares with a sequential fp32 scatter).
+// Backward, one block per (slice of <= CB_SLICE object points, sample).  A hand vertex belongs to the slice that holds its closest
+// object point; the block evaluates the per-vertex gradient g_delta of ITS vertices only, writes their hand side, and builds the
+// object side of its slice: the gradient of point n is the sum, in ascending hand-vertex order, of the g_delta of the vertices whose
+// closest point is n.
+//   1. the slice's vertices are compacted (ballot + popcount per wave, wave totals through LDS) as keys (point << 10 | vertex);
+//   2. a bitonic sort of the keys in LDS (a hand close to one patch puts most of its 778 vertices into one slice: 55 compare-exchange
+//      stages at worst) makes every point's group contiguous, ascending in the vertex number;
+//   3. one lane per sorted vertex: gather, square root, tanh -> g_delta record in LDS, hand-side gradient to memory;
+//   4. the first lane of a group is the point's OWNER and adds the group's records in order - the additions, and their order, of the
+//      point-major scan of rounds 1-4 (every point looked at all V vertices: 114 us at 16 050 points, ~4 x that at 64 050);
+//   5. the slice's LDS image goes out as one coalesced write (points nobody maps to: zeros).
+// Bit-identical results: tests/test_contact_gpu.py compares with a sequential fp32 scatter of the hand-side gradient.
 constexpr int CB_SLICE = 2048;
+constexpr int CB_VBITS = 10;
 
 __global__ __launch_bounds__(256) void contact_bwd_kernel(const float* __restrict__ hand, const float* __restrict__ obj,
                                                           const int* __restrict__ idx21,
@@ -173,56 +175,72 @@ __global__ __launch_bounds__(256) void contact_bwd_kernel(const float* __restric
                                                           const float* __restrict__ out, const float* __restrict__ g_missed,
                                                           const float* __restrict__ g_penetr, ContactCfg cfg, int target, int slice,
                                                           float* __restrict__ grad_hand, float* __restrict__ grad_obj) {
-  const int b = blockIdx.y, tid = threadIdx.x, V = cfg.V, N = cfg.N;
+  static_assert(CT_MAXV == 4 * 256 && CT_MAXV == 1 << CB_VBITS, "four vertices per thread, vertex number in the key's low bits");
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, V = cfg.V, N = cfg.N;
   const float* hb = hand + (size_t)b * V * 3;
   const float* ob = obj + (size_t)b * N * 3;
   const float wm = (g_missed && out[4] > 0.f) ? g_missed[0] / out[4] : 0.f;
   const float wp = (g_penetr && out[5] > 0.f) ? g_penetr[0] / out[5] : 0.f;
   const int n0 = blockIdx.x * slice, cnt = min(N - n0, slice);
-  __shared__ float4 s_g[CT_MAXV];  // (g_delta, point index as bits)
-  __shared__ int s_first[CB_SLICE], s_owner[CT_MAXV], s_n;
+  __shared__ float s_gx[CT_MAXV], s_gy[CT_MAXV], s_gz[CT_MAXV];  // g_delta of the sorted vertices
+  __shared__ int s_key[CT_MAXV], s_cnt[16];
   __shared__ float s_acc[CB_SLICE * 3];
-  if (grad_obj) {
-    for (int i = tid; i < cnt; i += 256) s_first[i] = 0x7fffffff;
+  if (grad_obj)
     for (int i = tid; i < cnt * 3; i += 256) s_acc[i] = 0.f;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
+  bool in[4];
+  int pre[4], key[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = it * 256 + tid;
+    const int j = v < V ? idx21[(size_t)b * V + v] : -1;
+    in[it] = j >= n0 && j < n0 + cnt;
+    key[it] = ((j - n0) << CB_VBITS) | v;
+    const unsigned long long bal = __ballot(in[it]);
+    pre[it] = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[it * 4 + wave] = __popcll(bal);
   }
-  for (int v = tid; v < V; v += 256) {
-    const int j = idx21[(size_t)b * V + v];
+  __syncthreads();
+  int n_in = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if ((q & 3) == wave && in[q >> 2]) s_key[n_in + pre[q >> 2]] = key[q >> 2];
+    n_in += s_cnt[q];
+  }
+  if (grad_obj) {  // block-uniform.  (Without an object side nothing depends on the order.)
+    int n_pad = 1;
+    while (n_pad < n_in) n_pad <<= 1;
+    for (int i = n_in + tid; i < n_pad; i += 256) s_key[i] = 0x7fffffff;
+    for (int size = 2; size <= n_pad; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __syncthreads();
+        for (int t = tid; t < (n_pad >> 1); t += 256) {
+          const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+          const int a = s_key[lo], c = s_key[hi];
+          if ((a > c) == ((lo & size) == 0)) { s_key[lo] = c; s_key[hi] = a; }
+        }
+      }
+  }
+  __syncthreads();
+  for (int k = tid; k < n_in; k += 256) {
+    const int v = s_key[k] & (CT_MAXV - 1), j = n0 + (s_key[k] >> CB_VBITS);
     float gx, gy, gz;
     contact_gdelta(hb, ob, v, j, attr_mask[(size_t)b * V + v], rep_mask[(size_t)b * V + v], wm, wp, cfg, gx, gy, gz);
-    if (blockIdx.x == 0 && grad_hand) {
+    if (grad_hand) {
       float* g = grad_hand + ((size_t)b * V + v) * 3;
       const bool on = target != TARGET_OBJ;
       g[0] = on ? -gx : -0.f; g[1] = on ? -gy : -0.f; g[2] = on ? -gz : -0.f;
     }
-    if (grad_obj) {
-      const bool on = target != TARGET_HAND;
-      s_g[v] = make_float4(on ? gx : 0.f, on ? gy : 0.f, on ? gz : 0.f, __int_as_float(j));
-      if (j >= n0 && j < n0 + cnt) atomicMin(&s_first[j - n0], v);
-    }
+    const bool on = target != TARGET_HAND;
+    s_gx[k] = on ? gx : 0.f; s_gy[k] = on ? gy : 0.f; s_gz[k] = on ? gz : 0.f;
   }
   if (!grad_obj) return;  // block-uniform
   __syncthreads();
-  for (int v = tid; v < V; v += 256) {
-    const int j = __float_as_int(s_g[v].w);
-    if (j >= n0 && j < n0 + cnt && s_first[j - n0] == v) s_owner[atomicAdd(&s_n, 1)] = v;
-  }
-  __syncthreads();
-  const int owners = s_n;
-  for (int k = tid; k < owners; k += 256) {
-    const int v = s_owner[k], j = __float_as_int(s_g[v].w);
+  for (int k = tid; k < n_in; k += 256) {
+    const int p = s_key[k] >> CB_VBITS;
+    if (k > 0 && (s_key[k - 1] >> CB_VBITS) == p) continue;  // not the first vertex of its point
     float ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll 8
-    for (int u = 0; u < V; ++u) {
-      const float4 g = s_g[u];  // the same address in every lane: a broadcast read
-      const bool take = __float_as_int(g.w) == j && u >= v;
-      ax += take ? g.x : 0.f;
-      ay += take ? g.y : 0.f;
-      az += take ? g.z : 0.f;
-    }
-    float* a = s_acc + (j - n0) * 3;
+    for (int u = k; u < n_in && (s_key[u] >> CB_VBITS) == p; ++u) { ax += s_gx[u]; ay += s_gy[u]; az += s_gz[u]; }
+    float* a = s_acc + p * 3;
     a[0] = ax; a[1] = ay; a[2] = az;
   }
   __syncthreads();
@@ -262,13 +280,13 @@ int obman_contact_bwd(const float* hand, const float* obj, const int* idx21, con
                       float collision_thresh, int target, float* grad_hand, float* grad_obj, obman_stream_t stream) {
   ContactCfg cfg{V, N, 0, 0, contact_mode, collision_mode, contact_thresh, collision_thresh};
   if (B <= 0 || !cfg_ok(cfg) || target < 0 || target > 2) return -1;
-  // slices: at most CB_SLICE points (the LDS image), and at least ~12 per sample when there are points for them, so that a block
-  // has about one wave of owners to walk
+  // slices: at most CB_SLICE points (the LDS image), and at least ~12 per sample when there are points for them (parallelism: a
+  // block's own work is a few dozen vertices).  Without an object-side gradient one block per sample owns every vertex.
   int nslices = obman_cdiv(N, CB_SLICE);
   const int want = N / 32 < 12 ? (N / 32 > 0 ? N / 32 : 1) : 12;
   if (nslices < want) nslices = want;
-  const int slice = obman_cdiv(N, nslices);
-  dim3 grid(grad_obj ? obman_cdiv(N, slice) : 1, B);
+  const int slice = grad_obj ? obman_cdiv(N, nslices) : N;
+  dim3 grid(obman_cdiv(N, slice), B);
   contact_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(hand, obj, idx21, attr_mask, rep_mask, out, g_missed, g_penetr,
                                                              cfg, target, slice, grad_hand, grad_obj);
   OBMAN_LAUNCH_CHECK();

@@ -243,3 +243,12 @@ def test_contact_backward_object_side_is_the_ordered_scatter_of_the_hand_side(su
     # contact_target only selects the side that receives the gradient (contactloss.py:187-196)
     assert np.array_equal(grads["obj"][1].view(np.uint32), go.view(np.uint32)) and not grads["obj"][0].any()
     assert np.array_equal(grads["hand"][0].view(np.uint32), gh.view(np.uint32)) and not grads["hand"][1].any()
+    # one side only asks for its gradient (the launcher then owns every vertex with one block per sample / skips the hand writes)
+    for side in ("hand", "obj"):
+        hand = hand0.clone().cuda().requires_grad_(side == "hand")
+        obj = obj0.clone().cuda().requires_grad_(side == "obj")
+        missed, penetr, _, _ = compute_contact_loss(hand, tf, obj, faces, contact_mode="dist_tanh", collision_mode="dist_tanh",
+                                                    obj_patches=patches)
+        (1.7 * missed + 0.6 * penetr).backward()
+        got, ref = (hand.grad, gh) if side == "hand" else (obj.grad, go)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32)), side
