@@ -16,7 +16,13 @@ def main(src, dst, steps="auto", cmd="", top=30, steady=""):
         steps = max([float(r["Calls"]) for r in rows if "mano_fwd_kernel" in r["Name"]] or [1.0])
     steps = float(steps)
     if steady:  # drop kernels launched in fewer than half of the steps: MIOpen's find-phase candidates, probes after the timed region
-        rows = [r for r in rows if float(r["Calls"]) >= 0.5 * steps]
+        # ("steady" = 0.5; a number sets the fraction: a fresh box runs the find phase inside the profiled process, and its candidates
+        # then reach > 50 % of the step count - 0.9 keeps the per-step kernels only)
+        try:
+            frac = float(steady)
+        except ValueError:
+            frac = 0.5
+        rows = [r for r in rows if float(r["Calls"]) >= frac * steps]
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
     ours = [r for r in rows if any(k in r["Name"] for k in OURS)]
     others = [r for r in rows if r not in ours]
