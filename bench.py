@@ -810,6 +810,7 @@ def main():
             "decoder_roofline": decoder,
             "host_enqueue_ms": {"median": sorted(host)[len(host) // 2], "max": max(host), "hipgraph": bool(args.graph),
                                 "hipgraph_mode": graphed.mode if graphed is not None else None,
+                                "watchdog_wait": getattr(graphed, "watchdog_wait", None),
                                 "note": "host time per step inside the timed region (launch enqueue; the GPU runs asynchronously)"},
         }
         if use_dist:

@@ -194,6 +194,12 @@ __global__ __launch_bounds__(256) void contact_bwd_kernel(const float* __restric
     const int v = it * 256 + tid;
     const int j = v < V ? idx21[(size_t)b * V + v] : -1;
     in[it] = j >= n0 && j < n0 + cnt;
+    // an index outside [0, N) lies in no slice (the forward never produces one; a caller-supplied idx21 might): the first slice's
+    // block gives such a vertex a zero gradient instead of leaving its rows of grad_hand unwritten
+    if (blockIdx.x == 0 && grad_hand && v < V && (j < 0 || j >= N)) {
+      float* g = grad_hand + ((size_t)b * V + v) * 3;
+      g[0] = 0.f; g[1] = 0.f; g[2] = 0.f;
+    }
     key[it] = ((j - n0) << CB_VBITS) | v;
     const unsigned long long bal = __ballot(in[it]);
     pre[it] = __popcll(bal & ((1ull << lane) - 1ull));

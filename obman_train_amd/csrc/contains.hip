@@ -280,7 +280,9 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
   for (int i = tid; i < MB_PT; i += MC_THREADS) sh.hit[i] = 0;
   if (tid == 0) sh.ndefer = 0;
   __syncthreads();
-  if (dbg_stop == 1) return;  // measurement only (OBMAN_MC_DBG): wrong results
+#ifdef OBMAN_ABLATION
+  if (dbg_stop == 1) return;  // measurement only (-DOBMAN_ABLATION build + OBMAN_MC_DBG): wrong results; not in the product library
+#endif
   if (tid == 0) {
     float lo[5], hi[5];
     bool ok = true;
@@ -373,7 +375,9 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
     }
   }
   __syncthreads();
+#ifdef OBMAN_ABLATION
   if (dbg_stop == 2) return;
+#endif
 
   // ---- phase C: one triangle per lane against the cells its inflated box touches -----------------------------------------
   const float tcx = sh.grid[7], tcy = sh.grid[8], tcz = sh.grid[9], trad = sh.grid[10], cmax = sh.grid[11];
@@ -410,7 +414,9 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
       cx0 = grid_cell(xlo, g0x, icx, lastx); cx1 = grid_cell(xhi, g0x, icx, lastx);
       cy0 = grid_cell(ylo, g0y, icy, lasty); cy1 = grid_cell(yhi, g0y, icy, lasty);
     }
+#ifdef OBMAN_ABLATION
     if (dbg_stop == 3) continue;
+#endif
     // A triangle whose cells hold many points (a wide box: large triangle, edge-on triangle with a large margin, or no box at
     // all) would keep its lane - and so its wave - busy for hundreds of tests: the block does those together afterwards.
     if (cy1 > cy0 || cx1 - cx0 > 3) {
@@ -438,7 +444,9 @@ __global__ __launch_bounds__(MC_THREADS) void contains_binned_kernel(const float
     }
   }
   __syncthreads();
+#ifdef OBMAN_ABLATION
   if (dbg_stop == 4) return;
+#endif
   {  // the wide triangles: one wave per triangle, the lanes stride over the candidate points of each grid row
     const int nd = min(sh.ndefer, MB_DEFER);
     for (int k = wid; k < nd; k += MC_THREADS / 64) {
@@ -543,7 +551,11 @@ int contains_binned_launch(const float* points, const float* verts, const int* f
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid(ptiles * tsplit, B);
+#ifdef OBMAN_ABLATION
   static const int dbg = [] { const char* e = std::getenv("OBMAN_MC_DBG"); return e ? atoi(e) : 0; }();  // measurement only
+#else
+  const int dbg = 0;  // the product library carries no wrong-result switch
+#endif
   ObmanProfScope prof(OBMAN_K_CONTAINS, st);
   if (group_faces)
     contains_binned_kernel<true><<<grid, MC_THREADS, 0, st>>>(points, verts, faces, P, Nv, F, ptiles, tchunk, tsplit, group_faces, dbg, hits);

@@ -42,9 +42,10 @@ template <> struct R3Src<BPlain> { static __device__ __forceinline__ const bfraw
 template <class AOp> struct R3Raw { static __device__ __forceinline__ typename AOp::Raw make(u32x4 v) { return typename AOp::Raw{v}; } };
 
 __device__ __forceinline__ void r3_dma16(__amdgpu_buffer_rsrc_t r, unsigned lds_base, unsigned voff, int soff) {
-  // m0 = LDS base of the wave-instruction; lane l writes [m0 + 16 l, + 16).  m0 is not used by anything the compiler emits in
-  // these kernels (gfx9 DS instructions do not read it)
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(r), "s"(soff) : "memory");
+  // m0 = LDS base of the wave-instruction; lane l writes [m0 + 16 l, + 16).  m0 is declared clobbered: gfx9 DS
+  // instructions do not read it, but the compiler may use it for s_movrel / v_readlane / LDS-direct and must not keep a value
+  // of its own live across this statement
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
 }
 
 template <class AOp, class Epi, int NB>  // NB = 2 or 3 ring blocks per wave

@@ -64,6 +64,7 @@ class GradientBuckets:
         self._next = 0         # next bucket to all-reduce (index order)
         self.capturing = False  # inside a stream capture: nothing that needs the host may run (no gradient-less parameters)
         self.last_missing = 0
+        self.last_works = []   # the Work handles of the step just finished (trainer.wait_for_watchdog polls them before a capture)
         if not self.enabled:
             return
         self.backend = dist.get_backend(group)
@@ -241,12 +242,26 @@ class GradientBuckets:
                 if float(had[self._flag_of[p]]) == 0.0:
                     p.grad = None
         self.last_missing = len(self._missing)  # parameters that had no local gradient in the step just finished
+        self.last_works = [] if self.capturing else [w for _, w in self._works]
         self._works = []
         self._seen = set()
         self._missing = []
         self._lacked = False
         self._next = 0
         self._pending = [1 if flat is None else len(slots) for flat, slots in self.buckets]
+
+
+    def some_rank_lacked_a_gradient(self):
+        """After ``finish()``: did ANY rank of the group lack a gradient for a planned parameter in the step just finished?
+        Read from the REDUCED flag words of the last bucket (mean over ranks of "had one": below 1 = some rank had none), so every
+        rank gets the same answer without an extra collective - a refusal based on it is raised by all ranks together (the
+        rank-local ``last_missing`` is not: a rank that raises alone leaves its peers inside collectives that never complete).
+        One small device->host read; not for the recorded path."""
+        if not self.enabled:
+            return False
+        if self._no_reduce:
+            return bool(self.last_missing)
+        return bool(float(self._flags.min().item()) < 1.0 - 0.5 / self.world)  # one lacking rank lowers the mean by 1 / world
 
 
 def init_rccl(device, rank=None, world_size=None):

@@ -60,17 +60,60 @@ def _same_entry(a, b):
         return False
 
 
-def _let_the_watchdog_reap(dev, seconds=0.5):
-    """Before a capture that will hold RCCL work.  ProcessGroupNCCL's watchdog thread polls the end events of the outstanding
-    EAGER collectives (``hipEventQuery``, every 100 ms) until it has seen them complete.  Once the recorded step pulls RCCL's stream
-    into the capture, HIP answers such a query - on an event last recorded on that stream, eagerly, by the warm-up steps - with
-    ``hipErrorCapturedEvent``; the watchdog rethrows and the process aborts (measured: 1 of 8 runs of the 1-rank bench command, always
-    inside the capture window, ``tools/r05/fused_flake.sh``).  After the synchronize every eager collective has finished, so ONE
-    poll empties the watchdog's list; there is no call that waits for that poll, hence a few poll periods of sleep."""
+def _watchdog_period_s():
+    """Poll period of ProcessGroupNCCL's watchdog loop: ``kWatchdogThreadSleepMillis`` = 100 ms, compiled in (no environment switch
+    changes it in torch 2.10; ``TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC`` and friends govern the monitor thread, not this loop)."""
+    return 0.1
+
+
+def wait_for_watchdog(buckets, dev, timeout_s=10.0):
+    """Before a capture that will hold RCCL work: wait until the process group's watchdog thread has DROPPED every eager collective.
+
+    ProcessGroupNCCL's watchdog polls the end events of the outstanding EAGER collectives (``hipEventQuery``) until it has seen
+    them complete, then removes them from its list.  Once the recorded step pulls RCCL's stream into the capture, HIP answers such a
+    query - on an event last recorded on that stream, eagerly, by the warm-up steps - with ``hipErrorCapturedEvent``; the watchdog
+    rethrows and the process aborts (measured in round 5: 1 of 8 runs of the 1-rank bench command, always inside the capture window).
+
+    Round 6: a CONDITION instead of round 5's fixed ``sleep(0.5)``.  The warm-up's last ``Work`` handles are kept by
+    ``GradientBuckets.finish()`` (``last_works``); ``ProcessGroupNCCL._verify_work_timeout(work, t)`` walks the watchdog's own list
+    under its mutex and raises once ``work`` is no longer in it - which is exactly "the watchdog will never query this work's
+    events again".  The list is in launch order and the watchdog drops entries front to back, so the wait ends when the LAST work of
+    the warm-up is gone.  Returns a dict saying which condition ended the wait (bench.py prints it).  Where the probe is not
+    usable (another torch build: the method absent or not raising for a finished work within ``timeout_s``) the fallback is the
+    measured one: five poll periods of sleep after the synchronize."""
+    import datetime
     import time
 
-    torch.cuda.synchronize(dev)
-    time.sleep(seconds)
+    import torch.distributed as dist
+
+    torch.cuda.synchronize(dev)  # every eager collective has finished on the device: one watchdog pass drops them all
+    t0 = time.perf_counter()
+    works = list(getattr(buckets, "last_works", None) or [])
+    backend = None
+    try:
+        group = buckets.group if buckets.group is not None else dist.distributed_c10d._get_default_group()
+        backend = group._get_backend(torch.device(dev))
+    except Exception:  # noqa: BLE001 - any failure = no probe
+        backend = None
+    probe = getattr(backend, "_verify_work_timeout", None)
+    if works and probe is not None:
+        td = datetime.timedelta(milliseconds=1)
+        pending = works
+        while pending and time.perf_counter() - t0 < timeout_s:
+            still = []
+            for w in pending:
+                try:
+                    probe(w, td)
+                    still.append(w)  # found in the watchdog's list: not reaped yet
+                except Exception:  # noqa: BLE001 - DistBackendError: not in the list any more
+                    pass
+            pending = still
+            if pending:
+                time.sleep(_watchdog_period_s() / 4)
+        if not pending:
+            return {"condition": "watchdog list empty", "works": len(works), "waited_s": round(time.perf_counter() - t0, 4)}
+    time.sleep(5 * _watchdog_period_s())
+    return {"condition": "slept 5 watchdog periods (no probe)", "works": len(works), "waited_s": round(time.perf_counter() - t0, 4)}
 
 
 class GraphedTrainStep:
@@ -143,15 +186,18 @@ class GraphedTrainStep:
                 train_step(model, optimizer, self.static, self.buckets)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        if self.buckets is not None and self.buckets.last_missing:
+        if self.buckets is not None and self.buckets.some_rank_lacked_a_gradient():
             # found by the eager warm-up step, BEFORE anything is being recorded (an exception inside a capture that holds RCCL work
-            # leaves the stream in capture mode)
-            raise RuntimeError("GraphedTrainStep: %d planned parameter(s) received no gradient in the warm-up step.  A recorded "
+            # leaves the stream in capture mode).  Decided from the REDUCED flag words, so every rank of the group raises here
+            # together (a rank-local check lets one rank raise while its peers record and replay collectives that
+            # never complete).
+            raise RuntimeError("GraphedTrainStep: some rank of the group had planned parameter(s) without a gradient in the warm-up step.  A recorded "
                                "data-parallel step needs a fixed autograd graph on every rank (the 'some rank had a gradient' flags "
                                "of dp.GradientBuckets need a host round trip): pass such parameters in `exclude`, or run this step "
-                               "eagerly" % self.buckets.last_missing)
+                               "eagerly (this rank lacked %d)" % self.buckets.last_missing)
+        self.watchdog_wait = None
         if self.mode == "fused":
-            _let_the_watchdog_reap(dev)
+            self.watchdog_wait = wait_for_watchdog(self.buckets, dev)
         self.graph = torch.cuda.CUDAGraph()
         if self.mode == "single":
             with torch.cuda.graph(self.graph):

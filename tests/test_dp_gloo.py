@@ -122,7 +122,14 @@ def _branchy_worker(rank, world, port, out_dir):
     buckets.zero_grad()
     net(x, use_side=(rank == 0)).sum().backward()  # rank 1 never touches `side`: its hooks never fire there
     buckets.finish()
-    torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, os.path.join(out_dir, "branchy_%d.pt" % rank))
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    # the verdict a recorded data-parallel step is refused on must be the SAME on every rank: only rank 1 lacked
+    verdict = {"lacked_somewhere": buckets.some_rank_lacked_a_gradient(), "lacked_here": buckets.last_missing}
+    buckets.zero_grad()
+    net(x, use_side=True).sum().backward()  # a step in which every rank produces every gradient
+    buckets.finish()
+    verdict["clean_step"] = buckets.some_rank_lacked_a_gradient()
+    torch.save({"grads": grads, "verdict": verdict}, os.path.join(out_dir, "branchy_%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -142,6 +149,11 @@ def test_rank_divergent_graphs_issue_identical_collectives(tmp_path):
             want[k] = want.get(k, 0) + g / world
     got0 = torch.load(os.path.join(str(tmp_path), "branchy_0.pt"))
     got1 = torch.load(os.path.join(str(tmp_path), "branchy_1.pt"))
+    v0, v1 = got0["verdict"], got1["verdict"]
+    assert v0["lacked_here"] == 0 and v1["lacked_here"] > 0  # the rank-local count differs ...
+    assert v0["lacked_somewhere"] is True and v1["lacked_somewhere"] is True  # ... the reduced verdict does not
+    assert v0["clean_step"] is False and v1["clean_step"] is False
+    got0, got1 = got0["grads"], got1["grads"]
     for k in want:
         torch.testing.assert_close(got0[k], want[k], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(got1[k], got0[k], rtol=0, atol=0)
