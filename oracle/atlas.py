@@ -42,15 +42,16 @@ def _mlp2(params, prefix, x):
 
 
 def forward_inference(params, features, template_verts, faces, predict_trans=False, predict_scale=False,
-                      separate_features=None, training=True, out_factor=200.0):
-    """AtlasBranch.forward_inference (atlasbranch.py:110-150).  template_verts [N,3], features [B,C]."""
+                      separate_features=None, training=True, out_factor=200.0, mfma_round=None):
+    """AtlasBranch.forward_inference (atlasbranch.py:110-150).  template_verts [N,3], features [B,C].
+    ``mfma_round`` (not in the reference): see ``pointgen`` - the model of the build's bf16-MFMA decoder flavour."""
     B = features.shape[0]
     trans = _mlp2(params, "decode_trans.", features) if predict_trans else None
     scale = _mlp2(params, "decode_scale.", features) if predict_scale else None
     grid = template_verts.unsqueeze(0).repeat(B, 1, 1).transpose(2, 1)  # [B,3,N]
     dec_feat = separate_features if separate_features is not None else features
     x = torch.cat((grid, dec_feat.unsqueeze(2).repeat(1, 1, grid.shape[2])), 1)
-    verts = pointgen(params, x, training=training, out_factor=out_factor).transpose(2, 1)
+    verts = pointgen(params, x, training=training, out_factor=out_factor, mfma_round=mfma_round).transpose(2, 1)
     if predict_scale:
         scaled = scale.unsqueeze(1) * verts
         if predict_trans:

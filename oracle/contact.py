@@ -25,8 +25,9 @@ def _rowdot(a, b):
     return torch.bmm(a.reshape(n, 1, 3), b.reshape(n, 3, 1)).reshape(n)
 
 
-def mesh_contains_points(ray_origins, obj_triangles, direction=None):
+def mesh_contains_points(ray_origins, obj_triangles, direction=None, return_counts=False):
     """origins [B,P,3], triangles [B,T,3,3] -> exterior [B,P] bool (even hit count).
+    ``return_counts`` (tests only; not a reference argument): the crossing count [B,P] itself, before the parity.
 
     Moeller-Trumbore for every (point, triangle) pair along one shared direction."""
     B, T = obj_triangles.shape[:2]
@@ -61,6 +62,8 @@ def mesh_contains_points(ray_origins, obj_triangles, direction=None):
     t_ok = t >= TOL
     hit = v_ok * u_ok * parallel.repeat(1, P).logical_not() * t_ok
     hits = hit.view(B, P, T).sum(2)
+    if return_counts:
+        return hits
     return hits % 2 == 0
 
 

@@ -37,11 +37,17 @@ def _sub(named, prefix):
 
 
 def handnet_forward(named, cfg, sample, keys, packs, template_verts, template_faces, zones=None,
-                    resnet_shell=None, training=True, bn_training=None, no_loss=False, features=None):
+                    resnet_shell=None, training=True, bn_training=None, no_loss=False, features=None, mfma_round=None,
+                    encoder_autocast=None):
     """``keys`` = namespace with images/verts3d/joints3d/objpoints3d/sides keys of ``sample``.
     ``bn_training``: BN mode (defaults to ``training``; False = --freeze_batchnorm, epochpass3d.py:48-52).
     ``features`` (test hook): encoder output [B,C] used instead of running the ResNet, so everything downstream of the encoder
-    can be compared at tight tolerance, free of convolution-library round-off."""
+    can be compared at tight tolerance, free of convolution-library round-off.
+    ``mfma_round`` / ``encoder_autocast`` (not in the reference; BASELINE configs[2]'s stated precision): the decoder's layer-2/3
+    contraction operands and stored outputs rounded by ``mfma_round`` (``oracle/atlas.py:pointgen``), the ResNet under
+    ``torch.autocast("cpu", dtype=encoder_autocast)`` with fp32 features handed to the heads - the model of the build's
+    ``decoder.mfma_dtype = "bf16"`` / ``base_net.autocast_dtype`` flavours, so that those are compared with the oracle and not
+    with the build's own fp32 run."""
     c = dict(DEFAULTS)
     c.update(cfg)
     bn_train = training if bn_training is None else bn_training
@@ -52,7 +58,12 @@ def handnet_forward(named, cfg, sample, keys, packs, template_verts, template_fa
         feats = features
     else:
         resnet_shell.train(bn_train)
-        feats, _ = functional_call(resnet_shell, _sub(named, "base_net."), (image,))
+        if encoder_autocast is not None:
+            with torch.autocast("cpu", dtype=encoder_autocast):
+                feats, _ = functional_call(resnet_shell, _sub(named, "base_net."), (image,))
+            feats = feats.float()
+        else:
+            feats, _ = functional_call(resnet_shell, _sub(named, "base_net."), (image,))
     if c["atlas_separate_encoder"]:
         atlas_feats, _ = functional_call(resnet_shell, _sub(named, "atlas_base_net."), (image,))
     mano_lambdas = bool(c["mano_lambda_verts"] or c["mano_lambda_joints3d"])
@@ -79,7 +90,7 @@ def handnet_forward(named, cfg, sample, keys, packs, template_verts, template_fa
             _sub(named, "atlas_branch."), feats, template_verts, template_faces,
             predict_trans=c["atlas_predict_trans"], predict_scale=c["atlas_predict_scale"],
             separate_features=atlas_feats if c["atlas_separate_encoder"] else None,
-            training=bn_train, out_factor=c["atlas_out_factor"],
+            training=bn_train, out_factor=c["atlas_out_factor"], mfma_round=mfma_round,
         )
         if c["contact_lambda"] or c["collision_lambda"]:
             attr, penetr, info, metrics = _contact.compute_contact_loss(

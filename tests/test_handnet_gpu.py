@@ -114,7 +114,10 @@ FLAVOUR_BOUNDS = {
     #   all_bf16 (three boxes): loss 3.8e-3 .. 1.4e-2 (final_chamfer_loss), total 1.7e-3 .. 5.0e-3, points max 6.8e-2 .. 8.0e-2 / rms 1.6e-2,
     #             hamming 3.0e-2 .. 3.1e-2, track 1.3e-2 .. 5.4e-2 - MIOpen's bf16 weight-gradient kernels accumulate with atomics, so
     #             the encoder's gradients (hence the Adam trajectory) differ from run to run; the decoder-only flavour is run-to-run stable
-    "dec_bf16": dict(loss=2e-3, total=1e-3, points=1.6e-2, points_rms=4e-3, hamming=6e-3, track=1e-2),
+    # r06: the dec_bf16 flavour's forward is pinned to the ORACLE with the same roundings at bs 64
+    # (tests/test_parity_evidence_gpu.py:test_configs2_dec_bf16_bs64_256_matches_the_bf16_oracle) and the all_bf16 flavour to the
+    # autocast oracle; what this self-comparison still holds for it is the five-step Adam trajectory
+    "dec_bf16": dict(track=1e-2),
     "all_bf16": dict(loss=3e-2, total=1.5e-2, points=0.16, points_rms=4e-2, hamming=6e-2, track=0.12),
 }
 

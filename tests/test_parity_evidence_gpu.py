@@ -58,9 +58,11 @@ def _mx(g, w):
     return float((g - w).abs().max() / w.abs().max().clamp_min(1e-30))
 
 
-def _run_both(cfg_name, B, res, inject, grad_names):
+def _run_both(cfg_name, B, res, inject, grad_names, flavour="f32"):
     """One train-mode forward + backward of HandNet(**CONFIGS[cfg_name]) on the GPU and of the oracle on the host, same weights and
-    batch (the batch bench.py times, seed 0).  inject: the encoder is replaced by fixed features on both sides."""
+    batch (the batch bench.py times, seed 0).  inject: the encoder is replaced by fixed features on both sides.
+    flavour: "f32" | "dec_bf16" (decoder contractions on the bf16 matrix pipe; oracle: operands and stored layer outputs rounded
+    to bf16) | "all_bf16" (additionally the encoder under bf16 autocast on both sides)."""
     from oracle import handnet as ohandnet
     from oracle import mano as omano
     from obman_train_amd.mano_params import synthetic_mano
@@ -86,10 +88,16 @@ def _run_both(cfg_name, B, res, inject, grad_names):
         f_o = feats.clone().requires_grad_()
     o_total, o_res, o_losses = ohandnet.handnet_forward(
         named, cfg, dict(sample), _keys(), packs, model.atlas_branch.test_verts.clone(), model.atlas_branch.test_faces,
-        zones=load_contacts()[1], resnet_shell=resnet.resnet18(), training=True, features=f_o)
+        zones=load_contacts()[1], resnet_shell=resnet.resnet18(), training=True, features=f_o,
+        mfma_round=(lambda t: t.bfloat16().float()) if flavour != "f32" else None,
+        encoder_autocast=torch.bfloat16 if flavour == "all_bf16" else None)
     o_total.backward()
     if inject:
         model.base_net = _FixedFeatures(feats)
+    if flavour != "f32":
+        model.atlas_branch.decoder.mfma_dtype = "bf16"
+    if flavour == "all_bf16":
+        model.base_net.autocast_dtype = torch.bfloat16
     model.cuda()
     total, out, losses = model.forward(sample)
     total.backward()
@@ -146,8 +154,62 @@ def test_configs2_model_bs64_256_matches_cpu_oracle():
     soft = {k: v for k, v in m["terms"].items() if k not in ("penetration_loss", "attraction_loss", "contact_loss", "max_penetr",
                                                                "mean_penetr", "contact_auc")}
     assert max(soft.values()) <= 1e-4, m
-    assert m["worst_loss"] <= 1e-3, m
-    assert max(m["grads_l2"].values()) <= 3e-2, m
+    # r06: <= 10 x the measured values (worst term 4.3e-6 -> north_star's 1e-4 itself; gradients through 18
+    # convolution layers of two libraries 4.9e-3 -> 2e-2), where r05 asserted 1e-3 / 3e-2
+    assert m["worst_loss"] <= 1e-4, m
+    assert max(m["grads_l2"].values()) <= 2e-2, m
+
+
+# configs[2] in its STATED precision against the ORACLE (VERDICT r05 task 2b).  Frozen at ~3x the MI355X measurement
+# (profiles/r06_parity_measured.md).  What the numbers mean: the oracle applies the same roundings (contraction operands and the
+# stored h2 / h3 in bf16, fp32 accumulation and statistics) but sums in another order, so a value on a bf16 rounding boundary
+# lands on the neighbouring bf16 number (2^-8 relative) in a few activations; the chamfer / vertex terms average that out, the
+# contact terms sit on hard thresholds (their bound is the mask Hamming distance).
+BF16_VS_ORACLE = {
+    "dec_bf16": dict(total=2e-3, soft=5e-3, points=1.6e-2, points_rms=4e-3, hamming=6e-3, verts=1e-4),
+    "all_bf16": dict(total=3e-2, soft=6e-2, points=0.16, points_rms=4e-2, hamming=6e-2, verts=5e-2),
+}
+_HARD = ("penetration_loss", "attraction_loss", "contact_loss", "max_penetr", "mean_penetr", "contact_auc")
+
+
+def _check_flavour(name, m, b):
+    soft = {k: v for k, v in m["terms"].items() if k not in _HARD}
+    m["worst_soft_term"] = max(soft, key=soft.get)
+    m["worst_soft"] = soft[m["worst_soft_term"]]
+    assert m["total"] <= b["total"], (name, m)
+    assert m["worst_soft"] <= b["soft"], (name, m)
+    assert m["objpoints3d_of_scale"] <= b["points"] and m["objpoints3d_rms_of_scale"] <= b["points_rms"], (name, m)
+    assert m["verts_of_scale"] <= b["verts"] and m["joints_of_scale"] <= b["verts"], (name, m)
+    assert m["repulsion_hamming"] <= b["hamming"] and m["attraction_hamming"] <= b["hamming"], (name, m)
+
+
+def test_configs2_dec_bf16_bs64_256_matches_the_bf16_oracle():
+    """configs[2] with the decoder's contractions on the bf16 matrix pipe (`decoder.mfma_dtype = "bf16"`), whole model, bs 64,
+    256 x 256, against one host step of the oracle WITH the same operand / storage roundings - total, every loss term, object
+    points (max and rms), hand vertices, both contact masks.  Until round 5 this flavour was only compared with the build's own
+    fp32 run at bs 16 (tests/test_handnet_gpu.py FLAVOUR_BOUNDS)."""
+    from tests.conftest import record_measurement
+
+    m, (_, out, _), (_, o_res, _) = _run_both("c3", 64, 256, False, _DOWNSTREAM, flavour="dec_bf16")
+    w = o_res["objpoints3d"].detach()
+    m["objpoints3d_rms_of_scale"] = float((out["objpoints3d"].detach().cpu() - w).square().mean().sqrt() / w.abs().max())
+    record_measurement("configs2_dec_bf16_bs64_256_vs_bf16_oracle", m)
+    _check_flavour("dec_bf16", m, BF16_VS_ORACLE["dec_bf16"])
+
+
+def test_configs2_all_bf16_bs16_256_matches_the_autocast_bf16_oracle():
+    """configs[2] as `bench.py --config c3 --encoder-dtype bf16 --decoder-dtype bf16` runs it (ResNet under bf16 autocast with the
+    fused bf16 BatchNorm kernels + bf16 decoder) against the oracle with the ResNet under CPU bf16 autocast (oneDNN's bf16
+    convolutions, fp32 accumulation) and the rounded decoder.  Two convolution libraries in bf16, 18 layers deep: the bounds are
+    bf16-noise bounds, measured then frozen - what they pin is that the stated-precision build is a bf16-accurate evaluation of
+    the REFERENCE's model, not merely of this build's fp32 flavour."""
+    from tests.conftest import record_measurement
+
+    m, (_, out, _), (_, o_res, _) = _run_both("c3", 16, 256, False, _DOWNSTREAM, flavour="all_bf16")
+    w = o_res["objpoints3d"].detach()
+    m["objpoints3d_rms_of_scale"] = float((out["objpoints3d"].detach().cpu() - w).square().mean().sqrt() / w.abs().max())
+    record_measurement("configs2_all_bf16_bs16_256_vs_autocast_oracle", m)
+    _check_flavour("all_bf16", m, BF16_VS_ORACLE["all_bf16"])
 
 
 def test_configs2_b2_names_the_loose_term():
