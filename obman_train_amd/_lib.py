@@ -9,7 +9,7 @@ import os
 from .build import LIB
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); 'p' pointer, 'i' int, 'l' long, 'f' float
 _SIGNATURES = {
@@ -45,6 +45,15 @@ _SIGNATURES = {
     "obman_bnpool_bwd_bf16": (_c_int, "ppppp" "iiii" "i" "pppp" "p"),
     "obman_imgstream_ws_bytes": (_c_long, "iii"),
     "obman_imgstream_fwd": (_c_int, "piiip" "ii" "iii" "pp" "pp" "p"),
+    "obman_adam_step": (_c_int, "pi" "fffff" "p"),
+    "obman_bf16_shadow": (_c_int, "ppl" "p"),
+    "obman_affine_points_fwd": (_c_int, "ppp" "ii" "p" "p"),
+    "obman_affine_points_ws_floats": (_c_long, "i"),
+    "obman_affine_points_bwd": (_c_int, "ppp" "ii" "pppp" "p"),
+    "obman_mse_terms_ws_floats": (_c_long, ""),
+    "obman_mse_terms_fwd": (_c_int, "pi" "pp" "p"),
+    "obman_mse_terms_bwd": (_c_int, "pi" "p" "p"),
+    "obman_gt_object_stats": (_c_int, "p" "ii" "ppp" "p"),
     "obman_prof_enable": (_c_int, "i"),
     "obman_prof_summary": (_c_int, "ipp"),
     "obman_mano_model_floats": (_c_int, ""),
@@ -70,6 +79,14 @@ class PointGenParams(ctypes.Structure):  # obman_pointgen_params
 class PointGenGrads(ctypes.Structure):  # obman_pointgen_grads
     _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("w4", _fp), ("b4", _fp),
                 ("bn_w", _fp * 3), ("bn_b", _fp * 3), ("feat", _fp)]
+
+
+class AdamTensor(ctypes.Structure):  # obman_adam_tensor
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("shadow_bf16", _fp), ("step", _fp), ("n", _c_long)]
+
+
+class MseTerm(ctypes.Structure):  # obman_mse_term
+    _fields_ = [("pred", _fp), ("target", _fp), ("grad", _fp), ("n", _c_long)]
 
 
 class ImgParams(ctypes.Structure):  # obman_img_params: 24 x 32-bit words per sample

@@ -4,7 +4,7 @@
 
 #include <atomic>
 
-#define OBMAN_ABI_VERSION 6
+#define OBMAN_ABI_VERSION 7
 #define OBMAN_WAVE 64
 
 #define OBMAN_LAUNCH_CHECK()                       \

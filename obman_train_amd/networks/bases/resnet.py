@@ -46,9 +46,9 @@ class BasicBlock(nn.Module):
         if self.downsample is None:
             skip = xs
         else:
-            skip = ops.bn_act(self.downsample[1], self.downsample[0](xs), relu=False, count=self._count)
-        y = ops.bn_act(self.bn1, self.conv1(x), count=self._count)
-        return ops.bn_act(self.bn2, self.conv2(y), skip=skip, count=self._count, dual=self._dual)
+            skip = ops.bn_act(self.downsample[1], ops.shadow_conv2d(self.downsample[0], xs), relu=False, count=self._count)
+        y = ops.bn_act(self.bn1, ops.shadow_conv2d(self.conv1, x), count=self._count)
+        return ops.bn_act(self.bn2, ops.shadow_conv2d(self.conv2, y), skip=skip, count=self._count, dual=self._dual)
 
 
 class Bottleneck(nn.Module):
@@ -72,10 +72,10 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             skip = xs
         else:
-            skip = ops.bn_act(self.downsample[1], self.downsample[0](xs), relu=False, count=self._count)
-        y = ops.bn_act(self.bn1, self.conv1(x), count=self._count)
-        y = ops.bn_act(self.bn2, self.conv2(y), count=self._count)
-        return ops.bn_act(self.bn3, self.conv3(y), skip=skip, count=self._count, dual=self._dual)
+            skip = ops.bn_act(self.downsample[1], ops.shadow_conv2d(self.downsample[0], xs), relu=False, count=self._count)
+        y = ops.bn_act(self.bn1, ops.shadow_conv2d(self.conv1, x), count=self._count)
+        y = ops.bn_act(self.bn2, ops.shadow_conv2d(self.conv2, y), count=self._count)
+        return ops.bn_act(self.bn3, ops.shadow_conv2d(self.conv3, y), skip=skip, count=self._count, dual=self._dual)
 
 
 class ResNet(nn.Module):
@@ -139,7 +139,7 @@ class ResNet(nn.Module):
             blk._count = not batched
             blk._dual = dual and blk is not self._blocks[-1]
         try:
-            x = ops.bn_relu_maxpool(self.bn1, self.conv1(x), self.maxpool, count=not batched)
+            x = ops.bn_relu_maxpool(self.bn1, ops.shadow_conv2d(self.conv1, x), self.maxpool, count=not batched)
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         finally:
             for blk in self._blocks:

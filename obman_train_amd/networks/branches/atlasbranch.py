@@ -52,12 +52,9 @@ class AtlasBranch(nn.Module):
 
     def _assemble(self, verts, trans, scale, with_faces):
         res = {}
-        if scale is not None:
-            scaled = scale.unsqueeze(1) * verts
-            if trans is not None:
-                points = scaled + trans.unsqueeze(1)
-        elif trans is not None:
-            points = verts + trans.unsqueeze(1)
+        if trans is not None:
+            # scale.unsqueeze(1) * verts + trans.unsqueeze(1) (atlasbranch.py:136-141): one launch, and a two-launch backward
+            points = ops.affine_points(verts, scale, trans)
         if scale is None and trans is None:
             res = {"objpoints3d": verts}
         if trans is not None:
@@ -131,12 +128,17 @@ class AtlasLoss:
                 TransQueries.center3d in target and self.trans_weight):
             gt = target[TransQueries.objpoints3d]
             if "objtrans" in preds and has_gt and "objpointscentered3d" in preds:
-                centroids = gt.mean(1)
-                l_trans = torch_f.mse_loss(preds["objtrans"], centroids)
-                out["atlas_trans3d"] = l_trans
-                centred = gt - centroids.unsqueeze(1)
+                # gt.mean(1), gt - centroids, norm(centred, 2, 2).max(1)[0] (atlasbranch.py:219-229): one launch (targets, no
+                # gradient); the two mse_loss heads: one launch per direction
+                centroids, centred, radius = ops.gt_object_stats(gt)
+                heads = [(preds["objtrans"], centroids)]
                 if "objscale" in preds:
-                    l_scale = torch_f.mse_loss(preds["objscale"], torch.norm(centred, 2, 2).max(1)[0].unsqueeze(1))
+                    heads.append((preds["objscale"], radius))
+                vals = ops.mse_terms(heads)
+                l_trans = vals[0]
+                out["atlas_trans3d"] = l_trans
+                if "objscale" in preds:
+                    l_scale = vals[1]
                     out["atlas_scale3d"] = l_scale
                 else:
                     l_scale = 0

@@ -100,27 +100,28 @@ class ManoLoss:
         dev = preds["verts"].device
         terms = []  # (lambda, term) in the reference's order: ``final = zeros(1); final += lambda * term`` (ops.weighted_terms)
         out = {}
+        # the reference's torch_f.mse_loss calls (manobranch.py:251-318), gathered and evaluated by ONE launch per direction
+        # (ops.mse_terms; target None = the reference's ``mse_loss(x, zeros_like(x))`` regularisers)
+        want = []  # (name, lambda, prediction, target)
         if TransQueries.verts3d in target and self.lambda_verts:
-            l_verts = torch_f.mse_loss(preds["verts"], target[TransQueries.verts3d])
-            terms.append((self.lambda_verts, l_verts))
-        else:
-            l_verts = None
-        out["mano_verts3d"] = l_verts
+            want.append(("verts", self.lambda_verts, preds["verts"], target[TransQueries.verts3d]))
         if TransQueries.joints3d in target and self.lambda_joints3d:
-            l_joints = torch_f.mse_loss(preds["joints"], target[TransQueries.joints3d])
-            terms.append((self.lambda_joints3d, l_joints))
-            out["mano_joints3d"] = l_joints
+            want.append(("joints", self.lambda_joints3d, preds["joints"], target[TransQueries.joints3d]))
         if self.lambda_shape:
-            l_shape = torch_f.mse_loss(preds["shape"], torch.zeros_like(preds["shape"]))
-            terms.append((self.lambda_shape, l_shape))
-        else:
-            l_shape = None
-        out["mano_shape"] = l_shape
+            if preds["shape"] is None:  # the reference fails here in torch.zeros_like(None) (manobranch.py:298-301)
+                raise TypeError("zeros_like(): argument 'input' (position 1) must be Tensor, not NoneType")
+            want.append(("shape", self.lambda_shape, preds["shape"], None))
         if self.lambda_pose_reg:
-            reg = preds["pose"][:, 3:]
-            l_pose = torch_f.mse_loss(reg, torch.zeros_like(reg))
-            terms.append((self.lambda_pose_reg, l_pose))
-            out["pose_reg"] = l_pose
+            want.append(("pose", self.lambda_pose_reg, preds["pose"][:, 3:], None))
+        vals = dict(zip([w[0] for w in want], ops.mse_terms([(w[2], w[3]) for w in want])))
+        for name, lam, _, _ in want:
+            terms.append((lam, vals[name]))
+        out["mano_verts3d"] = vals.get("verts")
+        if "joints" in vals:
+            out["mano_joints3d"] = vals["joints"]
+        out["mano_shape"] = vals.get("shape")
+        if "pose" in vals:
+            out["pose_reg"] = vals["pose"]
         if BaseQueries.hand_pcas in target and self.lambda_pca:
             raise KeyError("pcas")  # the reference reads preds['pcas'], which ManoBranch never produces (App. C #14)
         out["mano_pca"] = None

@@ -711,3 +711,177 @@ def image_stream(src_rgb, params_words, max_blur_r, any_contrast, out_res, chann
                                        int(out_res), int(bool(channels_last)), int(black_pad), _ct.addressof(mean3),
                                        _ct.addressof(std3), _ptr(ws), _ptr(out), _stream()), "obman_imgstream_fwd")
     return out.permute(0, 3, 1, 2) if channels_last else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: small operators of the step as single launches (csrc/stepops.hip)
+_SCRATCH = {}  # (name, device, stream) -> persistent fp32 scratch (launch-ordered on that stream; graph replays reuse it)
+
+
+def _scratch(name, floats, device):
+    key = (name, device, _stream())
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < floats:
+        t = _SCRATCH[key] = torch.empty(int(floats), dtype=torch.float32, device=device)
+    return t
+
+
+class _AffinePoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, scale, trans):
+        verts = _dev(verts, "verts")
+        B, N = verts.shape[0], verts.shape[1]
+        s = _dev(scale, "scale").reshape(B) if scale is not None else None
+        t = _dev(trans, "trans").reshape(B, 3) if trans is not None else None
+        out = torch.empty_like(verts)
+        _lib.check(_lib.lib().obman_affine_points_fwd(verts.data_ptr(), _ptr(s), _ptr(t), B, N, out.data_ptr(), _stream()),
+                   "obman_affine_points_fwd")
+        ctx.save_for_backward(verts, s)
+        ctx.shapes = (None if scale is None else scale.shape, None if trans is None else trans.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        verts, s = ctx.saved_tensors
+        B, N = verts.shape[0], verts.shape[1]
+        g = _dev(g, "grad")
+        need_v, need_s, need_t = ctx.needs_input_grad
+        gv = torch.empty_like(verts) if need_v else None
+        gs = torch.empty(B, dtype=torch.float32, device=verts.device) if (need_s and ctx.shapes[0] is not None) else None
+        gt = torch.empty((B, 3), dtype=torch.float32, device=verts.device) if (need_t and ctx.shapes[1] is not None) else None
+        ws = _scratch("affine", _lib.lib().obman_affine_points_ws_floats(B), verts.device)
+        _lib.check(_lib.lib().obman_affine_points_bwd(g.data_ptr(), verts.data_ptr(), _ptr(s), B, N, _ptr(gv), _ptr(gs), _ptr(gt),
+                                                      ws.data_ptr(), _stream()), "obman_affine_points_bwd")
+        return gv, (gs.reshape(ctx.shapes[0]) if gs is not None else None), (gt.reshape(ctx.shapes[1]) if gt is not None else None)
+
+
+def affine_points(verts, scale=None, trans=None):
+    """``scale.unsqueeze(1) * verts + trans.unsqueeze(1)`` (atlasbranch.py:136-141; verts [B,N,3], scale [B,1], trans [B,3]) as
+    one launch, and a backward of two launches where autograd runs two broadcast products and two [B,N,3] reductions."""
+    return _AffinePoints.apply(verts, scale, trans)
+
+
+class _MseTerms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n_pairs, *tensors):
+        preds, targets = tensors[:n_pairs], tensors[n_pairs:]
+        preds = [_dev(p, "pred") for p in preds]
+        targets = [None if t is None else _dev(t, "target") for t in targets]
+        for p, t in zip(preds, targets):
+            if t is not None and t.shape != p.shape:
+                raise ValueError("mse_terms: target %s does not match prediction %s" % (tuple(t.shape), tuple(p.shape)))
+        dev = preds[0].device
+        arr = (_lib.MseTerm * n_pairs)()
+        for i, (p, t) in enumerate(zip(preds, targets)):
+            arr[i].pred, arr[i].target, arr[i].grad, arr[i].n = p.data_ptr(), _ptr(t), None, p.numel()
+        out = torch.empty(n_pairs, dtype=torch.float32, device=dev)
+        ws = _scratch("mse", _lib.lib().obman_mse_terms_ws_floats(), dev)
+        _lib.check(_lib.lib().obman_mse_terms_fwd(_ct.addressof(arr), n_pairs, ws.data_ptr(), out.data_ptr(), _stream()),
+                   "obman_mse_terms_fwd")
+        ctx.n_pairs = n_pairs
+        ctx.has_target = [t is not None for t in targets]
+        ctx.save_for_backward(*preds, *[t for t in targets if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n_pairs
+        saved = ctx.saved_tensors
+        preds, rest = saved[:n], list(saved[n:])
+        targets = [rest.pop(0) if has else None for has in ctx.has_target]
+        g = _dev(g, "grad")
+        arr = (_lib.MseTerm * n)()
+        grads = []
+        for i, (p, t) in enumerate(zip(preds, targets)):
+            gr = torch.empty_like(p) if ctx.needs_input_grad[1 + i] else None
+            grads.append(gr)
+            arr[i].pred, arr[i].target, arr[i].grad, arr[i].n = p.data_ptr(), _ptr(t), _ptr(gr), p.numel()
+        _lib.check(_lib.lib().obman_mse_terms_bwd(_ct.addressof(arr), n, g.data_ptr(), _stream()), "obman_mse_terms_bwd")
+        return (None,) + tuple(grads) + (None,) * n
+
+
+def mse_terms(pairs):
+    """``[torch_f.mse_loss(pred, target) for pred, target in pairs]`` (``target=None``: zeros, the reference's
+    ``mse_loss(x, zeros_like(x))`` regularisers) as ONE forward launch (+ a one-block finalize) and ONE backward launch for up to
+    8 differently sized tensors: the MSE heads of ManoLoss / AtlasLoss (manobranch.py:251-318, atlasbranch.py:213-232).  Returns a
+    list of 0-dim tensors (views of one [k] tensor).  Targets get no gradient (they are data in the reference)."""
+    if not pairs:
+        return []
+    if len(pairs) > 8:
+        return mse_terms(pairs[:8]) + mse_terms(pairs[8:])
+    out = _MseTerms.apply(len(pairs), *[p for p, _ in pairs], *[t for _, t in pairs])
+    return [out[i] for i in range(len(pairs))]
+
+
+def gt_object_stats(gt):
+    """Ground-truth object cloud [B,N,3] -> (centroids [B,3], centred [B,N,3], max point norm [B,1]): the target preparation of
+    AtlasLoss.compute_loss (atlasbranch.py:219-229: ``gt.mean(1)``, ``gt - centroids.unsqueeze(1)``,
+    ``torch.norm(centred, 2, 2).max(1)[0].unsqueeze(1)``) in one launch instead of five.  No gradient."""
+    gt = _dev(gt.detach(), "gt")
+    B, N = gt.shape[0], gt.shape[1]
+    cen = torch.empty((B, 3), dtype=torch.float32, device=gt.device)
+    centred = torch.empty_like(gt)
+    mx = torch.empty((B, 1), dtype=torch.float32, device=gt.device)
+    _lib.check(_lib.lib().obman_gt_object_stats(gt.data_ptr(), B, N, cen.data_ptr(), centred.data_ptr(), mx.data_ptr(), _stream()),
+               "obman_gt_object_stats")
+    return cen, centred, mx
+
+
+def bf16_shadow(param, out=None):
+    """bf16 copy of an fp32 tensor in the SAME memory order (strides kept: a channels_last filter stays channels_last), written by
+    ``obman_bf16_shadow``; ``optim.ObmanAdam`` keeps it current from then on."""
+    if out is None:
+        out = torch.empty_like(param, dtype=torch.bfloat16, memory_format=torch.preserve_format)
+    if out.stride() != param.stride() or not _is_dense(param):
+        raise ValueError("bf16_shadow: needs a dense tensor and a shadow with the same strides")
+    _lib.check(_lib.lib().obman_bf16_shadow(param.data_ptr(), out.data_ptr(), param.numel(), _stream()), "obman_bf16_shadow")
+    return out
+
+
+def _is_dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+class _ShadowConv2d(torch.autograd.Function):
+    """conv2d(x, weight) of a bf16-autocast encoder reading the weight's bf16 SHADOW (kept current by the optimizer kernel) instead
+    of casting the fp32 filter every step; the gradient goes to the fp32 parameter.  MIOpen does the convolutions (north_star)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, shadow, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, shadow)
+        ctx.conf = (stride, padding, dilation, groups)
+        return torch.ops.aten.convolution(x, shadow, None, stride, padding, dilation, False, [0, 0], groups)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, shadow = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conf
+        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, shadow, None, stride, padding, dilation, False, [0, 0], groups,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw, None, None, None, None, None
+
+
+def shadow_conv2d(conv, x):
+    """``conv(x)`` for an ``nn.Conv2d`` without bias inside a bf16-autocast region when ``conv.weight`` carries a bf16 shadow
+    (``conv.weight._obman_shadow``, attached by ``optim.attach_bf16_shadows`` and rewritten by ``optim.ObmanAdam``'s kernel): same
+    MIOpen kernels, no weight-cast launch.  Anything else takes ``conv(x)`` itself.
+
+    Staleness: the optimizer kernel writes filter and shadow together through raw pointers, which leaves the filter's autograd
+    version counter alone; any torch-side in-place write (``load_state_dict``, another optimizer, ``copy_``) bumps it.  A shadow whose
+    recorded version differs from the filter's - or whose strides differ (the encoder re-lays its filters out as channels_last in
+    its first forward) - is rewritten here before it is used.  (Writes through ``.data`` are invisible to the counter:
+    ``optim.refresh_bf16_shadows`` after those.)"""
+    w = conv.weight
+    sh = getattr(w, "_obman_shadow", None)
+    if (sh is None or conv.bias is not None or not x.is_cuda or not torch.is_autocast_enabled()
+            or torch.get_autocast_dtype("cuda") != torch.bfloat16 or conv.padding_mode != "zeros" or not _is_dense(w)):
+        return conv(x)
+    if sh.stride() != w.stride():
+        sh = w._obman_shadow = bf16_shadow(w.detach())
+        w._obman_shadow_version = w._version
+    elif getattr(w, "_obman_shadow_version", None) != w._version:
+        bf16_shadow(w.detach(), out=sh)
+        w._obman_shadow_version = w._version
+    with torch.autocast("cuda", enabled=False):
+        return _ShadowConv2d.apply(x.to(torch.bfloat16), w, sh, list(conv.stride), list(conv.padding), list(conv.dilation),
+                                   conv.groups)

@@ -32,8 +32,17 @@ def make_optimizer(model, name="adam", lr=1e-4, momentum=0.9, weight_decay=0.0, 
     (``GraphedTrainStep``): Adam keeps its step counters on the device and never reads them on the host."""
     params = [p for p in model.parameters() if p.requires_grad]
     if name == "adam":
-        fused = all(p.is_cuda for p in params)  # one multi-tensor kernel instead of ~10 foreach launches per step
-        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused, capturable=bool(capturable and fused))
+        if params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            # round 6: the step as this package's multi-tensor kernel (csrc/stepops.hip; device-side step counters, so it records
+            # into a hipGraph whatever `capturable` says); a bf16-autocast encoder also gets bf16 shadow filters the kernel keeps
+            # current (no per-step weight-cast launches)
+            from . import optim
+
+            base = getattr(model, "base_net", None)
+            if base is not None and getattr(base, "autocast_dtype", None) == torch.bfloat16:
+                optim.attach_bf16_shadows(base)
+            return optim.ObmanAdam(params, lr=lr, weight_decay=weight_decay)
+        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
     if name == "rms":
         return torch.optim.RMSprop(params, lr=lr, weight_decay=weight_decay)
     if name == "sgd":
@@ -229,6 +238,9 @@ class GraphedTrainStep:
                             t.copy_(old[name])
                         else:  # state created by the warm-up itself (first step of a fresh optimizer): back to its initial value
                             t.zero_()
+            from . import optim  # bf16 shadow filters (optim.ObmanAdam): rewritten IN PLACE from the restored fp32 filters
+
+            optim.refresh_bf16_shadows(model)
 
     def __call__(self, sample):
         for k, v in sample.items():

@@ -123,9 +123,28 @@ def laplacian_loss(verts, row_ptr, col, val):
     return torch.norm(Lx.reshape(-1, 3), p=2, dim=1).mean()
 
 
+def affine_points(verts, scale=None, trans=None):
+    """atlasbranch.py:136-141, the reference's own operations."""
+    pts = verts if scale is None else scale.unsqueeze(1) * verts
+    return pts if trans is None else pts + trans.unsqueeze(1)
+
+
+def mse_terms(pairs):
+    import torch.nn.functional as F
+
+    return [F.mse_loss(p, torch.zeros_like(p) if t is None else t) for p, t in pairs]
+
+
+def gt_object_stats(gt):
+    centroids = gt.mean(1)
+    centred = gt - centroids.unsqueeze(1)
+    return centroids, centred, torch.norm(centred, 2, 2).max(1)[0].unsqueeze(1)
+
+
 def install(monkeypatch):
     from obman_train_amd import ops
 
-    for name in ("pairmin", "chamfer", "mano_lbs", "mesh_contains_hits", "contact_tail", "pointgen_decode", "edge_loss", "laplacian_loss"):
+    for name in ("pairmin", "chamfer", "mano_lbs", "mesh_contains_hits", "contact_tail", "pointgen_decode", "edge_loss", "laplacian_loss", "affine_points", "mse_terms",
+                 "gt_object_stats"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "require_rocm", lambda device: None)
