@@ -1801,6 +1801,26 @@ int tn_bf16_chunks(int M, int Nc, int N, int Bsz, int bn) {
   const long per = (ntiles + want - 1) / want;
   return (int)((ntiles + per - 1) / per);
 }
+// round 6: the wide (256 x 288) tile of decoder_tn2.h for the transposed layer-2 weight gradient (M = C1 = 515 = 2 x 256 + 3 rows,
+// Nc = C2 = 257 columns): full row tiles in tn2w_bf16_kernel, the M % 256 <= 3 remainder rows in gh2_inplace_side_kernel.
+// One round of blocks (one 512-thread block per CU).  OBMAN_DEC_TN2W=0: the 128 x 320 tiles of tn2_bf16_kernel (A/B).
+struct Tn2wPlan { bool use; int mt, ns, chunks, tiles_per_chunk; };
+Tn2wPlan tn2w_plan(int M, int Nc, int N, int Bsz) {
+  static const int on = [] { const char* e = getenv("OBMAN_DEC_TN2W"); return e ? atoi(e) : 1; }();
+  Tn2wPlan p{false, 0, 0, 0, 0};
+  if (!on || M < TW_BM || M % TW_BM > 3 || Nc > TW_BN || Nc <= 160) return p;
+  p.mt = M / TW_BM;
+  p.ns = M % TW_BM;
+  const long ntiles = (long)((Bsz + 7) / 8) * ((N + 3) / 4);
+  long want = 256 / p.mt;
+  if (want > ntiles) want = ntiles;
+  if (want < 1) want = 1;
+  p.tiles_per_chunk = (int)((ntiles + want - 1) / want);
+  p.chunks = (int)((ntiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk);
+  p.use = true;
+  return p;
+}
+long tn2w_part_floats(const Tn2wPlan& p, int Nc) { return (long)p.chunks * p.mt * TW_BM * Nc + (long)GH2S_BLOCKS * 3 * Nc; }
 // l1_reduce geometry: vertex sub-tiles per block such that tiles x sample-groups x channel-tiles ~ 1024 blocks
 struct L1Geo { int S, tiles, groups; };
 L1Geo l1_geo(const Dims& d) {
@@ -1864,7 +1884,10 @@ BwdWs bwd_ws(const Dims& d) {
     auto need = [&](int M, int Nc, long R) {
       if (d.bf16 && R == d.R) {  // the bf16 flavour forms the layer-2 product transposed (backward_bf16)
         if (M == d.C2 && Nc == d.C1) { M = d.C1; Nc = d.C2; }
-        return (long)tn_bf16_chunks(M, Nc, d.N, d.B, 64 * wide_wn(Nc)) * M * Nc;
+        long n1 = (long)tn_bf16_chunks(M, Nc, d.N, d.B, 64 * wide_wn(Nc)) * M * Nc;
+        const Tn2wPlan wp = tn2w_plan(M, Nc, d.N, d.B);
+        if (wp.use && tn2w_part_floats(wp, Nc) > n1) n1 = tn2w_part_floats(wp, Nc);
+        return n1;
       }
       const int rows = tn_chunk_rows(M, Nc, R, BN);
       return ((R + rows - 1) / rows) * (long)M * Nc;
@@ -1980,6 +2003,30 @@ int launch_tn2_bf16(const AOp& a, const BOp& b, int M, int Nc, int N, int Bsz, f
   OBMAN_LAUNCH_CHECK();
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out, transposed);
   OBMAN_LAUNCH_CHECK();
+  return 0;
+}
+// the wide tile: full 256-row tiles of the (transposed) product; the remainder rows' partials are in part_side [GH2S_BLOCKS][ns][Nc]
+template <class AOp, class BOp>
+int launch_tn2w_bf16(const AOp& a, const BOp& b, const Tn2wPlan& wp, int M, int Nc, int N, int Bsz, float* part, float* out, int ldo,
+                     hipStream_t st) {
+  const size_t lds = (size_t)2 * TW_KT * 2 * TW_P * sizeof(bfraw);
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if (!granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)tn2w_bf16_kernel<AOp, BOp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store(1, std::memory_order_relaxed);
+  }
+  const int Mmain = wp.mt * TW_BM;
+  tn2w_bf16_kernel<AOp, BOp><<<(unsigned)(wp.mt * wp.chunks), NTB, lds, st>>>(a, b, M, Nc, N, Bsz, wp.tiles_per_chunk, part);
+  OBMAN_LAUNCH_CHECK();
+  reduce_tn_kernel<<<obman_cdiv((long)Mmain * Nc, RTN_ELEMS), 256, 0, st>>>(part, wp.chunks, Mmain, Nc, ldo, 0, out, 1);
+  OBMAN_LAUNCH_CHECK();
+  if (wp.ns) {
+    const float* side = part + (size_t)wp.chunks * Mmain * Nc;
+    reduce_tn_kernel<<<obman_cdiv((long)wp.ns * Nc, RTN_ELEMS), 256, 0, st>>>(side, GH2S_BLOCKS, wp.ns, Nc, ldo, Mmain, out, 1);
+    OBMAN_LAUNCH_CHECK();
+  }
   return 0;
 }
 template <class AOp, class BOp>
@@ -2458,7 +2505,26 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
      // every operand is regenerated once per tile of the OTHER operand, and a1 (fp32 factors, add + fma + max per element) is the
      // expensive one - as the A operand of five 128 x 320 tiles it is generated once (640 channel columns per k-tile) and gh2 five
      // times (1 600), against 1 920 + 768 with gh2 as A on 3 x 2 tiles
-    if (gh_plain) {
+    const Tn2wPlan wp = gh_plain ? tn2w_plan(d.C1, d.C2, d.N, d.B) : Tn2wPlan{false, 0, 0, 0, 0};
+    if (gh_plain && wp.use) {
+      // round 6: gh2 materialised in place AND, in the same pass, the products of the 3 odd channels of a1 (512 .. 514) with it
+      // as VALU side sums; the 512 x 257 body of the product on two 256 x 288 tiles (decoder_tn2.h, "the WIDE tile")
+      float* part = ws2 + v.tn;
+      float* side = part + (size_t)wp.chunks * wp.mt * TW_BM * d.C2;
+      const int m0 = wp.mt * TW_BM;
+      if (wp.ns == 3)
+        gh2_inplace_side_kernel<3><<<GH2S_BLOCKS, dim3(64, 4), 0, st>>>(GY2, H2, k1, k2, k3, d.R, d.ld2, d.C2, ws + w.Gy, ws + w.Fy, d.ld1, d.N, m0, d.C2, side);
+      else if (wp.ns == 2)
+        gh2_inplace_side_kernel<2><<<GH2S_BLOCKS, dim3(64, 4), 0, st>>>(GY2, H2, k1, k2, k3, d.R, d.ld2, d.C2, ws + w.Gy, ws + w.Fy, d.ld1, d.N, m0, d.C2, side);
+      else if (wp.ns == 1)
+        gh2_inplace_side_kernel<1><<<GH2S_BLOCKS, dim3(64, 4), 0, st>>>(GY2, H2, k1, k2, k3, d.R, d.ld2, d.C2, ws + w.Gy, ws + w.Fy, d.ld1, d.N, m0, d.C2, side);
+      else
+        gh2_inplace_kernel<<<obman_cdiv(d.R, GH2_ROWS), dim3(64, 4), 0, st>>>(GY2, H2, k1, k2, k3, d.R, d.ld2, d.C2);
+      OBMAN_LAUNCH_CHECK();
+      T2Pre ta{ws + w.Gy, ws + w.Fy, d.ld1, d.N, d.B};
+      T2Plain tb{GY2, d.ld2, d.N, d.B};
+      if ((rc = launch_tn2w_bf16<T2Pre, T2Plain>(ta, tb, wp, d.C1, d.C2, d.N, d.B, part, g->w2, d.C1, st))) return rc;
+    } else if (gh_plain) {
       // gh2 materialised once (in place over gy2): both GEMMs below read it as a plain bf16 operand
       gh2_inplace_kernel<<<obman_cdiv(d.R, GH2_ROWS), dim3(64, 4), 0, st>>>(GY2, H2, k1, k2, k3, d.R, d.ld2, d.C2);
       OBMAN_LAUNCH_CHECK();

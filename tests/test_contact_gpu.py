@@ -196,7 +196,7 @@ def test_contains_adversarial_scenes_vs_oracle(seed, B, P, F):
     assert rec["kernel_vs_oracle_disagree_in_bound"] <= IN_BOUND_RATE * rec["in_error_bound"] + 2, rec
 
 
-IN_BOUND_RATE = 0.5
+IN_BOUND_RATE = 0.2  # measured 0.120 - 0.128 on the three parametrisations (profiles/r06_parity_measured.md)
 
 
 def test_grouped_inside_test_on_overlapping_patches():

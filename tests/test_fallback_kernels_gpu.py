@@ -11,6 +11,7 @@ pytest process with the variable set.  What each value selects:
   OBMAN_DEC_TN2=0      first-generation bf16 weight-gradient GEMMs (and gh2 regenerated instead of materialised)
   OBMAN_DEC_ROWS3=0    h3 on the rows2 kernel (register operand queue) instead of the LDS-DMA ring of decoder_rows3.h
   OBMAN_DEC_L4W=0      first-generation layer-4 kernels (32 / 64 lanes per row)
+  OBMAN_DEC_TN2W=0     the bf16 layer-2 weight gradient on five 128 x 320 tiles (tn2_bf16_kernel) instead of the round-6 wide tile
   OBMAN_MC_BINNED=0    the all-pairs inside-test kernel behind the product entry points
 """
 import os
@@ -28,7 +29,8 @@ _CONTACT = ["tests/test_contact_gpu.py", "-k", "contains or golden"]
 
 @pytest.mark.parametrize("knob,target", [
     ("OBMAN_DEC_ROWS2F", _DECODER), ("OBMAN_DEC_TN3", _DECODER), ("OBMAN_DEC_F2PQ", _DECODER), ("OBMAN_DEC_ROWS2", _DECODER),
-    ("OBMAN_DEC_TN2", _DECODER), ("OBMAN_DEC_ROWS3", _DECODER), ("OBMAN_DEC_L4W", _DECODER), ("OBMAN_MC_BINNED", _CONTACT)])
+    ("OBMAN_DEC_TN2", _DECODER), ("OBMAN_DEC_ROWS3", _DECODER), ("OBMAN_DEC_L4W", _DECODER), ("OBMAN_DEC_TN2W", _DECODER),
+    ("OBMAN_MC_BINNED", _CONTACT)])
 def test_fallback_generation_passes_the_parity_cases(knob, target):
     env = dict(os.environ, **{knob: "0"})
     proc = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "--timeout", "600", "-p", "no:cacheprovider"] + target,

@@ -166,8 +166,12 @@ def test_configs2_model_bs64_256_matches_cpu_oracle():
 # lands on the neighbouring bf16 number (2^-8 relative) in a few activations; the chamfer / vertex terms average that out, the
 # contact terms sit on hard thresholds (their bound is the mask Hamming distance).
 BF16_VS_ORACLE = {
-    "dec_bf16": dict(total=2e-3, soft=5e-3, points=1.6e-2, points_rms=4e-3, hamming=6e-3, verts=1e-4),
-    "all_bf16": dict(total=3e-2, soft=6e-2, points=0.16, points_rms=4e-2, hamming=6e-2, verts=5e-2),
+    # measured (r06, MI355X): total 2.9e-5, worst smooth term 4.5e-5 (atlas_objpoints3d), points max 6.4e-3 / rms 3.6e-4 of scale,
+    # masks 3.6e-4 / 4.0e-5, hand vertices 4.1e-7 - the decoder flavour meets north_star's 1e-4 on every smooth scalar
+    "dec_bf16": dict(total=1e-4, soft=1.5e-4, points=2e-2, points_rms=1.2e-3, hamming=1.2e-3, verts=1e-5),
+    # measured: total 7.9e-3, worst smooth term 3.0e-2 (atlas_objpoints3d), points max 9.1e-2 / rms 2.0e-2, masks 3.2e-2 / 1.8e-3,
+    # hand vertices 2.3e-3 (two convolution libraries in bf16, 18 layers deep)
+    "all_bf16": dict(total=2.5e-2, soft=6e-2, points=0.2, points_rms=5e-2, hamming=6e-2, verts=8e-3),
 }
 _HARD = ("penetration_loss", "attraction_loss", "contact_loss", "max_penetr", "mean_penetr", "contact_auc")
 
