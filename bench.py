@@ -59,9 +59,11 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (trainer.GraphedTrainStep): same kernels, one launch call per step; the live "
                          "per-kernel Chamfer / decoder timings are not available in this mode (no events inside a graph)")
-    ap.add_argument("--secondary-steps", type=int, default=10,
+    ap.add_argument("--secondary-steps", type=int, default=40,
                     help="timed steps of each secondary leg run after the headline (configs[2] and configs[4] in bf16, configs[1] as "
-                         "one hipGraph); 0 disables them.  Only with the default --config c2")
+                         "one hipGraph); 0 disables them.  Only with the default --config c2.  40 since round 6 (was 10 = 95 ms of "
+                         "measurement: a + 2 %% kernel change sat below the box-to-box noise of the record; the legs run in their own "
+                         "processes, 0.4 - 0.9 s each)")
     ap.add_argument("--leg", default=None, metavar="CFG:ENC:DEC:GRAPH",
                     help="internal: run ONE secondary leg (e.g. c3:bf16:bf16:0) in this process and print its JSON record as the last "
                          "line.  The headline run starts its secondary legs this way, each in its own process, so that a GPU fault, "
@@ -392,6 +394,11 @@ def chamfer_roofline(batch, n_pred, n_gt, steps, prof):
                     entry("pairmin_fwd_kernel, ground truth -> predicted (%d x %d queries against %d references each%s)"
                           % (batch, n_gt, n_pred, ", reference set split over blocks + merge" if n_pred >= 8192 else ""),
                           (20.0 * n_gt + 12.0 * n_pred) * batch, y_ms, y_n, flop / 2, "gt_to_pred")]
+    elif max(n_pred, n_gt) >= 8192 and min(n_pred, n_gt) <= 2048:
+        # round 6, csrc/pairmin.hip fused sweep: every pair evaluated ONCE (the long side as queries, the short side's minima from the
+        # same distances); algorithmic bytes of the whole forward: 12 B in per point, 8 B out (minimum, index) per point of both sides
+        launches = [entry("pairmin_fwd_kernel<10, true> (fused sweep: both directions from one evaluation of every pair, %d x %d x %d)"
+                          % (batch, n_pred, n_gt), 20.0 * (n_pred + n_gt) * batch, f_ms, f_n, flop / 2, "both")]
     else:
         launches = [entry("pairmin_fwd_kernel (both directions in one launch, %d samples)" % batch, 20.0 * (n_pred + n_gt) * batch,
                           f_ms, f_n, flop)]

@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 #include "decoder_bf16.h"
 #include "decoder_rows2.h"
 #include "decoder_rows3.h"
+#include "decoder_rows4.h"
 #include "decoder_tn2.h"
 #include "decoder_rows2f.h"
 #include "decoder_tn3.h"
@@ -2024,7 +2025,7 @@ int launch_tn2w_bf16(const AOp& a, const BOp& b, const Tn2wPlan& wp, int M, int 
   OBMAN_LAUNCH_CHECK();
   if (wp.ns) {
     const float* side = part + (size_t)wp.chunks * Mmain * Nc;
-    reduce_tn_kernel<<<obman_cdiv((long)wp.ns * Nc, RTN_ELEMS), 256, 0, st>>>(side, GH2S_BLOCKS, wp.ns, Nc, ldo, Mmain, out, 1);
+    reduce_side_kernel<<<obman_cdiv((long)wp.ns * Nc, 64), 1024, 0, st>>>(side, GH2S_BLOCKS, wp.ns, Nc, ldo, Mmain, out);
     OBMAN_LAUNCH_CHECK();
   }
   return 0;
@@ -2113,6 +2114,7 @@ size_t r2_lds_bytes(int Kp, const R2Geo& geo) {
   const size_t flush = (size_t)(R2_WAVES - 1) * (R2_NT + 1) * 32 * 2 * sizeof(double);  // the end-of-block reduction re-uses the slice
   return lds < flush ? flush : lds;
 }
+constexpr int R4_DEFAULT_MF = 0;  // the measured default (profiles/r06_kernels.md): 0 = rows2
 constexpr size_t R2_LDS_LIMIT = 160 * 1024;  // per workgroup on gfx950; wider layers than that fits take the first-generation kernels
 template <class AOp, class Epi>
 int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, hipStream_t st) {
@@ -2167,6 +2169,72 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
   rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, aop_floats);
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- round 6 experiment: h2 with one wave per SIMD and MF fragments per wave (decoder_rows4.h).  OBMAN_DEC_ROWS4 = 0 (rows2),
+// 2 or 4 (fragments per wave).
+int rows4_mf() {
+  static const int mf = [] { const char* e = getenv("OBMAN_DEC_ROWS4"); const int v = e ? atoi(e) : R4_DEFAULT_MF; return (v >= 2 && v <= 5) ? v : 0; }();
+  return mf;
+}
+R2Geo r4_geo(const Dims& d, int Nc, int mf) {
+  R2Geo g{};
+  g.R = (int)d.R; g.N = d.N; g.B = d.B; g.mode = 3;
+  g.vwaves = R4_WAVES * (mf == 5 ? 2 : mf);
+  g.nvt = (d.N + 4 * g.vwaves - 1) / (4 * g.vwaves);
+  g.nbg = (d.B + 7) / 8;
+  g.ngroups = Nc > R2_SIDE ? (Nc - R2_SIDE + R2_COLS - 1) / R2_COLS : 1;
+  { const int last = Nc - (g.ngroups - 1) * R2_COLS; g.wside = last > R2_COLS ? last - R2_COLS : 0; }
+  int target = device_cus() / g.ngroups;
+  if (target < 1) target = 1;
+  g.spb = target / g.nbg;
+  if (g.spb < 1) g.spb = 1;
+  if (g.spb > g.nvt) g.spb = g.nvt;
+  g.slots = g.spb * g.nbg;
+  g.chunk = (g.nvt + g.spb - 1) / g.spb;
+  return g;
+}
+size_t r4_lds_bytes(int Kp, const R2Geo& geo) {
+  return (size_t)(R2_COLS + geo.wside) * (Kp + 8) * sizeof(bfraw) + (size_t)R2Lds<BGridFeatPre>::floats(Kp) * sizeof(float) + (size_t)R4_WAVES * 256 * sizeof(float);
+}
+template <int MF, int DQ, int PF>
+int launch_rows4_h2_mf(const BGridFeatPre& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const EpiStoreB2& e, hipStream_t st) {
+  const size_t lds = r4_lds_bytes(Kp, geo);
+  static std::atomic<int> granted[MAX_DEVICES];
+  const int dev = current_device();
+  if ((int)lds > granted[dev].load(std::memory_order_relaxed)) {
+    const hipError_t err = hipFuncSetAttribute((const void*)rows4_h2_kernel<MF, DQ, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    granted[dev].store((int)lds, std::memory_order_relaxed);
+  }
+  const unsigned g = (unsigned)(geo.ngroups * geo.slots);
+  rows4_h2_kernel<MF, DQ, PF><<<g, R4_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, R2Lds<BGridFeatPre>::floats(Kp));
+  OBMAN_LAUNCH_CHECK();
+#ifdef OBMAN_R4_TIMING
+  {
+    (void)hipStreamSynchronize(st);
+    static int calls = 0;
+    if (++calls == 5) {
+      static unsigned long long host[1024 * R4_WAVES * 4];
+      (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(r4_dbg), sizeof(host));
+      double sum[4] = {0};
+      const int nw = (int)(g < 1024 ? g : 1024) * R4_WAVES;
+      for (int i = 0; i < nw; ++i) for (int k = 0; k < 4; ++k) sum[k] += (double)host[(size_t)i * 4 + k];
+      const double tiles = sum[3] > 0 ? sum[3] : 1;
+      fprintf(stderr, "R4DBG MF %d DQ %d PF %d waves %d tiles/wave %.1f | per tile ticks: k loop %.0f (%.1f per MFMA) epilogue %.0f | per wave total %.0f\n", MF, DQ, PF, nw,
+              tiles / nw, sum[0] / tiles, sum[0] / tiles / ((Kp >> 4) * 4.0 * MF), sum[1] / tiles, sum[2] / nw);
+    }
+  }
+#endif
+  return 0;
+}
+int launch_rows4_h2(int mf, const BGridFeatPre& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const EpiStoreB2& e, hipStream_t st) {
+  switch (mf) {
+    case 4: return launch_rows4_h2_mf<4, 2, 0>(a, Wb, Kp, Nc, geo, e, st);
+    case 3: return launch_rows4_h2_mf<3, 4, 1>(a, Wb, Kp, Nc, geo, e, st);
+    case 5: return launch_rows4_h2_mf<2, 6, 0>(a, Wb, Kp, Nc, geo, e, st);  // 2 fragments, no second LDS operand set
+    default: return launch_rows4_h2_mf<2, 6, 1>(a, Wb, Kp, Nc, geo, e, st);
+  }
 }
 
 // ---- third generation of the single-array rows GEMMs: A tile by LDS-DMA into a wave-private ring (decoder_rows3.h)
@@ -2385,11 +2453,14 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
       // rows as (8 samples x 4 vertices) per wave: a load instruction touches 4 rows of the layer-1 grid factor and 8 of the
       // feature factor instead of 32 + 1 (the fp32 factors go through the texture path 64 B per clock and CU),
       // and the feature factor's 8 rows of the block live in LDS.  Factors pre-scaled by BatchNorm-1's gamma / beta: add + max per element
-      const R2Geo g2 = r2_geo(d, d.C2, 2);
+      const int mf = rows4_mf();
+      const R2Geo g2 = (mf && r4_lds_bytes(Kp, r4_geo(d, d.C2, mf)) <= R2_LDS_LIMIT) ? r4_geo(d, d.C2, mf) : r2_geo(d, d.C2, 2);
       EpiStoreB2 e2{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
       BGridFeatPre ap{ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st, Kp))) return rc;
-      if ((rc = launch_rows2<BGridFeatPre, EpiStoreB2>(ap, wb, Kp, d.C2, g2, e2, st))) return rc;
+      if (g2.mode == 3) rc = launch_rows4_h2(mf, ap, wb, Kp, d.C2, g2, e2, st);  // one wave per SIMD, mf fragments per wave (decoder_rows4.h)
+      else rc = launch_rows2<BGridFeatPre, EpiStoreB2>(ap, wb, Kp, d.C2, g2, e2, st);
+      if (rc) return rc;
       mrows = g2.slots;
     } else {
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st))) return rc;

@@ -44,12 +44,14 @@ struct R2Geo {
   int mode;     // 0: wave = 1 sample x 32 vertices, block = 8 samples (h2, h3, gy2)
                 // 1: wave = 8 samples x 4 vertices, block = 64 samples over the SAME 4 vertices (dA: sums over samples stay in the block)
                 // 2: wave = 8 samples x 4 vertices, block = the SAME 8 samples over 32 vertices (h2: the block's 8 feature-factor rows sit in LDS)
+                // 3: as 2, but the block's tile is 4 * vwaves vertices wide (decoder_rows4.h: a wave works off several 32-row fragments)
   int nvt, nbg; // vertex tiles, sample groups
   int ngroups;  // column groups of R2_COLS
   int slots;    // persistent blocks per column group = spb * nbg
   int spb;      // slots per sample group
   int wside;    // side-column rows of the weight slice actually present (0 .. R2_SIDE): LDS rows = R2_COLS + wside
   int chunk;    // vertex tiles per slot
+  int vwaves;   // mode 3: 32-row fragments per block tile
   // row i (0..31) of the fragment of wave `wave` in block tile (bg, vt)
   __device__ __forceinline__ void row(int bg, int vt, int wave, int i, int& b, int& n, long& r, bool& ok) const {
     if (mode == 0) {
@@ -58,9 +60,12 @@ struct R2Geo {
     } else if (mode == 1) {
       b = bg * 64 + wave * 8 + (i >> 2);
       n = vt * 4 + (i & 3);
-    } else {
+    } else if (mode == 2) {
       b = bg * 8 + (i >> 2);
       n = vt * 32 + wave * 4 + (i & 3);
+    } else {
+      b = bg * 8 + (i >> 2);
+      n = (vt * vwaves + wave) * 4 + (i & 3);
     }
     ok = b < B && n < N;
     if (!ok) { b = 0; n = 0; }
@@ -367,6 +372,7 @@ struct R2Fin<BGradH3> {
 // ------------------------------------------------------------------------------------------------ epilogues
 struct R2Ctx {
   int lane, wave, c0, nside, last_group, slot, bg, vt;
+  int sw;  // which 1 KB piece of the epilogue's LDS scratch this wave uses (= wave, except where a wave works off several fragments: decoder_rows4.h)
 };
 
 __device__ __forceinline__ double r2_pick(const double (&v)[R2_SIDE], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
@@ -452,7 +458,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
     float s1[R2_NT], s2[R2_NT];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
+    unsigned* tb = reinterpret_cast<unsigned*>(red) + c.sw * 256;  // [16 rows][16 words = 32 columns]
     bool interior;
     {
       int b, n; long r; bool okl;
@@ -620,7 +626,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { p1[j] = 0.f; p2[j] = 0.f; }
     {
-      unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
+      unsigned* tb = reinterpret_cast<unsigned*>(red) + c.sw * 256;  // [16 rows][16 words = 32 columns]
       // the rows this lane moves: row 16 G + (lane >> 2) of the tile, columns 8 (lane & 3) .. + 7 of each 32-column piece
       size_t og[2];
       bool okg[2];
@@ -886,7 +892,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
 
   R2Src<AOp> src;
   src.init(aop, geo);
-  R2Ctx ctx{lane, wave, c0, nside, last_group, slot, 0, 0};
+  R2Ctx ctx{lane, wave, c0, nside, last_group, slot, 0, 0, wave};
   typename Epi::State est;
   epi.init(est, ctx);
   const int bg = slot / geo.spb, sq = slot - bg * geo.spb;

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NTB) void tn2w_bf16_kernel(AOp aop, BOp bop, int M,
 // from exactly the rounded operands the MFMA path would have consumed (products of two bf16 values are exact in fp32; fp32
 // accumulation).  A wave owns one row at a time (blockDim = (64 octet slots, 4 row slots)), so the three a1 values of a row are
 // wave-uniform: scalar loads.  grid-stride over row groups; one partial [NS][ld] per block, summed by reduce_tn_kernel.
-constexpr int GH2S_BLOCKS = 512;
+constexpr int GH2S_BLOCKS = 1024;  // 4 blocks = 16 waves per CU: the pass is HBM-bound and needs the loads in flight
 template <int NS>
 __global__ __launch_bounds__(256) void gh2_inplace_side_kernel(bfraw* __restrict__ GY, const bfraw* __restrict__ H, const float* __restrict__ ka,
                                                                const float* __restrict__ kb, const float* __restrict__ kc, long R, int ld, int K,
@@ -477,10 +477,14 @@ __global__ __launch_bounds__(256) void gh2_inplace_side_kernel(bfraw* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) side[s][e] = 0.f;
   // rows r = 4 * g + ry for the groups g = blockIdx.x, blockIdx.x + gridDim.x, ... (a block's rows interleave with the others':
-  // every block streams the whole length of the arrays, equal work)
-  for (long r = (long)blockIdx.x * 4 + ry; r < R; r += (long)gridDim.x * 4) {
-    const long bs = r / N;
-    const int n = (int)(r - bs * N);
+  // every block streams the whole length of the arrays, equal work).  (sample, vertex) of the row advance incrementally: the
+  // first version divided a 64-bit row number per row and ran at 537 us against the plain pass's 338.
+  const int stride = (int)gridDim.x * 4;
+  long r = (long)blockIdx.x * 4 + ry;
+  int bs = (int)(r / N), n = (int)(r - (long)bs * N);
+  const int sb = stride / N, sn = stride - sb * N;
+  for (; r < R; r += stride, bs += sb, n += sn) {
+    if (n >= N) { n -= N; ++bs; }
     float a1[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -519,5 +523,34 @@ __global__ __launch_bounds__(256) void gh2_inplace_side_kernel(bfraw* __restrict
         const float v = ((side[s][e] + red[0][s][e * 64 + threadIdx.x]) + red[1][s][e * 64 + threadIdx.x]) + red[2][s][e * 64 + threadIdx.x];
         if (c0 + e < Nc) part[((size_t)blockIdx.x * NS + s) * Nc + c0 + e] = v;
       }
+  }
+}
+
+// out[n * ldo + off + m] = sum over the GH2S_BLOCKS partials of side[m][n] (transposed store, as reduce_tn_kernel's): 64 elements per
+// block, 16 chunk groups of 64 lanes each summing every 16th partial with 8 loads in flight, combined in group order (fixed order:
+// run-to-run identical).  reduce_tn_kernel walks the chunks with 4 waves: fine for 100 chunks x 132 k elements, 30 us for 1 024 x 771.
+__global__ __launch_bounds__(1024) void reduce_side_kernel(const float* __restrict__ part, int chunks, int ns, int Nc, int ldo, int off,
+                                                           float* __restrict__ out) {
+  __shared__ float red[15][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int total = ns * Nc, i = blockIdx.x * 64 + e;
+  const bool ok = i < total;
+  const float* src = part + (ok ? i : 0);
+  float s = 0.f;
+  int c = g;
+  for (; c + 112 < chunks; c += 128) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(c + 16 * j) * total];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; c < chunks; c += 16) s += src[(size_t)c * total];
+  if (g) red[g - 1][e] = s;
+  __syncthreads();
+  if (g == 0 && ok) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) s += red[k][e];
+    out[(size_t)(i % Nc) * ldo + off + (i / Nc)] = s;
   }
 }

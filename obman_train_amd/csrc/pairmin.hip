@@ -42,6 +42,7 @@ struct PmDir {
   int* oidx;       // [B,nq] or null
   u64* ws;         // packed scratch when rsplit > 1
   int nq, nr, qtiles, rsplit, rchunk, tile;
+  u64* rs_ws;      // round 6 (fused sweep): [B,nr] keys (distance bits << 32 | query tile) of the REFERENCE-side minima, or null
 };
 
 // Block = 4 waves.  All 4 waves hold the SAME 64*QPT queries (lane l owns queries l, l+64, ..) and each
@@ -51,7 +52,34 @@ struct PmDir {
 // (value, then lower group start => first index), then 64*QPT lanes resolve the exact index.
 struct PmGrid { int gx, gz, B, xcd; };  // query tiles (x reference splits) per direction, directions in this launch, samples
 
-template <int QPT>
+// Wave-wide minimum, valid in lane 63: four DPP steps inside the 16-lane rows, then row_bcast15 / row_bcast31 across the rows
+// (rows outside the row mask keep their value: `old` = the value itself).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float pm_dpp_min(float v) {
+  const int vi = __builtin_bit_cast(int, v);
+  return __builtin_fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, CTRL, ROWS, 0xf, false)));
+}
+__device__ __forceinline__ float pm_wave_min_lane63(float v) {
+  v = pm_dpp_min<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = pm_dpp_min<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = pm_dpp_min<0x141, 0xf>(v);  // row_half_mirror
+  v = pm_dpp_min<0x140, 0xf>(v);  // row_mirror
+  v = pm_dpp_min<0x142, 0xa>(v);  // row_bcast15 -> rows 1, 3
+  v = pm_dpp_min<0x143, 0xc>(v);  // row_bcast31 -> rows 2, 3
+  return v;
+}
+
+// RS (round 6, VERDICT r05 task 4: "evaluate every pair once"): the sweep ALSO produces the reference-side minima from the same
+// distances.  A ChamferLoss at 16 050 x 600 used to be two independent all-pairs sweeps (predicted -> ground truth with the
+// predictions as queries, ground truth -> predicted with the roles swapped and the long reference set split over blocks): every
+// pair evaluated twice.  With RS the long side is the query side only: per chunk of 8 references a lane folds its QPT distances to
+// each reference with v_min3 (QPT / 2 instructions per reference), one DPP wave-min per reference leaves the minimum over the
+// block's 64 QPT queries in lane 63, which parks it in LDS (a reference belongs to ONE wave of the block); at the end of the block
+// the references' minima go to global memory as 64-bit atomicMin keys (distance bits << 32 | query tile): order-independent, and
+// the lowest tile among equal minima is the one that holds the first index.  pairmin_resolve_kernel then re-evaluates the winning
+// tile's queries with the same pinned instruction sequence and takes the first equal one - values, arg-mins and tie rule are bit-identical to the
+// swapped-role sweep (tests/test_pairmin_gpu.py keeps that path as the checker: OBMAN_PM_FUSED=0).
+template <int QPT, bool RS>
 __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir d1, PmGrid pg) {
   // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  All blocks
   // of one sample (every query tile, both directions: they read the same two point sets) take consecutive slots on ONE XCD,
@@ -83,6 +111,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
   float4* sref = reinterpret_cast<float4*>(pm_smem);
   float(*s_val)[64 * QPT] = reinterpret_cast<float(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4));
   int(*s_grp)[64 * QPT] = reinterpret_cast<int(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4) + 4 * 64 * QPT * sizeof(float));
+  float* s_rmin = reinterpret_cast<float*>(pm_smem + (size_t)d.tile * sizeof(float4) + 8 * 64 * QPT * sizeof(float));  // RS: [tile] reference-side minima
 
   static_assert(QPT % 2 == 0, "queries are processed as packed pairs");
   constexpr int QP = QPT / 2;
@@ -127,11 +156,20 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
       for (int u = 0; u < PM_CHUNK; ++u) r[u] = sref[j + u];
 #pragma unroll
       for (int u = 0; u < PM_CHUNK; ++u) asm volatile("" ::"v"(r[u].w));  // keep the reads ds_read_b128 (b96 is 2x the LDS cycles)
+      float rm[PM_CHUNK];
+      if constexpr (RS) {
+#pragma unroll
+        for (int u = 0; u < PM_CHUNK; ++u) rm[u] = __builtin_inff();
+      }
 #pragma unroll
       for (int p = 0; p < QP; ++p) {
         f2 e[PM_CHUNK];
 #pragma unroll
         for (int u = 0; u < PM_CHUNK; ++u) e[u] = pm_dist2_pk(qx[p], qy[p], qz[p], r[u].x, r[u].y, r[u].z);
+        if constexpr (RS) {
+#pragma unroll
+          for (int u = 0; u < PM_CHUNK; ++u) rm[u] = __builtin_fminf(__builtin_fminf(rm[u], e[u][0]), e[u][1]);  // v_min3_f32
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const float m0 = __builtin_fminf(__builtin_fminf(e[0][h], e[1][h]), e[2][h]);  // v_min3_f32
@@ -140,6 +178,13 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
           const bool better = m < best[2 * p + h];
           best[2 * p + h] = better ? m : best[2 * p + h];
           bestj[2 * p + h] = better ? base + j : bestj[2 * p + h];
+        }
+      }
+      if constexpr (RS) {
+#pragma unroll
+        for (int u = 0; u < PM_CHUNK; ++u) {
+          const float m = pm_wave_min_lane63(rm[u]);
+          if (lane == 63) s_rmin[j + u] = m;
         }
       }
     }
@@ -189,6 +234,48 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
       const u64 packed = ((u64)__float_as_uint(bv) << 32) | (unsigned)idx;
       atomicMin(&d.ws[o], packed);
     }
+  }
+  if constexpr (RS) {  // single reference tile (the launcher guarantees it): s_rmin holds the block's minimum for every reference
+    if (d.rs_ws) {
+      const int cnt = rend - rbeg;
+      for (int j = tid; j < cnt; j += PM_THREADS) {
+        float m = s_rmin[j];
+        if (!(m < __builtin_inff())) m = __builtin_inff();  // all-NaN / overflowed column: the swapped-role sweep reports (inf, first index)
+        atomicMin(&d.rs_ws[(size_t)b * d.nr + rbeg + j], ((u64)__float_as_uint(m) << 32) | (unsigned)qt);
+      }
+    }
+  }
+}
+
+// Reference-side arg-mins of the fused sweep: one wave per (sample, reference).  key = (minimum bits << 32 | query tile); the
+// queries of that tile are re-evaluated with obman_dist2 (the sweep's own rounding) 64 at a time and the first one that equals the
+// minimum wins - "first index on ties", as every other path of this file.
+__global__ __launch_bounds__(256) void pairmin_resolve_kernel(const u64* __restrict__ keys, const float* __restrict__ q, const float* __restrict__ r,
+                                                              int B, int nq, int nr, int qtile, float* __restrict__ omin, int* __restrict__ oidx) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= (long)B * nr) return;
+  const int b = (int)(w / nr);
+  const u64 key = keys[w];
+  const float val = __uint_as_float((unsigned)(key >> 32));
+  int idx = 0;
+  if (val < __builtin_inff()) {
+    const int t0 = (int)(unsigned)(key & 0xffffffffu) * qtile, t1 = min(nq, t0 + qtile);
+    const float* rp = r + (size_t)w * 3;
+    const float rx = rp[0], ry = rp[1], rz = rp[2];
+    const float* qb = q + (size_t)b * nq * 3;
+    idx = t0;
+    for (int i0 = t0; i0 < t1; i0 += 64) {
+      const int i = i0 + lane;
+      bool hit = false;
+      if (i < t1) hit = obman_dist2(qb[(size_t)i * 3], qb[(size_t)i * 3 + 1], qb[(size_t)i * 3 + 2], rx, ry, rz) == val;
+      const unsigned long long m = __ballot(hit);
+      if (m) { idx = i0 + __builtin_ctzll(m); break; }
+    }
+  }
+  if (lane == 0) {
+    omin[w] = val;
+    if (oidx) oidx[w] = idx;
   }
 }
 
@@ -611,12 +698,12 @@ int choose_qpt(int B, int nq, int nr) {
   return 2;
 }
 
-template <int QPT>
+template <int QPT, bool RS = false>
 void launch_fwd_t(dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b) {
   static const int xcd = [] { const char* e = getenv("OBMAN_PM_XCD"); return e ? atoi(e) : 1; }();  // A/B knob
   const PmGrid pg{(int)grid.x, (int)grid.z, (int)grid.y, xcd};
   const unsigned blocks = (unsigned)(((pg.B + 7) / 8) * 8) * grid.x * grid.z;  // samples padded to a multiple of 8 (one group per XCD slot)
-  pairmin_fwd_kernel<QPT><<<dim3(blocks), PM_THREADS, smem, st>>>(a, b, pg);
+  pairmin_fwd_kernel<QPT, RS><<<dim3(blocks), PM_THREADS, smem, st>>>(a, b, pg);
 }
 void launch_fwd(int qpt, dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b, int kid) {
   ObmanProfScope prof(kid, st);
@@ -726,8 +813,36 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
       return rc;
     }
   }
-  PmDir d0{x, y, min_x, idx_x, nullptr, Nx, Ny, 0, 1, Ny, PM_REF_TILE};
-  PmDir d1{y, x, min_y, idx_y, nullptr, Ny, Nx, 0, 1, Nx, PM_REF_TILE};
+  PmDir d0{x, y, min_x, idx_x, nullptr, Nx, Ny, 0, 1, Ny, PM_REF_TILE, nullptr};
+  PmDir d1{y, x, min_y, idx_y, nullptr, Ny, Nx, 0, 1, Nx, PM_REF_TILE, nullptr};
+  {
+    // Round 6, the fused sweep: both directions wanted, one side long (>= 8192 points: where the swapped-role direction needs the
+    // split path) and the other a single LDS tile.  The long side is the query side (10 per lane); the short side's minima come out
+    // of the same distances (pairmin_fwd_kernel<10, true>) and pairmin_resolve_kernel finds their arg-mins.  OBMAN_PM_FUSED=0: the
+    // two independent sweeps (the checker).
+    static const int fused_on = [] { const char* e = getenv("OBMAN_PM_FUSED"); return e ? atoi(e) : 1; }();
+    const bool x_long = Nx >= Ny;
+    const int nl = x_long ? Nx : Ny, ns = x_long ? Ny : Nx;
+    const long need = (long)sizeof(u64) * B * ns;
+    if (fused_on && min_x && min_y && nl >= 8192 && ns <= PM_REF_TILE && ws && ws_bytes >= need) {
+      PmDir d = x_long ? d0 : d1;
+      d.qtiles = obman_cdiv(d.nq, 640);
+      d.tile = ((ns + 31) / 32) * 32;
+      d.rs_ws = (u64*)ws;
+      (void)obman_fill_u32(ws, 0xffffffffu, (size_t)2 * B * ns, st);
+      const size_t smem = (size_t)d.tile * sizeof(float4) + (size_t)8 * 64 * 10 * sizeof(float) + (size_t)d.tile * sizeof(float);
+      {
+        ObmanProfScope prof(kid, st);
+        launch_fwd_t<10, true>(dim3(d.qtiles, B, 1), smem, st, d, d);
+      }
+      OBMAN_LAUNCH_CHECK();
+      const long nw = (long)B * ns;
+      pairmin_resolve_kernel<<<obman_cdiv(nw, 4), 256, 0, st>>>((const u64*)ws, d.q, d.r, B, d.nq, d.nr, 640, x_long ? min_y : min_x,
+                                                                 x_long ? idx_y : idx_x);
+      OBMAN_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   int q0 = choose_qpt(B, Nx, Ny), q1 = choose_qpt(B, Ny, Nx);
   // no split path involved: one launch for both directions beats two (2562 x 600, bs 64: 53 us merged at QPT 2, 61 us as
   // two launches at QPT 4 / 2, 69 us merged at QPT 4)

@@ -64,7 +64,6 @@ class GradientBuckets:
         self._next = 0         # next bucket to all-reduce (index order)
         self.capturing = False  # inside a stream capture: nothing that needs the host may run (no gradient-less parameters)
         self.last_missing = 0
-        self.last_works = []   # the Work handles of the step just finished (trainer.wait_for_watchdog polls them before a capture)
         if not self.enabled:
             return
         self.backend = dist.get_backend(group)
@@ -242,7 +241,6 @@ class GradientBuckets:
                 if float(had[self._flag_of[p]]) == 0.0:
                     p.grad = None
         self.last_missing = len(self._missing)  # parameters that had no local gradient in the step just finished
-        self.last_works = [] if self.capturing else [w for _, w in self._works]
         self._works = []
         self._seen = set()
         self._missing = []
@@ -276,6 +274,10 @@ def init_rccl(device, rank=None, world_size=None):
     import os
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by this driver for RCCL across processes
+    # the flight recorder's status record is how trainer.wait_for_watchdog SEES the watchdog thread drop finished eager work before
+    # a step with RCCL collectives is recorded into a hipGraph (a 64-entry ring; one record per collective, no stack traces)
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "64")
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "64")
     opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
     kw = {}
     if rank is not None:

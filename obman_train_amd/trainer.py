@@ -75,7 +75,7 @@ def _watchdog_period_s():
     return 0.1
 
 
-def wait_for_watchdog(buckets, dev, timeout_s=10.0):
+def wait_for_watchdog(buckets, dev, timeout_s=5.0):
     """Before a capture that will hold RCCL work: wait until the process group's watchdog thread has DROPPED every eager collective.
 
     ProcessGroupNCCL's watchdog polls the end events of the outstanding EAGER collectives (``hipEventQuery``) until it has seen
@@ -83,46 +83,35 @@ def wait_for_watchdog(buckets, dev, timeout_s=10.0):
     query - on an event last recorded on that stream, eagerly, by the warm-up steps - with ``hipErrorCapturedEvent``; the watchdog
     rethrows and the process aborts (measured in round 5: 1 of 8 runs of the 1-rank bench command, always inside the capture window).
 
-    Round 6: a CONDITION instead of round 5's fixed ``sleep(0.5)``.  The warm-up's last ``Work`` handles are kept by
-    ``GradientBuckets.finish()`` (``last_works``); ``ProcessGroupNCCL._verify_work_timeout(work, t)`` walks the watchdog's own list
-    under its mutex and raises once ``work`` is no longer in it - which is exactly "the watchdog will never query this work's
-    events again".  The list is in launch order and the watchdog drops entries front to back, so the wait ends when the LAST work of
-    the warm-up is gone.  Returns a dict saying which condition ended the wait (bench.py prints it).  Where the probe is not
-    usable (another torch build: the method absent or not raising for a finished work within ``timeout_s``) the fallback is the
-    measured one: five poll periods of sleep after the synchronize."""
-    import datetime
+    Round 6: a CONDITION instead of round 5's fixed ``sleep(0.5)``.  The watchdog publishes its progress in the process group's
+    status record, ``pg_status[pg]["last_completed_collective"]`` of the flight recorder's dump
+    (``torch._C._distributed_c10d._dump_nccl_trace``): the sequence number of the last collective it has seen complete AND dropped
+    from its list.  When that has reached ``last_enqueued_collective`` for every group, no eager work is left for it to query.  The
+    record exists when the flight recorder is on (``TORCH_NCCL_TRACE_BUFFER_SIZE`` > 0: ``dp.init_rccl`` sets 64 entries; measured:
+    the condition turns true 60 ms after the synchronize, ``tools/r06/watchdog_probe.py``).  Where it does not (another torch
+    build, the recorder switched off by the caller) the fallback is round 5's measured one: five watchdog poll periods of sleep.
+    Returns a dict saying which of the two ended the wait (``bench.py`` prints it)."""
+    import pickle
     import time
-
-    import torch.distributed as dist
 
     torch.cuda.synchronize(dev)  # every eager collective has finished on the device: one watchdog pass drops them all
     t0 = time.perf_counter()
-    works = list(getattr(buckets, "last_works", None) or [])
-    backend = None
-    try:
-        group = buckets.group if buckets.group is not None else dist.distributed_c10d._get_default_group()
-        backend = group._get_backend(torch.device(dev))
-    except Exception:  # noqa: BLE001 - any failure = no probe
-        backend = None
-    probe = getattr(backend, "_verify_work_timeout", None)
-    if works and probe is not None:
-        td = datetime.timedelta(milliseconds=1)
-        pending = works
-        while pending and time.perf_counter() - t0 < timeout_s:
-            still = []
-            for w in pending:
-                try:
-                    probe(w, td)
-                    still.append(w)  # found in the watchdog's list: not reaped yet
-                except Exception:  # noqa: BLE001 - DistBackendError: not in the list any more
-                    pass
-            pending = still
-            if pending:
-                time.sleep(_watchdog_period_s() / 4)
-        if not pending:
-            return {"condition": "watchdog list empty", "works": len(works), "waited_s": round(time.perf_counter() - t0, 4)}
+    dump = getattr(torch._C._distributed_c10d, "_dump_nccl_trace", None)
+    polls = 0
+    while dump is not None and time.perf_counter() - t0 < timeout_s:
+        try:
+            status = pickle.loads(dump(includeCollectives=False, includeStackTraces=False, onlyActive=False)).get("pg_status") or {}
+        except Exception:  # noqa: BLE001 - no recorder in this build
+            status = {}
+        if not status:
+            break
+        polls += 1
+        if all(int(s.get("last_completed_collective", -1)) >= int(s.get("last_enqueued_collective", 0)) for s in status.values()):
+            return {"condition": "watchdog reached last_enqueued_collective", "groups": len(status), "polls": polls,
+                    "waited_s": round(time.perf_counter() - t0, 4)}
+        time.sleep(_watchdog_period_s() / 4)
     time.sleep(5 * _watchdog_period_s())
-    return {"condition": "slept 5 watchdog periods (no probe)", "works": len(works), "waited_s": round(time.perf_counter() - t0, 4)}
+    return {"condition": "slept 5 watchdog periods (no flight-recorder status)", "polls": polls, "waited_s": round(time.perf_counter() - t0, 4)}
 
 
 class GraphedTrainStep:

@@ -8,6 +8,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29517")
+if os.environ.get("PROBE_FR"):  # flight recorder on: its entries carry what the watchdog has seen
+    os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = os.environ["PROBE_FR"]
+    os.environ["TORCH_FR_BUFFER_SIZE"] = os.environ["PROBE_FR"]
 import torch
 import torch.distributed as dist
 
@@ -35,6 +38,7 @@ def status():
         if ent:
             out["states"] = [e.get("state") for e in ent][-8:]
             out["discovered"] = [e.get("time_discovered_completed_ns") is not None for e in ent][-8:]
+            out["entry_keys"] = sorted(ent[-1].keys())
     except Exception as e:  # noqa: BLE001
         out["error"] = repr(e)[:200]
     return out
@@ -47,6 +51,6 @@ print("sync %.4f s" % (time.perf_counter() - t0), "is_completed:", [w.is_complet
 print("seq:", be._get_sequence_number_for_group())
 for i in range(30):
     s = status()
-    print("t=%.3f" % (time.perf_counter() - t0), s.get("pg_status"), s.get("states"), s.get("discovered"), s.get("error"))
+    print("t=%.3f" % (time.perf_counter() - t0), s.get("pg_status"), s.get("states"), s.get("discovered"), s.get("error"), s.get("entry_keys") if i == 0 else "")
     time.sleep(0.02)
 dist.destroy_process_group()
