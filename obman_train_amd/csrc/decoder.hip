@@ -768,7 +768,6 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 #include "decoder_bf16.h"
 #include "decoder_rows2.h"
 #include "decoder_rows3.h"
-#include "decoder_rows4.h"
 #include "decoder_tn2.h"
 #include "decoder_rows2f.h"
 #include "decoder_tn3.h"
@@ -1957,37 +1956,12 @@ int launch_rows_bf16(const AOp& a, const bfraw* Wb, int K, int Nc, const RowGeo&
   return wide_wn(Nc) == 5 ? launch_rows_bf16_wn<AOp, Epi, 5>(a, Wb, K, Nc, geo, e, st)
                           : launch_rows_bf16_wn<AOp, Epi, 2>(a, Wb, K, Nc, geo, e, st);
 }
+// weight-gradient GEMMs (decoder_tn2.h): operands through 16-byte loads and transposing LDS reads; WN = 5 (320-column block tiles) for
+// outputs wider than 128 columns, 2 below
 template <class AOp, class BOp, int WN>
-int launch_tn_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
-                      hipStream_t st, int transposed) {
-  const size_t lds = (size_t)2 * (BM + 64 * WN) * LPT * sizeof(bfraw);
-  static std::atomic<int> granted[MAX_DEVICES];
-  const int dev = current_device();
-  if (!granted[dev].load(std::memory_order_relaxed)) {
-    const hipError_t err = hipFuncSetAttribute((const void*)tn_bf16_kernel<AOp, BOp, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) return (int)err;
-    granted[dev].store(1, std::memory_order_relaxed);
-  }
-  const int chunks = tn_bf16_chunks(M, Nc, N, Bsz, 64 * WN);
-  const long ntiles = (long)((Bsz + 7) / 8) * ((N + 7) / 8);  // k-tiles of (8 samples) x (8 vertices)
-  const int tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
-  const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((Nc + 64 * WN - 1) / (64 * WN))) * (unsigned)chunks;
-  tn_bf16_kernel<AOp, BOp, WN><<<grid, NTB, lds, st>>>(a, b, M, Nc, R, N, Bsz, tiles_per_chunk, part);
-  OBMAN_LAUNCH_CHECK();
-  reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out, transposed);
-  OBMAN_LAUNCH_CHECK();
-  return 0;
-}
-bool tn2_enabled() {
-  static const int on = [] { const char* e = getenv("OBMAN_DEC_TN2"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = first-generation weight-gradient GEMM
-  return on != 0;
-}
-// second generation (decoder_tn2.h): same tiles, chunks, partials and reduction, operands through 16-byte loads and transposing LDS reads
-template <class AOp, class BOp>
-int launch_tn2_bf16(const AOp& a, const BOp& b, int M, int Nc, int N, int Bsz, float* part, float* out, int ldo, int off, hipStream_t st,
-                    int transposed) {
-  constexpr int WN = 5;
-  constexpr int PA = BM + 32, PB = 64 * WN + 96;
+int launch_tn2_bf16_wn(const AOp& a, const BOp& b, int M, int Nc, int N, int Bsz, float* part, float* out, int ldo, int off, hipStream_t st,
+                       int transposed) {
+  constexpr int PA = BM + 32, PB = 64 * WN + (64 * WN % 128 == 0 ? 32 : 96);
   const size_t lds = (size_t)2 * T2_KT * (PA + PB) * sizeof(bfraw);
   static std::atomic<int> granted[MAX_DEVICES];
   const int dev = current_device();
@@ -2005,6 +1979,12 @@ int launch_tn2_bf16(const AOp& a, const BOp& b, int M, int Nc, int N, int Bsz, f
   reduce_tn_kernel<<<obman_cdiv((long)M * Nc, RTN_ELEMS), 256, 0, st>>>(part, chunks, M, Nc, ldo, off, out, transposed);
   OBMAN_LAUNCH_CHECK();
   return 0;
+}
+template <class AOp, class BOp>
+int launch_tn2_bf16(const AOp& a, const BOp& b, int M, int Nc, int N, int Bsz, float* part, float* out, int ldo, int off, hipStream_t st,
+                    int transposed) {
+  return wide_wn(Nc) == 5 ? launch_tn2_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, N, Bsz, part, out, ldo, off, st, transposed)
+                          : launch_tn2_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, N, Bsz, part, out, ldo, off, st, transposed);
 }
 // the wide tile: full 256-row tiles of the (transposed) product; the remainder rows' partials are in part_side [GH2S_BLOCKS][ns][Nc]
 template <class AOp, class BOp>
@@ -2029,12 +2009,6 @@ int launch_tn2w_bf16(const AOp& a, const BOp& b, const Tn2wPlan& wp, int M, int 
     OBMAN_LAUNCH_CHECK();
   }
   return 0;
-}
-template <class AOp, class BOp>
-int launch_tn_bf16(const AOp& a, const BOp& b, int M, int Nc, long R, int N, int Bsz, float* part, float* out, int ldo, int off,
-                   hipStream_t st, int transposed = 0) {
-  return wide_wn(Nc) == 5 ? launch_tn_bf16_wn<AOp, BOp, 5>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st, transposed)
-                          : launch_tn_bf16_wn<AOp, BOp, 2>(a, b, M, Nc, R, N, Bsz, part, out, ldo, off, st, transposed);
 }
 // -> pointer / row count the finalize kernels should read: the partials themselves, or their 64-segment pre-reduction
 template <class T>
@@ -2114,7 +2088,6 @@ size_t r2_lds_bytes(int Kp, const R2Geo& geo) {
   const size_t flush = (size_t)(R2_WAVES - 1) * (R2_NT + 1) * 32 * 2 * sizeof(double);  // the end-of-block reduction re-uses the slice
   return lds < flush ? flush : lds;
 }
-constexpr int R4_DEFAULT_MF = 0;  // the measured default (profiles/r06_kernels.md): 0 = rows2
 constexpr size_t R2_LDS_LIMIT = 160 * 1024;  // per workgroup on gfx950; wider layers than that fits take the first-generation kernels
 template <class AOp, class Epi>
 int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const Epi& e, hipStream_t st) {
@@ -2129,7 +2102,7 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
   }
 #ifdef OBMAN_ABLATION  // tools/ablate_gemm.sh build: the product library holds no measurement-only kernel
   if constexpr (std::is_same<AOp, BGridFeatPre>::value || std::is_same<AOp, BPlain>::value) {
-    // measurement-only ablations of the k loop (wrong results; tools/r03_abl.sh): where does a k-step's time go?
+    // measurement-only ablations of the k loop (wrong results; tools/archive/r03/r03_abl.sh): where does a k-step's time go?
     static const int abl = [] { const char* v = getenv("OBMAN_R2_ABL"); return v ? atoi(v) : 0; }();
     if (abl) {
       const unsigned g = (unsigned)(geo.ngroups * geo.slots);
@@ -2169,72 +2142,6 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
   rows2_bf16_kernel<AOp, Epi><<<(unsigned)(geo.ngroups * geo.slots), R2_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, aop_floats);
   OBMAN_LAUNCH_CHECK();
   return 0;
-}
-
-// ---- round 6 experiment: h2 with one wave per SIMD and MF fragments per wave (decoder_rows4.h).  OBMAN_DEC_ROWS4 = 0 (rows2),
-// 2 or 4 (fragments per wave).
-int rows4_mf() {
-  static const int mf = [] { const char* e = getenv("OBMAN_DEC_ROWS4"); const int v = e ? atoi(e) : R4_DEFAULT_MF; return (v >= 2 && v <= 5) ? v : 0; }();
-  return mf;
-}
-R2Geo r4_geo(const Dims& d, int Nc, int mf) {
-  R2Geo g{};
-  g.R = (int)d.R; g.N = d.N; g.B = d.B; g.mode = 3;
-  g.vwaves = R4_WAVES * (mf == 5 ? 2 : mf);
-  g.nvt = (d.N + 4 * g.vwaves - 1) / (4 * g.vwaves);
-  g.nbg = (d.B + 7) / 8;
-  g.ngroups = Nc > R2_SIDE ? (Nc - R2_SIDE + R2_COLS - 1) / R2_COLS : 1;
-  { const int last = Nc - (g.ngroups - 1) * R2_COLS; g.wside = last > R2_COLS ? last - R2_COLS : 0; }
-  int target = device_cus() / g.ngroups;
-  if (target < 1) target = 1;
-  g.spb = target / g.nbg;
-  if (g.spb < 1) g.spb = 1;
-  if (g.spb > g.nvt) g.spb = g.nvt;
-  g.slots = g.spb * g.nbg;
-  g.chunk = (g.nvt + g.spb - 1) / g.spb;
-  return g;
-}
-size_t r4_lds_bytes(int Kp, const R2Geo& geo) {
-  return (size_t)(R2_COLS + geo.wside) * (Kp + 8) * sizeof(bfraw) + (size_t)R2Lds<BGridFeatPre>::floats(Kp) * sizeof(float) + (size_t)R4_WAVES * 256 * sizeof(float);
-}
-template <int MF, int DQ, int PF>
-int launch_rows4_h2_mf(const BGridFeatPre& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const EpiStoreB2& e, hipStream_t st) {
-  const size_t lds = r4_lds_bytes(Kp, geo);
-  static std::atomic<int> granted[MAX_DEVICES];
-  const int dev = current_device();
-  if ((int)lds > granted[dev].load(std::memory_order_relaxed)) {
-    const hipError_t err = hipFuncSetAttribute((const void*)rows4_h2_kernel<MF, DQ, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) return (int)err;
-    granted[dev].store((int)lds, std::memory_order_relaxed);
-  }
-  const unsigned g = (unsigned)(geo.ngroups * geo.slots);
-  rows4_h2_kernel<MF, DQ, PF><<<g, R4_THREADS, lds, st>>>(a, Wb, Kp, Nc, e, geo, R2Lds<BGridFeatPre>::floats(Kp));
-  OBMAN_LAUNCH_CHECK();
-#ifdef OBMAN_R4_TIMING
-  {
-    (void)hipStreamSynchronize(st);
-    static int calls = 0;
-    if (++calls == 5) {
-      static unsigned long long host[1024 * R4_WAVES * 4];
-      (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(r4_dbg), sizeof(host));
-      double sum[4] = {0};
-      const int nw = (int)(g < 1024 ? g : 1024) * R4_WAVES;
-      for (int i = 0; i < nw; ++i) for (int k = 0; k < 4; ++k) sum[k] += (double)host[(size_t)i * 4 + k];
-      const double tiles = sum[3] > 0 ? sum[3] : 1;
-      fprintf(stderr, "R4DBG MF %d DQ %d PF %d waves %d tiles/wave %.1f | per tile ticks: k loop %.0f (%.1f per MFMA) epilogue %.0f | per wave total %.0f\n", MF, DQ, PF, nw,
-              tiles / nw, sum[0] / tiles, sum[0] / tiles / ((Kp >> 4) * 4.0 * MF), sum[1] / tiles, sum[2] / nw);
-    }
-  }
-#endif
-  return 0;
-}
-int launch_rows4_h2(int mf, const BGridFeatPre& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo, const EpiStoreB2& e, hipStream_t st) {
-  switch (mf) {
-    case 4: return launch_rows4_h2_mf<4, 2, 0>(a, Wb, Kp, Nc, geo, e, st);
-    case 3: return launch_rows4_h2_mf<3, 4, 1>(a, Wb, Kp, Nc, geo, e, st);
-    case 5: return launch_rows4_h2_mf<2, 6, 0>(a, Wb, Kp, Nc, geo, e, st);  // 2 fragments, no second LDS operand set
-    default: return launch_rows4_h2_mf<2, 6, 1>(a, Wb, Kp, Nc, geo, e, st);
-  }
 }
 
 // ---- third generation of the single-array rows GEMMs: A tile by LDS-DMA into a wave-private ring (decoder_rows3.h)
@@ -2453,14 +2360,17 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
       // rows as (8 samples x 4 vertices) per wave: a load instruction touches 4 rows of the layer-1 grid factor and 8 of the
       // feature factor instead of 32 + 1 (the fp32 factors go through the texture path 64 B per clock and CU),
       // and the feature factor's 8 rows of the block live in LDS.  Factors pre-scaled by BatchNorm-1's gamma / beta: add + max per element
-      const int mf = rows4_mf();
-      const R2Geo g2 = (mf && r4_lds_bytes(Kp, r4_geo(d, d.C2, mf)) <= R2_LDS_LIMIT) ? r4_geo(d, d.C2, mf) : r2_geo(d, d.C2, 2);
+      // (Round 6, measured and dropped - VERDICT r05 task 1a: ONE wave per SIMD with 2 - 4 fragments per wave (256-thread blocks, up
+      // to 512 registers, weight fragments / feature-factor vectors shared by the fragments: 4.25 - 3.9 instead of 5 instructions per
+      // MFMA in the k loop).  Parity-green; 643 - 767 us against this kernel's 523: with nobody on the SIMD to hide them the k loop's
+      // LDS round trips and operand waits run it at 96 - 106 cycles per MFMA (s_memtime; 32 is the pipe's rate) and the epilogue
+      // (27 % of a tile) runs beside an idle matrix pipe; 3 and 4 fragments also spill (82 - 129 registers).  The kernel is
+      // decoder_rows4.h of commit 12fc77d; numbers in profiles/r06_kernels.md section 2.)
+      const R2Geo g2 = r2_geo(d, d.C2, 2);
       EpiStoreB2 e2{H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
       BGridFeatPre ap{ws + w.Gy, ws + w.Fy, d.ld1, d.C1};
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st, Kp))) return rc;
-      if (g2.mode == 3) rc = launch_rows4_h2(mf, ap, wb, Kp, d.C2, g2, e2, st);  // one wave per SIMD, mf fragments per wave (decoder_rows4.h)
-      else rc = launch_rows2<BGridFeatPre, EpiStoreB2>(ap, wb, Kp, d.C2, g2, e2, st);
-      if (rc) return rc;
+      if ((rc = launch_rows2<BGridFeatPre, EpiStoreB2>(ap, wb, Kp, d.C2, g2, e2, st))) return rc;
       mrows = g2.slots;
     } else {
       if ((rc = launch_wcast(p->w2, d.C1, d.C2, d.C1, 0, wb, st))) return rc;
@@ -2538,14 +2448,10 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C3, 4), 256, 0, st>>>(sp, srows, d.R, d.C3, tr, p->bn_w[2], ws + w.mean3, ws + w.rstd3, g->bn_w[2], g->bn_b[2],
                                                                  g->b3, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
-  if (tn2_enabled() && wide_wn(d.C2) == 5 && (d.ld3 & 7) == 0 && (d.ld2 & 7) == 0) {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
+  {  // gW3[o,c] = sum_r gh3[r,o] a2[r,c]
     T2GradH3 ta{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3, d.N, d.B};
     T2BnRelu tb{H2, ws + w.s2, ws + w.t2, d.ld2, d.C2, d.N, d.B};
     if ((rc = launch_tn2_bf16<T2GradH3, T2BnRelu>(ta, tb, d.C3, d.C2, d.N, d.B, ws2 + v.tn, g->w3, d.C2, 0, st, 0))) return rc;
-  } else {
-    TGradH3 ta{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
-    TBnRelu tb{H2, ws + w.s2, ws + w.t2, d.ld2, d.C2};
-    if ((rc = launch_tn_bf16<TGradH3, TBnRelu>(ta, tb, d.C3, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w3, d.C2, 0, st))) return rc;
   }
   {  // gy2 = (gh3 W3) * (y2 > 0) stored bf16, BN-2 sums.  B[k = out channel][n = in channel] = W3[k][n]: the transposed image
     BGradH3 a{g_out, p->w4, H3, ws + w.s3, ws + w.t3, k1, k2, k3, f, d.ld3, d.C3};
@@ -2569,7 +2475,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
   bn_bwd_finalize_kernel<<<obman_cdiv(d.C2, 4), 256, 0, st>>>(sp, srows, d.R, d.C2, tr, p->bn_w[1], ws + w.mean2, ws + w.rstd2, g->bn_w[1], g->bn_b[1],
                                                                  g->b2, k1, k2, k3);
   OBMAN_LAUNCH_CHECK();
-  const bool gh_plain = tn2_enabled() && wide_wn(d.C2) == 5 && rows2_enabled() && (d.ld2 & 7) == 0 && d.ld2 <= 512 &&
+  const bool gh_plain = rows2_enabled() && (d.ld2 & 7) == 0 && d.ld2 <= 512 &&
                         (size_t)d.R * d.ld2 * sizeof(bfraw) <= R2_PLAIN_MAX_BYTES &&
                         r2_lds_bytes<BPlain, EpiL1B2>(kpad16(d.C2), r2_geo(d, d.C1, 1)) <= R2_LDS_LIMIT;
   {  // gW2[o,c] = sum_r gh2[r,o] a1[r,c], formed TRANSPOSED (M = the 515 channels of a1, one 320-wide tile for the 257 of gh2):
@@ -2602,14 +2508,10 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
       T2Pre ta{ws + w.Gy, ws + w.Fy, d.ld1, d.N, d.B};
       T2Plain tb{GY2, d.ld2, d.N, d.B};
       if ((rc = launch_tn2_bf16<T2Pre, T2Plain>(ta, tb, d.C1, d.C2, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
-    } else if (tn2_enabled() && wide_wn(d.C2) == 5) {
+    } else {
       T2Pre ta{ws + w.Gy, ws + w.Fy, d.ld1, d.N, d.B};
       T2GradH tb{GY2, H2, k1, k2, k3, d.ld2, d.C2, d.N, d.B};
       if ((rc = launch_tn2_bf16<T2Pre, T2GradH>(ta, tb, d.C1, d.C2, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
-    } else {
-      TGridFeat ta{ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.ld1, d.C1};
-      TGradH tb{GY2, H2, k1, k2, k3, d.ld2, d.C2};
-      if ((rc = launch_tn_bf16<TGridFeat, TGradH>(ta, tb, d.C1, d.C2, d.R, d.N, d.B, ws2 + v.tn, g->w2, d.C1, 0, st, 1))) return rc;
     }
   }
   const L1Geo lg = l1_geo(d);

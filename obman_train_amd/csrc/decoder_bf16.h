@@ -543,250 +543,6 @@ __global__ __launch_bounds__(NTB) void rows_bf16_kernel(AOp aop, const bfraw* __
   epi.template finish<WN>(acc, ctx, geo, smem);
 }
 
-// ------------------------------------------------------------------------------------------------ weight gradients
-// C[M x Nc] = sum_r A[r,m] B[r,n] over a chunk of rows; the contraction index is the row, so a lane's MFMA fragment is 8
-// consecutive ROWS of one channel.  A task = (a pair of adjacent channels) x (8 consecutive rows): 4-byte loads of bf16 pairs
-// (8-byte for fp32 sources), coalesced along the channels; the task packs row pairs and writes two 16-byte pieces of the
-// [channel][row] LDS tile.  A: 64 pairs x 8 row groups = one task per thread; B: 32*WN pairs x 8 groups.
-struct TRows {  // the 8 rows of a task: global rows r0 .. r0+7 = vertices n .. n+7 of sample b (never across samples), nvalid of them real
-  long r0;
-  int nvalid, b, n;
-};
-struct TBnRelu {  // relu(s*H+t), H bf16
-  const bfraw* H;
-  const float *s, *t;
-  int ld, K;
-  struct KC { float s0, s1, t0, t1; };
-  struct Raw { unsigned h[8]; };
-  __device__ KC kc(int c) const { const bool a = c < K, b = c + 1 < K; return KC{a ? s[c] : 0.f, b ? s[c + 1] : 0.f, a ? t[c] : 0.f, b ? t[c + 1] : 0.f}; }
-  __device__ void load(Raw& q, const TRows& w, int c, int) const {
-    const int cc = c < ld ? c : 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q.h[i] = *reinterpret_cast<const unsigned*>(H + (size_t)(w.r0 + (i < w.nvalid ? i : 0)) * ld + cc);
-  }
-  __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      o0[i] = fmaxf(__fmaf_rn(k.s0, bf_lo(q.h[i]), k.t0), 0.f);
-      o1[i] = fmaxf(__fmaf_rn(k.s1, bf_hi(q.h[i]), k.t1), 0.f);
-    }
-  }
-};
-struct TGradH {  // ka*gy + kb*h + kc, gy and h bf16
-  const bfraw *GY, *H;
-  const float *ka, *kb, *kc_;
-  int ld, K;
-  struct KC { float a0, a1, b0, b1, c0, c1; };
-  struct Raw { unsigned gy[8], h[8]; };
-  __device__ KC kc(int c) const {
-    const bool a = c < K, b = c + 1 < K;
-    return KC{a ? ka[c] : 0.f, b ? ka[c + 1] : 0.f, a ? kb[c] : 0.f, b ? kb[c + 1] : 0.f, a ? kc_[c] : 0.f, b ? kc_[c + 1] : 0.f};
-  }
-  __device__ void load(Raw& q, const TRows& w, int c, int) const {
-    const int cc = c < ld ? c : 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const size_t o = (size_t)(w.r0 + (i < w.nvalid ? i : 0)) * ld + cc;
-      q.gy[i] = *reinterpret_cast<const unsigned*>(GY + o);
-      q.h[i] = *reinterpret_cast<const unsigned*>(H + o);
-    }
-  }
-  __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      o0[i] = __fmaf_rn(k.a0, bf_lo(q.gy[i]), __fmaf_rn(k.b0, bf_lo(q.h[i]), k.c0));
-      o1[i] = __fmaf_rn(k.a1, bf_hi(q.gy[i]), __fmaf_rn(k.b1, bf_hi(q.h[i]), k.c1));
-    }
-  }
-};
-struct TGradH3 {  // gh3 regenerated from the 3-channel output gradient (see BGradH3)
-  const float *G, *W4;
-  const bfraw* H;
-  const float *s, *t, *ka, *kb, *kc_;
-  float f;
-  int ld, K;
-  struct KC { float s[2], t[2], a[2], b[2], c[2], w0[2], w1[2], w2[2]; };
-  struct Raw { unsigned h[8]; float g[8][3]; };
-  __device__ KC kc(int c) const {
-    KC k;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const bool ok = c + e < K;
-      const int cc = ok ? c + e : 0;
-      k.s[e] = ok ? s[cc] : 0.f; k.t[e] = ok ? t[cc] : 0.f; k.a[e] = ok ? ka[cc] : 0.f; k.b[e] = ok ? kb[cc] : 0.f; k.c[e] = ok ? kc_[cc] : 0.f;
-      k.w0[e] = ok ? W4[cc] : 0.f; k.w1[e] = ok ? W4[K + cc] : 0.f; k.w2[e] = ok ? W4[2 * K + cc] : 0.f;
-    }
-    return k;
-  }
-  __device__ void load(Raw& q, const TRows& w, int c, int) const {
-    const int cc = c < ld ? c : 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long r = w.r0 + (i < w.nvalid ? i : 0);
-      q.h[i] = *reinterpret_cast<const unsigned*>(H + (size_t)r * ld + cc);
-      q.g[i][0] = G[r * 3]; q.g[i][1] = G[r * 3 + 1]; q.g[i][2] = G[r * 3 + 2];
-    }
-  }
-  __device__ void fin(const Raw& q, const KC& k, const TRows& w, int c, float* o0, float* o1) const {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float h0 = bf_lo(q.h[i]), h1 = bf_hi(q.h[i]);
-      const float g0 = f * q.g[i][0], g1 = f * q.g[i][1], g2 = f * q.g[i][2];
-      const float gy0 = __fmaf_rn(k.s[0], h0, k.t[0]) > 0.f ? (g0 * k.w0[0] + g1 * k.w1[0] + g2 * k.w2[0]) : 0.f;
-      const float gy1 = __fmaf_rn(k.s[1], h1, k.t[1]) > 0.f ? (g0 * k.w0[1] + g1 * k.w1[1] + g2 * k.w2[1]) : 0.f;
-      o0[i] = __fmaf_rn(k.a[0], gy0, __fmaf_rn(k.b[0], h0, k.c[0]));
-      o1[i] = __fmaf_rn(k.a[1], gy1, __fmaf_rn(k.b[1], h1, k.c[1]));
-    }
-  }
-};
-struct TGridFeat {  // a1 = relu(gamma*(Gx[n]+Fx[b])+beta) from the fp32 factors; a task's 8 rows are 8 vertices of ONE sample
-  const float *Gx, *Fx, *gamma, *beta;
-  int N, ld, K;
-  struct KC { float g0, g1, b0, b1; };
-  struct Raw { float2 gx[8]; float2 f; };
-  __device__ KC kc(int c) const { const bool a = c < K, b = c + 1 < K; return KC{a ? gamma[c] : 0.f, b ? gamma[c + 1] : 0.f, a ? beta[c] : 0.f, b ? beta[c + 1] : 0.f}; }
-  __device__ void load(Raw& q, const TRows& w, int c, int) const {
-    const int cc = c + 1 < ld ? c : 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q.gx[i] = *reinterpret_cast<const float2*>(Gx + (size_t)(w.n + (i < w.nvalid ? i : 0)) * ld + cc);
-    q.f = *reinterpret_cast<const float2*>(Fx + (size_t)w.b * ld + cc);
-  }
-  __device__ void fin(const Raw& q, const KC& k, const TRows&, int, float* o0, float* o1) const {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      o0[i] = fmaxf(__fmaf_rn(k.g0, q.gx[i].x + q.f.x, k.b0), 0.f);
-      o1[i] = fmaxf(__fmaf_rn(k.g1, q.gx[i].y + q.f.y, k.b1), 0.f);
-    }
-  }
-};
-
-template <class AOp, class BOp, int WN>
-__global__ __launch_bounds__(NTB) void tn_bf16_kernel(AOp aop, BOp bop, int M, int Nc, long R, int N, int Bsz, int tiles_per_chunk,
-                                                      float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BNW = 64 * WN, NPB = 32 * WN;     // B channels / channel pairs per block
-  constexpr int BT = (NPB * 8 + NTB - 1) / NTB;  // B tasks per thread
-  bfraw* As = reinterpret_cast<bfraw*>(smem);    // [2][BM][LPT]   (m, r)
-  bfraw* Bs = As + 2 * BM * LPT;                 // [2][BNW][LPT]  (n, r)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  // 1-D grid of (output tiles) x (split-K chunks); the tiles of a chunk are neighbours on one XCD: they contract the same rows
-  const int mt = (M + BM - 1) / BM, ntile = mt * ((Nc + BNW - 1) / BNW);
-  const int vid = xcd_virtual_id(blockIdx.x, gridDim.x), chunk = vid / ntile, tile = vid - chunk * ntile;
-  const int bm0 = (tile % mt) * BM, bn0 = (tile / mt) * BNW;
-  // The contraction runs over the rows in TILES of (8 samples) x (8 consecutive template vertices): k-tile t = (sample group
-  // t / NV8, vertex group t % NV8), row group g of a tile = sample 8*(t / NV8) + g, its 8 rows = the 8 vertices (contiguous in
-  // memory).  The eight groups of a tile therefore share the same eight rows of the layer-1 grid factor Gx (the operand the
-  // weight gradient of layer 2 regenerates a1 from): with plain row order every 64-row tile pulled 64 distinct Gx rows - 6.3 GB
-  // of the 8.5 GB this kernel fetched per call at 16 050 points (PMC, profiles/r02_kernels.md).
-  const int NV8 = (N + 7) / 8, ntiles = ((Bsz + 7) / 8) * NV8;
-  const int tbeg = chunk * tiles_per_chunk, tend = tbeg + tiles_per_chunk < ntiles ? tbeg + tiles_per_chunk : ntiles;
-  const int ga = __builtin_amdgcn_readfirstlane(tid >> 6);  // A task: row group = wave, channel pair = lane
-  const int ca = bm0 + 2 * lane;
-  const typename AOp::KC kca = aop.kc(ca);
-  int cb[BT], gb[BT];
-  bool tb_ok[BT];
-  typename BOp::KC kcb[BT];
-#pragma unroll
-  for (int j = 0; j < BT; ++j) {
-    const int t = tid + NTB * j;
-    tb_ok[j] = t < NPB * 8;
-    gb[j] = (tb_ok[j] ? t : 0) / NPB;
-    cb[j] = bn0 + 2 * ((tb_ok[j] ? t : 0) % NPB);
-    kcb[j] = bop.kc(cb[j]);
-  }
-  typename AOp::Raw ra;
-  typename BOp::Raw rb[BT];
-  // Cursor of a task: the tile it will load next, as (sample group, vertex group); advanced by one tile per iteration
-  struct Cursor { int bg, ng; };
-  auto cursor_at = [&](int t) { return Cursor{t / NV8, t % NV8}; };
-  auto advance = [&](Cursor& c) {
-    if (++c.ng == NV8) { c.ng = 0; ++c.bg; }
-  };
-  auto rows_at = [&](const Cursor& c, int g) {  // the 8 rows of row group g (= sample) of the tile
-    TRows w;
-    const int b = c.bg * 8 + g, n0 = c.ng * 8;
-    const int left = N - n0;
-    w.nvalid = b < Bsz ? (left >= 8 ? 8 : (left > 0 ? left : 0)) : 0;
-    w.b = w.nvalid ? b : 0;   // a group beyond the batch re-reads valid rows and is masked to zero
-    w.n = w.nvalid ? n0 : 0;
-    w.r0 = (long)w.b * N + w.n;
-    return w;
-  };
-  // rows i >= nvalid of a packed 8-row strip -> zero (words hold row pairs)
-  auto mask_rows = [](u32x4 v, int nvalid) {
-    const unsigned m0 = (nvalid > 0 ? 0xffffu : 0u) | (nvalid > 1 ? 0xffff0000u : 0u);
-    const unsigned m1 = (nvalid > 2 ? 0xffffu : 0u) | (nvalid > 3 ? 0xffff0000u : 0u);
-    const unsigned m2 = (nvalid > 4 ? 0xffffu : 0u) | (nvalid > 5 ? 0xffff0000u : 0u);
-    const unsigned m3 = (nvalid > 6 ? 0xffffu : 0u) | (nvalid > 7 ? 0xffff0000u : 0u);
-    v.x &= m0; v.y &= m1; v.z &= m2; v.w &= m3;
-    return v;
-  };
-  Cursor cur_t = cursor_at(tbeg);
-  TRows wa, wb[BT];
-  auto fetch = [&]() {  // loads of the tile the cursor points at; then the cursor moves on
-#pragma unroll
-    for (int j = 0; j < BT; ++j) {
-      wb[j] = rows_at(cur_t, gb[j]);
-      if (tb_ok[j]) bop.load(rb[j], wb[j], cb[j], Bsz);
-    }
-    wa = rows_at(cur_t, ga);
-    aop.load(ra, wa, ca, Bsz);
-    advance(cur_t);
-  };
-  auto stash = [&](int buf) {
-    float o0[8], o1[8];
-    aop.fin(ra, kca, wa, ca, o0, o1);
-    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + 2 * lane) * LPT + ga * 8) = mask_rows(pack8(o0), wa.nvalid);
-    *reinterpret_cast<u32x4*>(As + ((size_t)buf * BM + 2 * lane + 1) * LPT + ga * 8) = mask_rows(pack8(o1), wa.nvalid);
-#pragma unroll
-    for (int j = 0; j < BT; ++j) {
-      if (tb_ok[j]) {
-        bop.fin(rb[j], kcb[j], wb[j], cb[j], o0, o1);
-        const int ch = cb[j] - bn0;
-        *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + ch) * LPT + gb[j] * 8) = mask_rows(pack8(o0), wb[j].nvalid);
-        *reinterpret_cast<u32x4*>(Bs + ((size_t)buf * BNW + ch + 1) * LPT + gb[j] * 8) = mask_rows(pack8(o1), wb[j].nvalid);
-      }
-    }
-  };
-  f32x16 acc[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const int nk = tend > tbeg ? tend - tbeg : 0;
-  if (nk > 0) {
-    fetch();
-    stash(0);
-  }
-  __syncthreads();
-  const int fk = (lane >> 5) * 8, fr = lane & 31;
-  const bool wave_live = bm0 + wm * 32 < M;  // the 257th channel makes a third M tile with one live MFMA row tile
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) fetch();
-    if (wave_live) {
-#pragma unroll
-      for (int ks = 0; ks < BKT / 16; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((size_t)cur * BM + wm * 32 + fr) * LPT + ks * 16 + fk);
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((size_t)cur * BNW + wn * 32 * WN + j * 32 + fr) * LPT + ks * 16 + fk);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-        }
-      }
-    }
-    if (more) stash(cur ^ 1);
-    __syncthreads();
-  }
-  float* dst = part + (size_t)chunk * M * Nc;
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int col = bn0 + wn * 32 * WN + j * 32 + (lane & 31);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = bm0 + wm * 32 + acc_row(reg, lane);
-      if (m < M && col < Nc) dst[(size_t)m * Nc + col] = acc[j][reg];
-    }
-  }
-}
+// (The first-generation weight-gradient GEMM of this file - tn_bf16_kernel and its T* operand generators: (8 rows) x (2 channels)
+// strips, k-major LDS images written through a VALU transpose - was removed in round 6: decoder_tn2.h covers every width with
+// WN = 2 or 5 tiles per wave.  git history: "bf16 decoder" of round 2.)

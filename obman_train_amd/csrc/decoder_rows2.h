@@ -44,14 +44,12 @@ struct R2Geo {
   int mode;     // 0: wave = 1 sample x 32 vertices, block = 8 samples (h2, h3, gy2)
                 // 1: wave = 8 samples x 4 vertices, block = 64 samples over the SAME 4 vertices (dA: sums over samples stay in the block)
                 // 2: wave = 8 samples x 4 vertices, block = the SAME 8 samples over 32 vertices (h2: the block's 8 feature-factor rows sit in LDS)
-                // 3: as 2, but the block's tile is 4 * vwaves vertices wide (decoder_rows4.h: a wave works off several 32-row fragments)
   int nvt, nbg; // vertex tiles, sample groups
   int ngroups;  // column groups of R2_COLS
   int slots;    // persistent blocks per column group = spb * nbg
   int spb;      // slots per sample group
   int wside;    // side-column rows of the weight slice actually present (0 .. R2_SIDE): LDS rows = R2_COLS + wside
   int chunk;    // vertex tiles per slot
-  int vwaves;   // mode 3: 32-row fragments per block tile
   // row i (0..31) of the fragment of wave `wave` in block tile (bg, vt)
   __device__ __forceinline__ void row(int bg, int vt, int wave, int i, int& b, int& n, long& r, bool& ok) const {
     if (mode == 0) {
@@ -60,12 +58,9 @@ struct R2Geo {
     } else if (mode == 1) {
       b = bg * 64 + wave * 8 + (i >> 2);
       n = vt * 4 + (i & 3);
-    } else if (mode == 2) {
-      b = bg * 8 + (i >> 2);
-      n = vt * 32 + wave * 4 + (i & 3);
     } else {
       b = bg * 8 + (i >> 2);
-      n = (vt * vwaves + wave) * 4 + (i & 3);
+      n = vt * 32 + wave * 4 + (i & 3);
     }
     ok = b < B && n < N;
     if (!ok) { b = 0; n = 0; }
@@ -105,7 +100,7 @@ struct BPlain {
 // 4 / 8 for the bf16-stored activations
 template <class AOp> struct R2Depth { static constexpr int value = 8; };
 template <> struct R2Depth<BGridFeat> { static constexpr int value = 4; };
-template <> struct R2Depth<BGradH> { static constexpr int value = 2; };  // fallback path (OBMAN_DEC_TN2=0): EpiL1B2 keeps 32 registers of state
+template <> struct R2Depth<BGradH> { static constexpr int value = 2; };  // layers too wide for a materialised gh2 (ld2 > 512): EpiL1B2 keeps 32 registers of state
 template <> struct R2Depth<BGridFeatPre> { static constexpr int value = 4; };
 
 // LDS floats an operand generator needs besides the weight slice (per-channel constants; the 8 Fy rows), and how it fills them
@@ -372,7 +367,6 @@ struct R2Fin<BGradH3> {
 // ------------------------------------------------------------------------------------------------ epilogues
 struct R2Ctx {
   int lane, wave, c0, nside, last_group, slot, bg, vt;
-  int sw;  // which 1 KB piece of the epilogue's LDS scratch this wave uses (= wave, except where a wave works off several fragments: decoder_rows4.h)
 };
 
 __device__ __forceinline__ double r2_pick(const double (&v)[R2_SIDE], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
@@ -427,7 +421,7 @@ __device__ __forceinline__ void r2_flush_cols(double (&d1)[R2_NT], double (&d2)[
 
 struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, sum of squares of the STORED values) per slot
   // Stores are ISSUE-bound on this chip (a wave's store instruction costs the same whether it carries 4 or 16 bytes per lane;
-  // the 32 dword stores per tile of the first version were 30 % of the h2 kernel, tools/r03_abl.sh): every 16 x 32 piece of
+  // the 32 dword stores per tile of the first version were 30 % of the h2 kernel, tools/archive/r03/r03_abl.sh): every 16 x 32 piece of
   // the tile is transposed through 1 KB of LDS per wave (4 ds_write_b32 + 1 ds_read_b128 per lane) and leaves as ONE
   // 16-byte store per lane - 8 store instructions per tile instead of 32.
   static constexpr int LDS_FLOATS = R2_WAVES * 256;
@@ -458,7 +452,7 @@ struct EpiStoreB2 {  // C[r,n] = bf16(acc + bias[n]); fp64 column moments (sum, 
     float s1[R2_NT], s2[R2_NT];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    unsigned* tb = reinterpret_cast<unsigned*>(red) + c.sw * 256;  // [16 rows][16 words = 32 columns]
+    unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
     bool interior;
     {
       int b, n; long r; bool okl;
@@ -626,7 +620,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j) { p1[j] = 0.f; p2[j] = 0.f; }
     {
-      unsigned* tb = reinterpret_cast<unsigned*>(red) + c.sw * 256;  // [16 rows][16 words = 32 columns]
+      unsigned* tb = reinterpret_cast<unsigned*>(red) + c.wave * 256;  // [16 rows][16 words = 32 columns]
       // the rows this lane moves: row 16 G + (lane >> 2) of the tile, columns 8 (lane & 3) .. + 7 of each 32-column piece
       size_t og[2];
       bool okg[2];
@@ -854,8 +848,8 @@ struct EpiL1B2 {
 // group's MFMAs run beside the other group's fragment reads / transform / requests - was 30 - 40 % SLOWER on all four kernels
 // (h2 539 -> 726 us, dA 611 -> 872 us): these kernels are bound by VALU ISSUE, not by idle matrix pipes waiting for operands, and
 // a barrier interval costs the slower of the two phases; profiles/r05_kernels.md section 2.)
-// ABL != 0: measurement-only variants, instantiated only with -DOBMAN_ABLATION (tools/ablate_gemm.sh build, then tools/r03_abl.sh /
-// tools/r03_dbg.sh with OBMAN_R2_ABL; wrong results): 1 no operand requests inside the k loop,
+// ABL != 0: measurement-only variants, instantiated only with -DOBMAN_ABLATION (tools/ablate_gemm.sh build, then tools/archive/r03/r03_abl.sh /
+// tools/archive/r03/r03_dbg.sh with OBMAN_R2_ABL; wrong results): 1 no operand requests inside the k loop,
 // 2 weight fragments read once, 3 no epilogue, 4 no MFMAs, 5 = 2 + the generator's LDS constants read once
 // ABL == 8: s_memtime stamps inside the k-step of every wave (LDS phase / transform + operand wait / MFMA issue / rest / epilogue),
 // summed per wave into r2_dbg[block][wave][8] - printed by launch_rows2 (measurement only; the stamps serialise the phases)
@@ -892,7 +886,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
 
   R2Src<AOp> src;
   src.init(aop, geo);
-  R2Ctx ctx{lane, wave, c0, nside, last_group, slot, 0, 0, wave};
+  R2Ctx ctx{lane, wave, c0, nside, last_group, slot, 0, 0};
   typename Epi::State est;
   epi.init(est, ctx);
   const int bg = slot / geo.spb, sq = slot - bg * geo.spb;

@@ -666,7 +666,7 @@ struct F2EpiL1PQ {  // dA(gy1) WITHOUT gy1: layer 1 only needs P[b,c] = sum_n gy
 // grid = ngroups * slots blocks (1-D, XCD-aware virtual ids: the column groups of one slot are neighbours on one XCD - they
 // stream the same activation rows).  Dynamic LDS: weight slice [(32 NT + wside)][Kp + 4] fp32, then the generator's constants.
 // W is the fp32 weight matrix as the module holds it: w_kn == 0: W[n][k] (row stride ldw), w_kn == 1: W[k][n].
-#ifdef OBMAN_F2_TIMING  // measurement build (tools/r04/dec_dbg.sh): s_memtime per wave around staging / k loops / epilogues
+#ifdef OBMAN_F2_TIMING  // measurement build (tools/archive/r04/dec_dbg.sh): s_memtime per wave around staging / k loops / epilogues
 __device__ unsigned long long f2_dbg[2048 * 8];
 #define F2_TICK() __builtin_readcyclecounter()
 #else

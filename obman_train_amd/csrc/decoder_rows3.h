@@ -75,7 +75,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows3_bf16_kernel(AOp aop, const b
   R2Lds<AOp>::stage(aop, kcs, Kp, tid, (vid / geo.ngroups) / geo.spb, geo);
   __syncthreads();
 
-  R2Ctx ctx{lane, wave, c0, nside, last_group, slot, 0, 0, wave};
+  R2Ctx ctx{lane, wave, c0, nside, last_group, slot, 0, 0};
   typename Epi::State est;
   epi.init(est, ctx);
   const int bg = slot / geo.spb, sq = slot - bg * geo.spb;

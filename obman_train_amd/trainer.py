@@ -141,7 +141,7 @@ class GraphedTrainStep:
     would need the host).  A host-driven backend (gloo) cannot be recorded.  (A split form for such backends - forward +
     backward graph, exchange from Python, optimizer graph - was built and REMOVED: on ROCm 7.0 / torch 2.10 a recorded backward that
     ends its graph produced garbage gradients for the encoder's early layers in most two-process runs, with autograd-allocated
-    and with persistent gradient buffers alike; tools/r05/dp_split_dbg*.py are the reproducers.)
+    and with persistent gradient buffers alike; tools/archive/r05/dp_split_dbg*.py are the reproducers.)
     Lambdas baked into the step (``ops.weighted_terms`` caches the loss weights as device tensors) are those of the capture:
     a schedule that changes them needs a re-capture.
 

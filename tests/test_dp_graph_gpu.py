@@ -6,7 +6,7 @@
   same state, and a parameter without a gradient must be refused before anything is recorded.
 * Two processes on the one GPU cannot run this: RCCL refuses two ranks per device and gloo's collectives are host work that a
   graph cannot hold; the split form built for that case (forward + backward graph / exchange / optimizer graph) was removed as
-  unreliable on this ROCm (trainer.GraphedTrainStep docstring, tools/r05/dp_split_dbg*.py).  Multi-rank correctness of the
+  unreliable on this ROCm (trainer.GraphedTrainStep docstring, tools/archive/r05/dp_split_dbg*.py).  Multi-rank correctness of the
   collective plan itself is what tests/test_dp_gloo.py and tests/test_dp_two_ranks_gpu.py hold; the graph adds no collective.
 Reference semantics: ``nn.DataParallel`` replicas (traineval.py:130), SURVEY section 8e.
 """

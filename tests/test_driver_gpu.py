@@ -136,8 +136,8 @@ def test_graphed_train_step_replays_the_eager_step():
     finally:
         request_restore()
     # The yardstick is measured in the same process: two EAGER runs from the same seed.  At this size (4 images of 64 x 64) not even
-    # the first forward is bit-reproducible (tools/r04/step_det.py: loss terms differ by 1e-7 .. 1e-4 between two passes over the
-    # same weights; this package's kernels use no float atomics and the decoder is bit-reproducible - tools/r04/det_check.py - so
+    # the first forward is bit-reproducible (tools/archive/r04/step_det.py: loss terms differ by 1e-7 .. 1e-4 between two passes over the
+    # same weights; this package's kernels use no float atomics and the decoder is bit-reproducible - tools/archive/r04/det_check.py - so
     # the source is a library kernel: MIOpen's find lists split-K "gkgs" solutions with atomic accumulation among its picks), and
     # Adam's first steps (~lr * sign(gradient)) amplify that: seven steps in, eager runs of different processes scatter by +- 1.4 %
     # (eight runs, round 4).  Replays have to track the eager step within 4 x the eager-vs-eager difference (floor 2e-3, the

@@ -8,7 +8,6 @@ pytest process with the variable set.  What each value selects:
   OBMAN_DEC_TN3=0      first-generation fp32 weight-gradient GEMMs instead of decoder_tn3.h
   OBMAN_DEC_F2PQ=0     second-generation layer-2 data gradient with a materialised gy1
   OBMAN_DEC_ROWS2=0    first-generation bf16 rows GEMMs (decoder_bf16.h) instead of decoder_rows2.h / rows3.h
-  OBMAN_DEC_TN2=0      first-generation bf16 weight-gradient GEMMs (and gh2 regenerated instead of materialised)
   OBMAN_DEC_ROWS3=0    h3 on the rows2 kernel (register operand queue) instead of the LDS-DMA ring of decoder_rows3.h
   OBMAN_DEC_L4W=0      first-generation layer-4 kernels (32 / 64 lanes per row)
   OBMAN_DEC_TN2W=0     the bf16 layer-2 weight gradient on five 128 x 320 tiles (tn2_bf16_kernel) instead of the round-6 wide tile
@@ -29,7 +28,7 @@ _CONTACT = ["tests/test_contact_gpu.py", "-k", "contains or golden"]
 
 @pytest.mark.parametrize("knob,target", [
     ("OBMAN_DEC_ROWS2F", _DECODER), ("OBMAN_DEC_TN3", _DECODER), ("OBMAN_DEC_F2PQ", _DECODER), ("OBMAN_DEC_ROWS2", _DECODER),
-    ("OBMAN_DEC_TN2", _DECODER), ("OBMAN_DEC_ROWS3", _DECODER), ("OBMAN_DEC_L4W", _DECODER), ("OBMAN_DEC_TN2W", _DECODER),
+    ("OBMAN_DEC_ROWS3", _DECODER), ("OBMAN_DEC_L4W", _DECODER), ("OBMAN_DEC_TN2W", _DECODER),
     ("OBMAN_MC_BINNED", _CONTACT)])
 def test_fallback_generation_passes_the_parity_cases(knob, target):
     env = dict(os.environ, **{knob: "0"})

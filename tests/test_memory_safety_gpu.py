@@ -44,8 +44,8 @@ def test_guard_page_allocator_detects_one_byte_out_of_bounds():
     ("configs[2] bf16 bs64, guard BEFORE the tensors", ["--config", "c3", "--batch", "64", "--encoder-dtype", "bf16",
                                                          "--decoder-dtype", "bf16", "--steps", "1", "--left"]),
     ("configs[2] fp32 bs16", ["--config", "c3", "--batch", "16", "--steps", "1"]),
-    ("configs[2] first-generation bf16 kernels bs16", ["--config", "c3", "--batch", "16", "--decoder-dtype", "bf16", "--steps", "1",
-                                                        "--env", "OBMAN_DEC_ROWS2=0", "--env", "OBMAN_DEC_TN2=0"]),
+    ("configs[2] block-tiled bf16 rows kernels + five-tile dW2, bs16", ["--config", "c3", "--batch", "16", "--decoder-dtype", "bf16", "--steps", "1",
+                                                                        "--env", "OBMAN_DEC_ROWS2=0", "--env", "OBMAN_DEC_TN2W=0"]),
     ("configs[4] bf16 bs8", ["--config", "c5", "--batch", "8", "--encoder-dtype", "bf16", "--decoder-dtype", "bf16", "--steps", "1"]),
     ("configs[4] fp32 bs4, guard BEFORE", ["--config", "c5", "--batch", "4", "--steps", "1", "--left"]),
 ])
