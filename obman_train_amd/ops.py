@@ -507,9 +507,25 @@ def bn_act(bn, x, skip=None, relu=True, count=True, dual=False):
                         bool(dual and torch.is_grad_enabled()))
 
 
-_TERM_WEIGHTS = {}  # (device, weights) -> fp32 tensor on the device; a handful of 16-byte entries (the lambdas change once per decay
-# epoch).  NEVER evicted: a captured GraphedTrainStep has the address of its weight tensor baked into the graph, and this cache is
-# what keeps that tensor alive
+_TERM_WEIGHTS = {}  # (device, weights) -> fp32 tensor on the device, LRU-bounded (a lambda schedule that changes every step
+# must not leak one tensor per step).  A weight tensor used WHILE A STREAM IS BEING CAPTURED has its address baked into that graph:
+# those are also appended to _CAPTURED_TERM_WEIGHTS - never evicted, and collected by trainer.GraphedTrainStep, which keeps them
+# alive itself and refuses a replay after the model's lambdas have changed.
+_TERM_WEIGHTS_MAX = 64
+_CAPTURED_TERM_WEIGHTS = []  # [(values tuple, tensor)] in capture order
+
+
+def _term_weight_tensor(dev, values):
+    key = (dev, values)
+    w = _TERM_WEIGHTS.pop(key, None)
+    if w is None:
+        w = torch.tensor(values, dtype=torch.float32, device=dev)
+        while len(_TERM_WEIGHTS) >= _TERM_WEIGHTS_MAX:
+            _TERM_WEIGHTS.pop(next(iter(_TERM_WEIGHTS)))  # least recently used first (dicts keep insertion order)
+    _TERM_WEIGHTS[key] = w
+    if torch.cuda.is_current_stream_capturing():
+        _CAPTURED_TERM_WEIGHTS.append((values, w))
+    return w
 
 
 class _WeightedTerms(torch.autograd.Function):
@@ -543,10 +559,7 @@ def weighted_terms(pairs, shape=()):
             raise ValueError("weighted_terms: python-number terms other than 0 are not part of any reference composition")
         pairs = [(w, t) for w, t in pairs if torch.is_tensor(t)]
         dev = tensors[0].device
-        key = (dev, tuple(float(w) for w, _ in pairs))
-        w = _TERM_WEIGHTS.get(key)
-        if w is None:
-            w = _TERM_WEIGHTS[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+        w = _term_weight_tensor(dev, tuple(float(w) for w, _ in pairs))
         return _WeightedTerms.apply(w, *tensors).reshape(shape)
     acc = None
     for w, t in pairs:

@@ -114,6 +114,23 @@ def wait_for_watchdog(buckets, dev, timeout_s=5.0):
     return {"condition": "slept 5 watchdog periods (no flight-recorder status)", "polls": polls, "waited_s": round(time.perf_counter() - t0, 4)}
 
 
+def _lambda_signature(model):
+    """(module path, attribute, value) of every python-number loss weight of the model's loss objects / branches: attributes named
+    ``*lambda*`` or ``*_weight`` (``HandNet.contact_lambda``, ``ManoLoss.lambda_verts``, ``AtlasLoss.trans_weight``, ...)."""
+    sig = []
+    owners = [("", model)] + [(n, m) for n, m in model.named_modules() if n]
+    for name, owner in list(owners):
+        for attr in ("mano_loss", "atlas_loss"):
+            sub = getattr(owner, attr, None)
+            if sub is not None and not isinstance(sub, torch.nn.Module):
+                owners.append((name + "." + attr, sub))
+    for name, owner in owners:
+        for attr, val in vars(owner).items():
+            if ("lambda" in attr or attr.endswith("_weight")) and isinstance(val, (int, float)) and not isinstance(val, bool):
+                sig.append((name, attr, float(val)))
+    return tuple(sorted(sig))
+
+
 class GraphedTrainStep:
     """One training step (forward -> zero_grad -> backward -> optimizer.step) recorded ONCE into a hipGraph and replayed.
 
@@ -142,8 +159,10 @@ class GraphedTrainStep:
     backward graph, exchange from Python, optimizer graph - was built and REMOVED: on ROCm 7.0 / torch 2.10 a recorded backward that
     ends its graph produced garbage gradients for the encoder's early layers in most two-process runs, with autograd-allocated
     and with persistent gradient buffers alike; tools/archive/r05/dp_split_dbg*.py are the reproducers.)
-    Lambdas baked into the step (``ops.weighted_terms`` caches the loss weights as device tensors) are those of the capture:
-    a schedule that changes them needs a re-capture.
+    Lambdas baked into the step (``ops.weighted_terms`` keeps the loss weights as device tensors; the ones a capture used are held by
+    this object: ``term_weights``) are those of the capture: ``__call__`` compares the model's lambda attributes with the captured
+    ones and raises when a schedule has changed them - re-capture, or write the new values into ``term_weights`` in
+    place and call ``accept_lambdas()``.
 
     Side effect of construction: the ``warmup`` eager steps and the capture pass are REAL train steps on the capture batch
     (``warmup`` optimizer updates, BatchNorm running statistics, Adam step counters move; the capture pass itself only
@@ -196,6 +215,9 @@ class GraphedTrainStep:
         self.watchdog_wait = None
         if self.mode == "fused":
             self.watchdog_wait = wait_for_watchdog(self.buckets, dev)
+        from . import ops
+
+        mark = len(ops._CAPTURED_TERM_WEIGHTS)
         self.graph = torch.cuda.CUDAGraph()
         if self.mode == "single":
             with torch.cuda.graph(self.graph):
@@ -209,6 +231,9 @@ class GraphedTrainStep:
                     self.total, self.results, self.losses = train_step(model, optimizer, self.static, b)
             finally:
                 b.capturing = False
+        self.term_weights = list(ops._CAPTURED_TERM_WEIGHTS[mark:])  # keeps the tensors the graph reads alive; [(values, tensor)]
+        del ops._CAPTURED_TERM_WEIGHTS[mark:]
+        self._lambdas = _lambda_signature(model)
         if snapshot is not None:
             with torch.no_grad():
                 live = model.state_dict()
@@ -231,7 +256,15 @@ class GraphedTrainStep:
 
             optim.refresh_bf16_shadows(model)
 
+    def accept_lambdas(self):
+        """The caller has updated ``term_weights`` in place for the model's current lambdas."""
+        self._lambdas = _lambda_signature(self.model)
+
     def __call__(self, sample):
+        if _lambda_signature(self.model) != self._lambdas:
+            raise ValueError("GraphedTrainStep: the model's loss weights changed since the capture (%s).  The recorded step multiplies "
+                             "by the captured values: capture a new graph, or write the new values into `term_weights` and call "
+                             "accept_lambdas()" % sorted(set(_lambda_signature(self.model)) ^ set(self._lambdas))[:4])
         for k, v in sample.items():
             if torch.is_tensor(v):
                 self.static[k].copy_(v, non_blocking=True)

@@ -7,7 +7,8 @@ import csv
 import sys
 
 OURS = ("pairmin", "rowmean2", "mano_", "contains_", "contact_", "dec::", "edge_", "laplacian", "bnact::", "imgstream", "blur_kernel",
-        "warp_kernel", "mean_kernel")
+        "warp_kernel", "mean_kernel", "adam_kernel", "adam_tick", "affine_fwd", "affine_bwd", "mse_fwd", "mse_bwd", "mse_finalize", "gt_stats",
+        "bf16_shadow")
 
 
 def main(src, dst, steps="auto", cmd="", top=30, steady=""):
