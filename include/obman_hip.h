@@ -269,8 +269,8 @@ int obman_imgstream_fwd(const uint8_t* src, int B, int pitch_h, int pitch_w, con
                         void* ws, float* out, obman_stream_t stream);
 
 /* ---- K11: optimizer step ------------------------------------------------------------------------
- * Replaces torch.optim.Adam(model.parameters()).step() of the reference's training loop (traineval.py:104-127,
- * epochpass3d.py:103-105; defaults nets3dopts.py:249-273): exp_avg / exp_avg_sq / bias-corrected update of every
+ * Replaces torch.optim.Adam(model.parameters()).step() of the reference's training loop (traineval.py:112-127,
+ * epochpass3d.py:86-91; defaults nets3dopts.py:249-273): exp_avg / exp_avg_sq / bias-corrected update of every
  * parameter in ONE multi-tensor kernel per <= 64 tensors (plain Adam: L2 weight decay added to the gradient, no amsgrad).
  * `tensors` is a HOST array; every pointer in it is a device pointer to n contiguous fp32 elements in the parameter's own
  * memory order (p, g, m, v alike).  `step` is the tensor's step counter (device fp32, incremented by this call before use,
@@ -290,7 +290,7 @@ int obman_adam_step(const obman_adam_tensor* tensors, int count, float lr, float
 int obman_bf16_shadow(const float* src, uint16_t* dst, long n, obman_stream_t stream);
 
 /* ---- K12: objpoints3d = scale * verts + trans ---------------------------------------------------
- * Replaces `scaled = scale.unsqueeze(1) * verts; points = scaled + trans.unsqueeze(1)` (atlasbranch.py:136-141) and its
+ * Replaces `scaled = scale.unsqueeze(1) * verts; points = scaled + trans.unsqueeze(1)` (atlasbranch.py:133-138) and its
  * autograd backward (two broadcast products and two [B,N,3] -> [B,1,.] reductions).  verts / out / g / gverts [B,N,3],
  * scale [B] (NULL = 1), trans [B,3] (NULL = 0); gverts / gscale [B] / gtrans [B,3] may each be NULL.  ws: scratch of
  * obman_affine_points_ws_floats(B) floats (fixed-order partial sums: deterministic). */
@@ -302,7 +302,7 @@ int obman_affine_points_bwd(const float* g, const float* verts, const float* sca
 
 /* ---- K13: the mean-squared-error heads ----------------------------------------------------------
  * Replaces the torch_f.mse_loss calls of ManoLoss.compute_loss (manobranch.py:251-318: vertices, joints, shape, pose
- * regulariser) and AtlasLoss.compute_loss (atlasbranch.py:213-232: translation, scale): out[i] = mean((pred_i - target_i)^2)
+ * regulariser) and AtlasLoss.compute_loss (atlasbranch.py:211-228: translation, scale): out[i] = mean((pred_i - target_i)^2)
  * for up to 8 differently sized tensors in one launch (+ a one-block finalize); target NULL = zeros.  Backward:
  * grad_i = 2 / n_i * (pred_i - target_i) * g_out[i] for every term whose grad pointer is set.  `terms` is a HOST array of
  * device pointers; ws: obman_mse_terms_ws_floats() floats. */
@@ -318,7 +318,7 @@ int obman_mse_terms_bwd(const obman_mse_term* terms, int count, const float* g_o
 
 /* ---- K14: ground-truth object statistics --------------------------------------------------------
  * Replaces `centroids = gt.mean(1); centred = gt - centroids.unsqueeze(1); torch.norm(centred, 2, 2).max(1)[0]`
- * (atlasbranch.py:219-229).  gt [B,N,3] -> centroid [B,3], centred [B,N,3], maxnorm [B].  No gradient (targets). */
+ * (atlasbranch.py:211-222).  gt [B,N,3] -> centroid [B,3], centred [B,N,3], maxnorm [B].  No gradient (targets). */
 int obman_gt_object_stats(const float* gt, int B, int N, float* centroid, float* centred, float* maxnorm, obman_stream_t stream);
 
 /* ---- measurement utility (not on the product path) ----------------------------------------------

@@ -2,14 +2,14 @@
 // 10.06 ms of kernel time of a configs[2] step were ~150 "other PyTorch kernels", each costing its full 4 - 13 us because the GPU
 // is back-to-back busy).  Everything here is bandwidth- or latency-trivial; the point is ONE launch where there were 4 - 40.
 //
-//   K11 obman_adam_step          torch.optim.Adam over every parameter (traineval.py:104-127) as a multi-tensor kernel that
+//   K11 obman_adam_step          torch.optim.Adam over every parameter (traineval.py:112-127) as a multi-tensor kernel that
 //                                also writes the bf16 SHADOW copy of a filter the autocast encoder reads (no per-step cast kernels)
-//   K12 obman_affine_points_*    objpoints3d = scale * verts + trans (atlasbranch.py:136-141) and its backward (two full
+//   K12 obman_affine_points_*    objpoints3d = scale * verts + trans (atlasbranch.py:133-138) and its backward (two full
 //                                [B,N,3] -> [B,1,3] reductions in the stock form: 51 us each at 16 050 points)
-//   K13 obman_mse_terms_*        the MSE heads of ManoLoss / AtlasLoss (manobranch.py:251-318, atlasbranch.py:213-232): k
+//   K13 obman_mse_terms_*        the MSE heads of ManoLoss / AtlasLoss (manobranch.py:251-318, atlasbranch.py:211-228): k
 //                                mean-squared errors over k differently sized tensors, forward and backward, one launch each
 //   K14 obman_gt_object_stats    centroid, centred cloud and max point norm of the ground-truth object points
-//                                (atlasbranch.py:219-229: gt.mean(1), gt - centroid, norm(.,2,2).max(1))
+//                                (atlasbranch.py:211-222: gt.mean(1), gt - centroid, norm(.,2,2).max(1))
 #include "common.h"
 #include "../../include/obman_hip.h"
 

@@ -53,7 +53,7 @@ class AtlasBranch(nn.Module):
     def _assemble(self, verts, trans, scale, with_faces):
         res = {}
         if trans is not None:
-            # scale.unsqueeze(1) * verts + trans.unsqueeze(1) (atlasbranch.py:136-141): one launch, and a two-launch backward
+            # scale.unsqueeze(1) * verts + trans.unsqueeze(1) (atlasbranch.py:133-138): one launch, and a two-launch backward
             points = ops.affine_points(verts, scale, trans)
         if scale is None and trans is None:
             res = {"objpoints3d": verts}
@@ -128,7 +128,7 @@ class AtlasLoss:
                 TransQueries.center3d in target and self.trans_weight):
             gt = target[TransQueries.objpoints3d]
             if "objtrans" in preds and has_gt and "objpointscentered3d" in preds:
-                # gt.mean(1), gt - centroids, norm(centred, 2, 2).max(1)[0] (atlasbranch.py:219-229): one launch (targets, no
+                # gt.mean(1), gt - centroids, norm(centred, 2, 2).max(1)[0] (atlasbranch.py:211-222): one launch (targets, no
                 # gradient); the two mse_loss heads: one launch per direction
                 centroids, centred, radius = ops.gt_object_stats(gt)
                 heads = [(preds["objtrans"], centroids)]

@@ -509,22 +509,29 @@ def bn_act(bn, x, skip=None, relu=True, count=True, dual=False):
 
 _TERM_WEIGHTS = {}  # (device, weights) -> fp32 tensor on the device, LRU-bounded (a lambda schedule that changes every step
 # must not leak one tensor per step).  A weight tensor used WHILE A STREAM IS BEING CAPTURED has its address baked into that graph:
-# those are also appended to _CAPTURED_TERM_WEIGHTS - never evicted, and collected by trainer.GraphedTrainStep, which keeps them
-# alive itself and refuses a replay after the model's lambdas have changed.
+# ownership MOVES from the cache to _CAPTURE_OWNED (trainer.GraphedTrainStep collects its entries, keeps them alive and lets the
+# caller rewrite them in place for a changed lambda - which is why a captured tensor must no longer serve eager compositions).
 _TERM_WEIGHTS_MAX = 64
-_CAPTURED_TERM_WEIGHTS = []  # [(values tuple, tensor)] in capture order
+_CAPTURE_OWNED = {}  # (device, weights) -> tensor owned by a capture (in progress, or finished and not collected by a GraphedTrainStep)
 
 
 def _term_weight_tensor(dev, values):
     key = (dev, values)
+    if torch.cuda.is_current_stream_capturing():
+        w = _CAPTURE_OWNED.get(key)
+        if w is None:
+            w = _TERM_WEIGHTS.pop(key, None)
+            if w is None:  # a tensor made now would be filled by a host copy recorded into the graph
+                raise RuntimeError("weighted_terms: loss weights %r first appear while a stream is being captured; run one eager step "
+                                   "with them before the capture (trainer.GraphedTrainStep's warm-up does)" % (values,))
+            _CAPTURE_OWNED[key] = w
+        return w
     w = _TERM_WEIGHTS.pop(key, None)
     if w is None:
         w = torch.tensor(values, dtype=torch.float32, device=dev)
         while len(_TERM_WEIGHTS) >= _TERM_WEIGHTS_MAX:
             _TERM_WEIGHTS.pop(next(iter(_TERM_WEIGHTS)))  # least recently used first (dicts keep insertion order)
     _TERM_WEIGHTS[key] = w
-    if torch.cuda.is_current_stream_capturing():
-        _CAPTURED_TERM_WEIGHTS.append((values, w))
     return w
 
 
@@ -769,7 +776,7 @@ class _AffinePoints(torch.autograd.Function):
 
 
 def affine_points(verts, scale=None, trans=None):
-    """``scale.unsqueeze(1) * verts + trans.unsqueeze(1)`` (atlasbranch.py:136-141; verts [B,N,3], scale [B,1], trans [B,3]) as
+    """``scale.unsqueeze(1) * verts + trans.unsqueeze(1)`` (atlasbranch.py:133-138; verts [B,N,3], scale [B,1], trans [B,3]) as
     one launch, and a backward of two launches where autograd runs two broadcast products and two [B,N,3] reductions."""
     return _AffinePoints.apply(verts, scale, trans)
 
@@ -816,7 +823,7 @@ class _MseTerms(torch.autograd.Function):
 def mse_terms(pairs):
     """``[torch_f.mse_loss(pred, target) for pred, target in pairs]`` (``target=None``: zeros, the reference's
     ``mse_loss(x, zeros_like(x))`` regularisers) as ONE forward launch (+ a one-block finalize) and ONE backward launch for up to
-    8 differently sized tensors: the MSE heads of ManoLoss / AtlasLoss (manobranch.py:251-318, atlasbranch.py:213-232).  Returns a
+    8 differently sized tensors: the MSE heads of ManoLoss / AtlasLoss (manobranch.py:251-318, atlasbranch.py:211-228).  Returns a
     list of 0-dim tensors (views of one [k] tensor).  Targets get no gradient (they are data in the reference)."""
     if not pairs:
         return []
@@ -828,7 +835,7 @@ def mse_terms(pairs):
 
 def gt_object_stats(gt):
     """Ground-truth object cloud [B,N,3] -> (centroids [B,3], centred [B,N,3], max point norm [B,1]): the target preparation of
-    AtlasLoss.compute_loss (atlasbranch.py:219-229: ``gt.mean(1)``, ``gt - centroids.unsqueeze(1)``,
+    AtlasLoss.compute_loss (atlasbranch.py:211-222: ``gt.mean(1)``, ``gt - centroids.unsqueeze(1)``,
     ``torch.norm(centred, 2, 2).max(1)[0].unsqueeze(1)``) in one launch instead of five.  No gradient."""
     gt = _dev(gt.detach(), "gt")
     B, N = gt.shape[0], gt.shape[1]

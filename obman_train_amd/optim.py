@@ -1,7 +1,7 @@
 """The optimizer step of the training loop as ONE multi-tensor HIP kernel (``csrc/stepops.hip``, ``obman_adam_step``).
 
-The reference builds ``torch.optim.Adam(model.parameters(), lr, weight_decay)`` (``traineval.py:104-111``) and calls ``step()`` once
-per batch (``epochpass3d.py:103-105``).  ``ObmanAdam`` IS a ``torch.optim.Adam`` (constructor, ``param_groups``, ``state_dict`` /
+The reference builds ``torch.optim.Adam(model.parameters(), lr, weight_decay)`` (``traineval.py:112-116``) and calls ``step()`` once
+per batch (``epochpass3d.py:86-91``).  ``ObmanAdam`` IS a ``torch.optim.Adam`` (constructor, ``param_groups``, ``state_dict`` /
 ``load_state_dict`` layout with ``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter - checkpoints written by either load into the
 other), with ``step()`` replaced:
 
@@ -24,7 +24,7 @@ from . import _lib, ops
 class ObmanAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **kw):
         if amsgrad or kw.get("maximize"):
-            raise ValueError("ObmanAdam implements plain Adam (traineval.py:104-111): no amsgrad / maximize")
+            raise ValueError("ObmanAdam implements plain Adam (traineval.py:112-116): no amsgrad / maximize")
         kw.pop("fused", None)
         kw.pop("capturable", None)
         kw.pop("foreach", None)

@@ -28,7 +28,7 @@ def read_losses(losses):
 
 
 def make_optimizer(model, name="adam", lr=1e-4, momentum=0.9, weight_decay=0.0, capturable=False):
-    """traineval.py:104-127 (defaults nets3dopts.py:249-273).  ``capturable``: the step may be recorded into a hipGraph
+    """traineval.py:112-127 (defaults nets3dopts.py:249-273).  ``capturable``: the step may be recorded into a hipGraph
     (``GraphedTrainStep``): Adam keeps its step counters on the device and never reads them on the host."""
     params = [p for p in model.parameters() if p.requires_grad]
     if name == "adam":
@@ -217,7 +217,7 @@ class GraphedTrainStep:
             self.watchdog_wait = wait_for_watchdog(self.buckets, dev)
         from . import ops
 
-        mark = len(ops._CAPTURED_TERM_WEIGHTS)
+        owned_before = set(ops._CAPTURE_OWNED)
         self.graph = torch.cuda.CUDAGraph()
         if self.mode == "single":
             with torch.cuda.graph(self.graph):
@@ -231,8 +231,10 @@ class GraphedTrainStep:
                     self.total, self.results, self.losses = train_step(model, optimizer, self.static, b)
             finally:
                 b.capturing = False
-        self.term_weights = list(ops._CAPTURED_TERM_WEIGHTS[mark:])  # keeps the tensors the graph reads alive; [(values, tensor)]
-        del ops._CAPTURED_TERM_WEIGHTS[mark:]
+        # the loss-weight tensors this capture took out of ops' cache: kept alive here; [(values, tensor)] (a key another, uncollected
+        # capture already owned stays with ops._CAPTURE_OWNED)
+        mine = [k for k in ops._CAPTURE_OWNED if k not in owned_before]
+        self.term_weights = [(k[1], ops._CAPTURE_OWNED.pop(k)) for k in mine]
         self._lambdas = _lambda_signature(model)
         if snapshot is not None:
             with torch.no_grad():

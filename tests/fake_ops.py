@@ -124,7 +124,7 @@ def laplacian_loss(verts, row_ptr, col, val):
 
 
 def affine_points(verts, scale=None, trans=None):
-    """atlasbranch.py:136-141, the reference's own operations."""
+    """atlasbranch.py:133-138, the reference's own operations."""
     pts = verts if scale is None else scale.unsqueeze(1) * verts
     return pts if trans is None else pts + trans.unsqueeze(1)
 

@@ -1,11 +1,11 @@
 """GPU: the round-6 step operators (csrc/stepops.hip) against the stock torch operations they replace.
 
-* K11 ``optim.ObmanAdam`` == ``torch.optim.Adam`` (traineval.py:104-111) over several steps, tensors of awkward sizes, a
+* K11 ``optim.ObmanAdam`` == ``torch.optim.Adam`` (traineval.py:112-116) over several steps, tensors of awkward sizes, a
   channels_last filter, weight decay, a parameter that skips steps, checkpoints that move between the two optimizers, bf16 shadows
   bit-equal to ``p.bfloat16()``;
-* K12 ``ops.affine_points`` == ``scale.unsqueeze(1) * verts + trans.unsqueeze(1)`` (atlasbranch.py:136-141), bit-exact forward;
-* K13 ``ops.mse_terms`` == ``torch_f.mse_loss`` per term (manobranch.py:251-318, atlasbranch.py:213-232);
-* K14 ``ops.gt_object_stats`` == ``gt.mean(1)``, ``gt - centroids``, ``norm(centred, 2, 2).max(1)`` (atlasbranch.py:219-229);
+* K12 ``ops.affine_points`` == ``scale.unsqueeze(1) * verts + trans.unsqueeze(1)`` (atlasbranch.py:133-138), bit-exact forward;
+* K13 ``ops.mse_terms`` == ``torch_f.mse_loss`` per term (manobranch.py:251-318, atlasbranch.py:211-228);
+* K14 ``ops.gt_object_stats`` == ``gt.mean(1)``, ``gt - centroids``, ``norm(centred, 2, 2).max(1)`` (atlasbranch.py:211-222);
 * ``ops.shadow_conv2d`` == the autocast convolution it replaces, and notices a filter somebody else has written.
 The torch side runs on the HOST in fp32 (the oracle convention of this suite: the reference's CPU path)."""
 import copy
