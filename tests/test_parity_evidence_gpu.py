@@ -176,10 +176,13 @@ BF16_VS_ORACLE = {
 _HARD = ("penetration_loss", "attraction_loss", "contact_loss", "max_penetr", "mean_penetr", "contact_auc")
 
 
-def _check_flavour(name, m, b):
+def _soft(m):
     soft = {k: v for k, v in m["terms"].items() if k not in _HARD}
     m["worst_soft_term"] = max(soft, key=soft.get)
     m["worst_soft"] = soft[m["worst_soft_term"]]
+
+
+def _check_flavour(name, m, b):
     assert m["total"] <= b["total"], (name, m)
     assert m["worst_soft"] <= b["soft"], (name, m)
     assert m["objpoints3d_of_scale"] <= b["points"] and m["objpoints3d_rms_of_scale"] <= b["points_rms"], (name, m)
@@ -197,6 +200,7 @@ def test_configs2_dec_bf16_bs64_256_matches_the_bf16_oracle():
     m, (_, out, _), (_, o_res, _) = _run_both("c3", 64, 256, False, _DOWNSTREAM, flavour="dec_bf16")
     w = o_res["objpoints3d"].detach()
     m["objpoints3d_rms_of_scale"] = float((out["objpoints3d"].detach().cpu() - w).square().mean().sqrt() / w.abs().max())
+    _soft(m)
     record_measurement("configs2_dec_bf16_bs64_256_vs_bf16_oracle", m)
     _check_flavour("dec_bf16", m, BF16_VS_ORACLE["dec_bf16"])
 
@@ -212,6 +216,7 @@ def test_configs2_all_bf16_bs16_256_matches_the_autocast_bf16_oracle():
     m, (_, out, _), (_, o_res, _) = _run_both("c3", 16, 256, False, _DOWNSTREAM, flavour="all_bf16")
     w = o_res["objpoints3d"].detach()
     m["objpoints3d_rms_of_scale"] = float((out["objpoints3d"].detach().cpu() - w).square().mean().sqrt() / w.abs().max())
+    _soft(m)
     record_measurement("configs2_all_bf16_bs16_256_vs_autocast_oracle", m)
     _check_flavour("all_bf16", m, BF16_VS_ORACLE["all_bf16"])
 
