@@ -398,7 +398,7 @@ def chamfer_roofline(batch, n_pred, n_gt, steps, prof):
         # round 6, csrc/pairmin.hip fused sweep: every pair evaluated ONCE (the long side as queries, the short side's minima from the
         # same distances); algorithmic bytes of the whole forward: 12 B in per point, 8 B out (minimum, index) per point of both sides
         launches = [entry("pairmin_fwd_kernel<10, true> (fused sweep: both directions from one evaluation of every pair, %d x %d x %d)"
-                          % (batch, n_pred, n_gt), 20.0 * (n_pred + n_gt) * batch, f_ms, f_n, flop / 2, "both")]
+                          % (batch, n_pred, n_gt), 20.0 * (n_pred + n_gt) * batch, f_ms, f_n, flop, "both")]  # the whole once-per-pair count: this launch IS both directions
     else:
         launches = [entry("pairmin_fwd_kernel (both directions in one launch, %d samples)" % batch, 20.0 * (n_pred + n_gt) * batch,
                           f_ms, f_n, flop)]
