@@ -80,13 +80,16 @@ def bench_tile_sweep():
     The tile cap is read once per process (OBMAN_PM_TILE), so this re-executes itself per value."""
     import subprocess
 
+    # round 6: the product path at this size is the fused sweep, whose reference side (600 ground-truth points = 9.6 KB) is ONE LDS tile by
+    # construction - the tile parameter only exists for the two independent sweeps (the checker path, OBMAN_PM_FUSED=0), where the
+    # ground truth -> predicted direction stages 64 050 references through LDS tile by tile
     for tile in (256, 512, 1024, 2048, 3072):
-        env = dict(os.environ, OBMAN_PM_TILE=str(tile), OBMAN_KBENCH_ONE="1")
+        env = dict(os.environ, OBMAN_PM_TILE=str(tile), OBMAN_KBENCH_ONE="1", OBMAN_PM_FUSED="0")
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "chamfer"], env=env, capture_output=True, text=True).stdout
         for line in out.splitlines():
             if line.startswith("{"):
                 d = json.loads(line)
-                print(json.dumps(dict(kernel="chamfer_tile_sweep", tile_points=tile, lds_bytes=tile * 16, **{k: d[k] for k in ("n_pred", "fwd_us", "fwd_Tpairs_per_s")})), flush=True)
+                print(json.dumps(dict(kernel="chamfer_tile_sweep", path="two independent sweeps (OBMAN_PM_FUSED=0)", tile_points=tile, lds_bytes=tile * 16, **{k: d[k] for k in ("n_pred", "fwd_us", "fwd_Tpairs_per_s")})), flush=True)
 
 
 def bench_mano():
