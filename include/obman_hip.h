@@ -275,7 +275,8 @@ int obman_imgstream_fwd(const uint8_t* src, int B, int pitch_h, int pitch_w, con
  * `tensors` is a HOST array; every pointer in it is a device pointer to n contiguous fp32 elements in the parameter's own
  * memory order (p, g, m, v alike).  `step` is the tensor's step counter (device fp32, incremented by this call before use,
  * as torch's capturable Adam keeps it).  `shadow_bf16` (NULL = none): receives bf16(p_new) - the copy a bf16-autocast
- * convolution reads, so that no per-step cast kernel is needed (obman_bf16_shadow initialises it). */
+ * convolution reads, so that no per-step cast kernel is needed (obman_bf16_shadow initialises it).  The hyper-parameters are doubles, as
+ * torch holds them: 1 - beta2 is formed in double (0.001, not the 0.00099998713 of fp32 arithmetic on the rounded 0.999f). */
 typedef struct obman_adam_tensor {
   float* p;
   const float* g;
@@ -285,8 +286,8 @@ typedef struct obman_adam_tensor {
   float* step;
   long n;
 } obman_adam_tensor;
-int obman_adam_step(const obman_adam_tensor* tensors, int count, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, obman_stream_t stream);
+int obman_adam_step(const obman_adam_tensor* tensors, int count, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, obman_stream_t stream);
 int obman_bf16_shadow(const float* src, uint16_t* dst, long n, obman_stream_t stream);
 
 /* ---- K12: objpoints3d = scale * verts + trans ---------------------------------------------------

@@ -45,7 +45,7 @@ _SIGNATURES = {
     "obman_bnpool_bwd_bf16": (_c_int, "ppppp" "iiii" "i" "pppp" "p"),
     "obman_imgstream_ws_bytes": (_c_long, "iii"),
     "obman_imgstream_fwd": (_c_int, "piiip" "ii" "iii" "pp" "pp" "p"),
-    "obman_adam_step": (_c_int, "pi" "fffff" "p"),
+    "obman_adam_step": (_c_int, "pi" "ddddd" "p"),
     "obman_bf16_shadow": (_c_int, "ppl" "p"),
     "obman_affine_points_fwd": (_c_int, "ppp" "ii" "p" "p"),
     "obman_affine_points_ws_floats": (_c_long, "i"),
@@ -62,7 +62,7 @@ _SIGNATURES = {
     "obman_mano_bwd_scratch_floats": (_c_int, "i"),
     "obman_mano_lbs_bwd": (_c_int, "pppppp" "iiiii" "ppp" "p"),
 }
-_KIND = {"p": _c_void_p, "i": _c_int, "l": _c_long, "f": _c_float}
+_KIND = {"p": _c_void_p, "i": _c_int, "l": _c_long, "f": _c_float, "d": ctypes.c_double}
 _lib = None
 _fp = ctypes.c_void_p
 

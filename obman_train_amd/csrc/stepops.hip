@@ -54,7 +54,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p -= k.lr_over_bc1 * m / denom;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamBatch b, float lr, float beta1, float beta2, float eps, float wd) {
+// lr, beta1, beta2 arrive as DOUBLES (what torch.optim.Adam holds): 1 - beta2 formed in fp32 from the rounded 0.999f is 1.3e-5 off
+// the 0.001 every torch implementation multiplies by (first version: exp_avg_sq drifted from torch's by exactly that factor)
+__global__ __launch_bounds__(256) void adam_kernel(AdamBatch b, double lr, double beta1, double beta2, float eps, float wd) {
   // which tensor: binary search of the block id in the (scalar) prefix table
   int lo = 0, hi = b.count;
   while (hi - lo > 1) {
@@ -70,9 +72,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch b, float lr, float 
   unsigned short* __restrict__ sh = b.shadow[t];
   const double step = (double)*b.step[t];  // already incremented by adam_tick_kernel
   AdamK k;
-  k.lr_over_bc1 = (float)((double)lr / (1.0 - pow((double)beta1, step)));
-  k.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
-  k.beta1w = 1.f - beta1; k.beta2 = beta2; k.beta2w = 1.f - beta2; k.eps = eps; k.wd = wd;
+  k.lr_over_bc1 = (float)(lr / (1.0 - pow(beta1, step)));
+  k.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, step));
+  k.beta1w = (float)(1.0 - beta1); k.beta2 = (float)beta2; k.beta2w = (float)(1.0 - beta2); k.eps = eps; k.wd = wd;
   const bool vec = ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) | reinterpret_cast<size_t>(v)) & 15) == 0 &&
                    (reinterpret_cast<size_t>(sh) & 7) == 0;
 #pragma unroll
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(256) void gt_stats_kernel(const float* __restrict__
 
 extern "C" {
 
-int obman_adam_step(const obman_adam_tensor* tensors, int count, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, obman_stream_t stream) {
+int obman_adam_step(const obman_adam_tensor* tensors, int count, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, obman_stream_t stream) {
   if (count < 0 || (count > 0 && !tensors)) return -1;
   hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < count; base += ADAM_MAX) {
@@ -273,7 +275,7 @@ int obman_adam_step(const obman_adam_tensor* tensors, int count, float lr, float
     adam_tick_kernel<<<1, ADAM_MAX, 0, st>>>(b);
     OBMAN_LAUNCH_CHECK();
     if (blocks > 0) {
-      adam_kernel<<<blocks, 256, 0, st>>>(b, lr, beta1, beta2, eps, weight_decay);
+      adam_kernel<<<blocks, 256, 0, st>>>(b, lr, beta1, beta2, (float)eps, (float)weight_decay);
       OBMAN_LAUNCH_CHECK();
     }
   }

@@ -51,46 +51,75 @@ class ObmanAdam(torch.optim.Adam):
                 loss = closure()
         lib = _lib.lib()
         stream = torch.cuda.current_stream().cuda_stream
-        for group in self.param_groups:
-            todo = []
-            for p in group["params"]:
-                g = p.grad
-                if g is None:
-                    continue
-                if g.is_sparse:
-                    raise RuntimeError("ObmanAdam does not support sparse gradients")
-                st = self._init_state(p)
-                m, v = st["exp_avg"], st["exp_avg_sq"]
-                if g.stride() != p.stride() or not ops._is_dense(p):
-                    if not ops._is_dense(p):
-                        raise RuntimeError("ObmanAdam needs dense parameters (contiguous or channels_last)")
-                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)  # element order of the parameter
-                if m.stride() != p.stride():  # a state loaded from a checkpoint written with another layout
-                    m = st["exp_avg"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(m)
-                    v = st["exp_avg_sq"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(v)
-                step = st["step"]
-                if not (torch.is_tensor(step) and step.is_cuda and step.dtype == torch.float32):
-                    step = st["step"] = torch.as_tensor(float(step), dtype=torch.float32, device=p.device)
-                sh = getattr(p, "_obman_shadow", None)
-                if sh is not None and sh.stride() != p.stride():
-                    sh = p._obman_shadow = ops.bf16_shadow(p.detach())  # the parameter was re-laid out (channels_last) after the shadow was made
-                    p._obman_shadow_version = p._version
-                todo.append((p, g, m, v, sh, step))
-            if not todo:
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
                 continue
-            arr = (_lib.AdamTensor * len(todo))()
-            for i, (p, g, m, v, sh, step) in enumerate(todo):
-                a = arr[i]
-                a.p, a.g, a.m, a.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
-                a.shadow_bf16 = None if sh is None else sh.data_ptr()
-                a.step, a.n = step.data_ptr(), p.numel()
+            cache = self._plans.get(gi) if hasattr(self, "_plans") else None
+            if cache is None or not self._refresh(cache, params):
+                cache = self._build(params)
+                if not hasattr(self, "_plans"):
+                    self._plans = {}
+                self._plans[gi] = cache
             b1, b2 = group["betas"]
             lr = group["lr"]
             if torch.is_tensor(lr):
                 lr = float(lr)
-            _lib.check(lib.obman_adam_step(ctypes.addressof(arr), len(todo), float(lr), float(b1), float(b2), float(group["eps"]),
+            _lib.check(lib.obman_adam_step(cache["addr"], len(params), float(lr), float(b1), float(b2), float(group["eps"]),
                                            float(group["weight_decay"]), stream), "obman_adam_step")
         return loss
+
+    def _build(self, params):
+        """The launch's descriptor table (host array of device pointers) for this set of parameters; everything but the gradient
+        pointers is constant from step to step, so ``_refresh`` only rewrites those (the table was rebuilt field by field every step
+        at first: ~0.5 ms of host time per step, in a step whose enqueue time is within 10 % of its GPU time)."""
+        arr = (_lib.AdamTensor * len(params))()
+        keep = []
+        for i, p in enumerate(params):
+            g = p.grad
+            if g.is_sparse:
+                raise RuntimeError("ObmanAdam does not support sparse gradients")
+            if not ops._is_dense(p):
+                raise RuntimeError("ObmanAdam needs dense parameters (contiguous or channels_last)")
+            st = self._init_state(p)
+            if st["exp_avg"].stride() != p.stride():  # a state loaded from a checkpoint written with another layout
+                st["exp_avg"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st["exp_avg"])
+                st["exp_avg_sq"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st["exp_avg_sq"])
+            step = st["step"]
+            if not (torch.is_tensor(step) and step.is_cuda and step.dtype == torch.float32):
+                step = st["step"] = torch.as_tensor(float(step), dtype=torch.float32, device=p.device)
+            sh = getattr(p, "_obman_shadow", None)
+            if sh is not None and sh.stride() != p.stride():
+                sh = p._obman_shadow = ops.bf16_shadow(p.detach())  # the parameter was re-laid out (channels_last) after the shadow was made
+                p._obman_shadow_version = p._version
+            if g.stride() != p.stride():
+                g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)  # element order of the parameter
+            a = arr[i]
+            a.p, a.g, a.m, a.v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            a.shadow_bf16 = None if sh is None else sh.data_ptr()
+            a.step, a.n = step.data_ptr(), p.numel()
+            keep.append((p, st["exp_avg"], st["exp_avg_sq"], step, sh, g))
+        return {"arr": arr, "addr": ctypes.addressof(arr), "keep": keep, "ids": [id(p) for p in params],
+                "ptrs": [p.data_ptr() for p in params], "strides": [p.stride() for p in params]}
+
+    def _refresh(self, cache, params):
+        """Same parameters, same storage, same state tensors as when the table was built?  Then only the gradient pointers change."""
+        if len(params) != len(cache["ids"]):
+            return False
+        arr, keep = cache["arr"], cache["keep"]
+        for i, p in enumerate(params):
+            kp, m, v, step, sh, _ = keep[i]
+            if kp is not p or p.data_ptr() != cache["ptrs"][i] or p.stride() != cache["strides"][i]:
+                return False
+            st = self.state[p]
+            if st.get("exp_avg") is not m or st.get("exp_avg_sq") is not v or st.get("step") is not step or getattr(p, "_obman_shadow", None) is not sh:
+                return False  # load_state_dict / a re-created shadow: rebuild
+            g = p.grad
+            if g.stride() != cache["strides"][i]:
+                g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+            arr[i].g = g.data_ptr()
+            keep[i] = (kp, m, v, step, sh, g)  # the gradient stays referenced until the launch below has been enqueued
+        return True
 
 
 def attach_bf16_shadows(module):

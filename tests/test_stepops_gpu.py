@@ -113,6 +113,8 @@ def test_adam_writes_the_bf16_shadow_and_records_into_a_graph():
     ref_p, ref_q = p.detach().clone(), q.detach().clone()
     ref = torch.optim.Adam([torch.nn.Parameter(ref_p.cpu()), torch.nn.Parameter(ref_q.cpu())], lr=1e-2)
     ref.load_state_dict(copy.deepcopy(opt.state_dict()))
+    for grp in ref.param_groups:
+        grp["capturable"] = False  # ObmanAdam's groups say capturable (device-side step counters); the host reference cannot be
     graph = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
