@@ -50,7 +50,7 @@ class ObmanAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.lib()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = ops._stream()
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
