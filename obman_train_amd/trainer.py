@@ -88,7 +88,7 @@ def wait_for_watchdog(buckets, dev, timeout_s=5.0):
     (``torch._C._distributed_c10d._dump_nccl_trace``): the sequence number of the last collective it has seen complete AND dropped
     from its list.  When that has reached ``last_enqueued_collective`` for every group, no eager work is left for it to query.  The
     record exists when the flight recorder is on (``TORCH_NCCL_TRACE_BUFFER_SIZE`` > 0: ``dp.init_rccl`` sets 64 entries; measured:
-    the condition turns true 60 ms after the synchronize, ``tools/r06/watchdog_probe.py``).  Where it does not (another torch
+    the condition turns true 60 ms after the synchronize, ``tools/archive/r06/watchdog_probe.py``).  Where it does not (another torch
     build, the recorder switched off by the caller) the fallback is round 5's measured one: five watchdog poll periods of sleep.
     Returns a dict saying which of the two ended the wait (``bench.py`` prints it)."""
     import pickle

@@ -1,5 +1,5 @@
 """Which aten operators of one train step launch device kernels OUTSIDE the convolutions and this package's HIP kernels, from where?
-   gpurun -- 'CFG=c3 ENC=bf16 DEC=bf16 python tools/r06/aten_ops.py'      (the "other PyTorch kernels" of configs[2])"""
+   gpurun -- 'CFG=c3 ENC=bf16 DEC=bf16 python tools/archive/r06/aten_ops.py'      (the "other PyTorch kernels" of configs[2])"""
 import collections
 import os
 import sys

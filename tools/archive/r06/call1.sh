@@ -8,4 +8,4 @@ for i in 1 2 3; do
 import json,sys
 d=json.load(open('$out/r06_fd_graph_$i.json')); print('fd-graph', d['ms_per_step'], d['host_enqueue_ms'])"
 done
-CFG=c3 ENC=bf16 DEC=bf16 timeout 600 python tools/r06/aten_ops.py > $out/r06_aten_ops_c3_bf16.txt 2>$out/r06_aten_ops.err; tail -40 $out/r06_aten_ops_c3_bf16.txt
+CFG=c3 ENC=bf16 DEC=bf16 timeout 600 python tools/archive/r06/aten_ops.py > $out/r06_aten_ops_c3_bf16.txt 2>$out/r06_aten_ops.err; tail -40 $out/r06_aten_ops_c3_bf16.txt

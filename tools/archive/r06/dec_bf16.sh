@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: bf16 decoder A/B on one box: parity tests, then per-kernel rocprof of tools/kbench.py decoder for each knob setting
-#   KNOB=OBMAN_DEC_TN2W VARIANTS="1 0" TAG=tn2w bash tools/r06/dec_bf16.sh
+#   KNOB=OBMAN_DEC_TN2W VARIANTS="1 0" TAG=tn2w bash tools/archive/r06/dec_bf16.sh
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd $GRAFT_REPO_ROOT

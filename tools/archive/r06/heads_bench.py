@@ -1,5 +1,5 @@
 """The small Linear layers of the MANO / Atlas heads at bs 64: F.linear (addmm with a bias epilogue: hipBLASLt) against mm + add, per shape.
-   gpurun -- 'python tools/r06/heads_bench.py'"""
+   gpurun -- 'python tools/archive/r06/heads_bench.py'"""
 import torch
 import torch.nn.functional as F
 

@@ -1,5 +1,5 @@
 """Where does the HOST spend its time in one eager train step?  cProfile over 30 steps (GPU work is asynchronous: this is enqueue cost).
-   gpurun -- 'CFG=c3 ENC=bf16 DEC=bf16 python tools/r06/host_profile.py'"""
+   gpurun -- 'CFG=c3 ENC=bf16 DEC=bf16 python tools/archive/r06/host_profile.py'"""
 import cProfile
 import os
 import pstats

@@ -1,5 +1,5 @@
 """What can a Python thread observe about ProcessGroupNCCL's watchdog having dropped finished eager work?  (1-rank RCCL group)
-   gpurun -- 'python tools/r06/watchdog_probe.py'"""
+   gpurun -- 'python tools/archive/r06/watchdog_probe.py'"""
 import os
 import pickle
 import sys
