@@ -957,13 +957,18 @@ def linear(x, weight, bias=None, relu=False):
     return _Linear.apply(x, weight, bias, bool(relu))
 
 
+import os as _os
+
+_MLP_ON = _os.environ.get("OBMAN_MLP", "1") not in ("", "0")  # A/B: 0 = the modules' own forward (library GEMMs)
+
+
 def mlp(module, x):
     """``module(x)`` for an ``nn.Linear`` or an ``nn.Sequential`` of ``nn.Linear`` / ``nn.ReLU`` (/ inactive ``nn.Dropout``) - the head
     regressors of ManoBranch and AtlasBranch (manobranch.py:56-81, atlasbranch.py:44-69) - through ``linear`` with the ReLU fused.  The
     modules keep their parameters (state-dict names unchanged).  Anything else (other layers, other dtypes, off-device or N-D inputs)
     is the module's own forward."""
     nn = torch.nn
-    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2) or torch.is_autocast_enabled():
+    if not _MLP_ON or not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2) or torch.is_autocast_enabled():
         return module(x)
     layers = [module] if isinstance(module, nn.Linear) else (list(module) if isinstance(module, nn.Sequential) else None)
     if layers is None:
