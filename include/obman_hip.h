@@ -322,16 +322,6 @@ int obman_mse_terms_bwd(const obman_mse_term* terms, int count, const float* g_o
  * (atlasbranch.py:211-222).  gt [B,N,3] -> centroid [B,3], centred [B,N,3], maxnorm [B].  No gradient (targets). */
 int obman_gt_object_stats(const float* gt, int B, int N, float* centroid, float* centred, float* maxnorm, obman_stream_t stream);
 
-/* ---- K15: the fully connected layers of the heads -----------------------------------------------
- * Replaces nn.Linear (+ nn.ReLU) of ManoBranch's regressor (manobranch.py:56-81,118-121: base_layer, pose_reg, shape_reg) and of
- * AtlasBranch's translation / scale heads (atlasbranch.py:44-69,112-116) at batch sizes where a library GEMM is a launch-latency
- * problem.  x [B,K], w [N,K] (nn.Linear's layout), b [N] or NULL, y [B,N] = act(x w^T + b), relu = 0 / 1.  Backward: gy [B,N], y
- * (the forward's output; only read when relu = 1: the mask), dx [B,K] / dw [N,K] / db [N] may each be NULL (db needs dw).
- * Deterministic (fixed summation order). */
-int obman_linear_fwd(const float* x, const float* w, const float* b, int B, int K, int N, int relu, float* y, obman_stream_t stream);
-int obman_linear_bwd(const float* gy, const float* y, const float* x, const float* w, int B, int K, int N, int relu, float* dx, float* dw,
-                     float* db, obman_stream_t stream);
-
 /* ---- measurement utility (not on the product path) ----------------------------------------------
  * obman_prof_enable(1) makes the launchers bracket their main kernel with HIP events on the launch
  * stream (pool of 8192 records, reset by every enable call); obman_prof_summary synchronises and

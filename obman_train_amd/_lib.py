@@ -54,8 +54,6 @@ _SIGNATURES = {
     "obman_mse_terms_fwd": (_c_int, "pi" "pp" "p"),
     "obman_mse_terms_bwd": (_c_int, "pi" "p" "p"),
     "obman_gt_object_stats": (_c_int, "p" "ii" "ppp" "p"),
-    "obman_linear_fwd": (_c_int, "ppp" "iiii" "p" "p"),
-    "obman_linear_bwd": (_c_int, "pppp" "iiii" "ppp" "p"),
     "obman_prof_enable": (_c_int, "i"),
     "obman_prof_summary": (_c_int, "ipp"),
     "obman_mano_model_floats": (_c_int, ""),

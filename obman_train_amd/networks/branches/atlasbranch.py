@@ -69,7 +69,7 @@ class AtlasBranch(nn.Module):
         """Random points on the unit sphere (atlasbranch.py:78-108), one set per sample, through the fused decoder
         (``obman_pointgen_fwd/bwd`` with ``grid_per_sample``): the [B,3+C,points_nb] concat is not built here either.
         ``rand_grid`` (test hook): the normal draws [B,3,points_nb] the reference would make, to compare like with like."""
-        trans = ops.mlp(self.decode_trans, img_features) if self.predict_trans else None
+        trans = self.decode_trans(img_features) if self.predict_trans else None
         B = img_features.shape[0]
         if rand_grid is None:
             rand_grid = torch.randn((B, 3, self.points_nb), device=img_features.device, dtype=img_features.dtype)
@@ -78,8 +78,8 @@ class AtlasBranch(nn.Module):
         return self._assemble(verts, trans, None, with_faces=False)
 
     def forward_inference(self, img_features, separate_encoder_features=None):
-        trans = ops.mlp(self.decode_trans, img_features) if self.predict_trans else None
-        scale = ops.mlp(self.decode_scale, img_features) if self.predict_scale else None
+        trans = self.decode_trans(img_features) if self.predict_trans else None
+        scale = self.decode_scale(img_features) if self.predict_scale else None
         dec_features = separate_encoder_features if self.separate_encoder else img_features
         verts = self._decode(self.test_verts, dec_features)
         if scale is not None and trans is None:

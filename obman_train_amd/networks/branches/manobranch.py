@@ -65,10 +65,9 @@ class ManoBranch(nn.Module):
     def forward(self, inp, sides, root_palm=False, shape=None, pose=None, use_stereoshape=False):
         if use_stereoshape:
             raise NotImplementedError("stereo shape prior: HandNet always passes use_stereoshape=False (handnet.py:273)")
-        # the regressor's nn.Linear (+ ReLU) layers through ops.mlp: one launch per layer and direction at this batch size
-        base = ops.mlp(self.base_layer, inp)
-        pose = ops.mlp(self.pose_reg, base)
-        shape = ops.mlp(self.shape_reg, base) if self.use_shape else None
+        base = self.base_layer(inp)
+        pose = self.pose_reg(base)
+        shape = self.shape_reg(base) if self.use_shape else None
         B, dev = inp.shape[0], inp.device
         side = self._side_tensor(list(sides), B, dev)
         mano_pose = pose

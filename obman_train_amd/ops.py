@@ -914,75 +914,3 @@ def shadow_conv2d(conv, x):
     with torch.autocast("cuda", enabled=False):
         return _ShadowConv2d.apply(x.to(torch.bfloat16), w, sh, list(conv.stride), list(conv.padding), list(conv.dilation),
                                    conv.groups)
-
-
-class _Linear(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w, b, relu):
-        x, w = _dev(x, "x"), _dev(w, "weight")
-        b = _dev(b, "bias") if b is not None else None
-        B, K, N = x.shape[0], x.shape[1], w.shape[0]
-        if w.shape[1] != K or (b is not None and b.shape[0] != N):
-            raise ValueError("linear: x [B,%d] does not match weight %s / bias" % (K, tuple(w.shape)))
-        y = torch.empty((B, N), dtype=torch.float32, device=x.device)
-        if B:
-            _lib.check(_lib.lib().obman_linear_fwd(x.data_ptr(), w.data_ptr(), _ptr(b), B, K, N, int(relu), y.data_ptr(), _stream()),
-                       "obman_linear_fwd")
-        ctx.relu, ctx.has_bias = bool(relu), b is not None
-        ctx.save_for_backward(x, w, y if relu else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
-        gy = _dev(gy, "grad")
-        B, K, N = x.shape[0], x.shape[1], w.shape[0]
-        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx = torch.empty_like(x) if need_x else None
-        dw = torch.empty_like(w) if (need_w or need_b) else None
-        db = torch.empty(N, dtype=torch.float32, device=x.device) if need_b else None
-        if B:
-            _lib.check(_lib.lib().obman_linear_bwd(gy.data_ptr(), _ptr(y), x.data_ptr(), w.data_ptr(), B, K, N, int(ctx.relu), _ptr(dx), _ptr(dw),
-                                                   _ptr(db), _stream()), "obman_linear_bwd")
-        else:
-            for t in (dx, dw, db):
-                if t is not None:
-                    t.zero_()
-        return dx, (dw if need_w else None), db, None
-
-
-def linear(x, weight, bias=None, relu=False):
-    """``relu(F.linear(x, weight, bias))`` (or without the ReLU) for a 2-D fp32 ROCm ``x`` as ONE launch forward and two backward
-    (``csrc/linear.hip``): the head layers at batch size ~64, where a library GEMM + bias + ReLU is 3 launches of 5 - 35 us each."""
-    return _Linear.apply(x, weight, bias, bool(relu))
-
-
-import os as _os
-
-_MLP_ON = _os.environ.get("OBMAN_MLP", "1") not in ("", "0")  # A/B: 0 = the modules' own forward (library GEMMs)
-
-
-def mlp(module, x):
-    """``module(x)`` for an ``nn.Linear`` or an ``nn.Sequential`` of ``nn.Linear`` / ``nn.ReLU`` (/ inactive ``nn.Dropout``) - the head
-    regressors of ManoBranch and AtlasBranch (manobranch.py:56-81, atlasbranch.py:44-69) - through ``linear`` with the ReLU fused.  The
-    modules keep their parameters (state-dict names unchanged).  Anything else (other layers, other dtypes, off-device or N-D inputs)
-    is the module's own forward."""
-    nn = torch.nn
-    if not _MLP_ON or not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2) or torch.is_autocast_enabled():
-        return module(x)
-    layers = [module] if isinstance(module, nn.Linear) else (list(module) if isinstance(module, nn.Sequential) else None)
-    if layers is None:
-        return module(x)
-    i = 0
-    while i < len(layers):
-        m = layers[i]
-        if isinstance(m, nn.Linear) and m.weight.dtype == torch.float32 and m.weight.is_cuda:
-            relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
-            x = linear(x, m.weight, m.bias, relu)
-            i += 2 if relu else 1
-        elif isinstance(m, nn.Dropout) and (not m.training or m.p == 0):
-            i += 1
-        else:
-            x = m(x)
-            i += 1
-    return x

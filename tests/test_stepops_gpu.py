@@ -246,56 +246,3 @@ def test_shadow_conv_equals_the_autocast_convolution_and_notices_foreign_writes(
     # outside autocast, or without a shadow: the module itself
     out = ops.shadow_conv2d(conv, x)
     assert out.dtype == torch.float32
-
-
-@pytest.mark.parametrize("B,K,N,relu,bias", [(64, 512, 1024, True, True), (64, 1024, 256, True, True), (64, 256, 33, False, True),
-                                             (64, 256, 10, False, True), (64, 512, 256, True, True), (64, 256, 3, False, True),
-                                             (64, 256, 1, False, True), (70, 130, 37, True, True), (1, 5, 2, False, False),
-                                             (200, 21, 21, False, False), (3, 2048, 16, True, True)])
-def test_linear_matches_f_linear(B, K, N, relu, bias):
-    """K15 (csrc/linear.hip): the head layers of ManoBranch / AtlasBranch (manobranch.py:56-81, atlasbranch.py:44-69) against
-    ``relu(F.linear(x, w, b))`` and its autograd on the host: forward and all three gradients, the layers' real shapes plus ragged
-    ones (K, N not multiples of 4, B beyond one 64-row tile, a single row)."""
-    from obman_train_amd import ops
-
-    g = torch.Generator().manual_seed(B * 1000 + K + N)
-    x = torch.randn(B, K, generator=g)
-    w = torch.randn(N, K, generator=g) / K ** 0.5
-    b = torch.randn(N, generator=g) if bias else None
-    cot = torch.randn(B, N, generator=g)
-    hx, hw = x.clone().requires_grad_(), w.clone().requires_grad_()
-    hb = b.clone().requires_grad_() if bias else None
-    want = F.linear(hx, hw, hb)
-    if relu:
-        want = torch.relu(want)
-    (want * cot).sum().backward()
-    dx, dw = x.cuda().requires_grad_(), w.cuda().requires_grad_()
-    db = b.cuda().requires_grad_() if bias else None
-    got = ops.linear(dx, dw, db, relu=relu)
-    (got * cot.cuda()).sum().backward()
-    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=2e-5, atol=2e-5)
-    torch.testing.assert_close(dx.grad.cpu(), hx.grad, rtol=2e-5, atol=2e-5 * float(hx.grad.abs().max()))
-    torch.testing.assert_close(dw.grad.cpu(), hw.grad, rtol=2e-5, atol=2e-5 * float(hw.grad.abs().max()))
-    if bias:
-        torch.testing.assert_close(db.grad.cpu(), hb.grad, rtol=2e-5, atol=2e-5 * float(hb.grad.abs().max()))
-    got2 = ops.linear(dx.detach(), dw.detach(), None if db is None else db.detach(), relu=relu)
-    assert torch.equal(got2, got.detach())  # run to run identical
-
-
-def test_mlp_walks_the_reference_heads():
-    """``ops.mlp`` on the modules the reference builds - ``nn.Sequential(Linear, ReLU, Linear)`` (atlasbranch.py:44-69), the regressor's
-    ``[Linear, ReLU] x 2`` with an inactive Dropout in front (manobranch.py:56-66), a bare ``nn.Linear`` - equals the module's own forward;
-    modules it does not know (an active Dropout, a 3-D input) run as they are."""
-    from obman_train_amd import ops
-
-    torch.manual_seed(0)
-    nn = torch.nn
-    x = torch.randn(64, 512).cuda()
-    for mod in (nn.Sequential(nn.Linear(512, 256), nn.ReLU(), nn.Linear(256, 3)),
-                nn.Sequential(nn.Dropout(p=0.0), nn.Linear(512, 1024), nn.ReLU(), nn.Linear(1024, 256), nn.ReLU()),
-                nn.Linear(512, 33), nn.Sequential(nn.Linear(512, 10))):
-        mod = mod.cuda().train()
-        torch.testing.assert_close(ops.mlp(mod, x), mod(x), rtol=2e-5, atol=2e-5)
-    seq = nn.Sequential(nn.Linear(21, 21, bias=False)).cuda()
-    x3 = torch.randn(4, 3, 21).cuda()
-    assert torch.equal(ops.mlp(seq, x3), seq(x3))  # N-D input: the module itself
