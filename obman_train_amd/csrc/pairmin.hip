@@ -89,8 +89,14 @@ __device__ __forceinline__ void pm_wave_min8_lane63(float (&v)[8]) {
 // the lowest tile among equal minima is the one that holds the first index.  pairmin_resolve_kernel then re-evaluates the winning
 // tile's queries with the same pinned instruction sequence and takes the first equal one - values, arg-mins and tie rule are bit-identical to the
 // swapped-role sweep (tests/test_pairmin_gpu.py keeps that path as the checker: OBMAN_PM_FUSED=0).
-template <int QPT, bool RS>
+//
+// QS = false (RS only; the contact term's hand -> object direction, 778 x 16 050 / 64 050): ONLY the reference-side minima are
+// wanted and the wanted side is the short one.  The same sweep with the long side in the registers, without the per-query
+// bookkeeping (chunk minimum, compare, two selects per query and chunk) and without its merge buffers in LDS; before, this
+// direction ran as pairmin_fwd_kernel<2> with the 16 050 references split over three blocks and merged through 64-bit atomics.
+template <int QPT, bool RS, bool QS = true>
 __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir d1, PmGrid pg) {
+  static_assert(RS || QS, "a sweep without outputs");
   // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  All blocks
   // of one sample (every query tile, both directions: they read the same two point sets) take consecutive slots on ONE XCD,
   // so a sample's points are fetched from HBM by one L2 instead of by all eight (profiles/r01_chamfer_pmc.md: 3.5x the
@@ -109,7 +115,9 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
   }
   if (b >= pg.B) return;
   const PmDir d = dir == 0 ? d0 : d1;
-  if (d.omin == nullptr) return;
+  if constexpr (QS) {
+    if (d.omin == nullptr) return;
+  }
   if (tile >= d.qtiles * d.rsplit) return;
   const int qt = tile % d.qtiles, rs = tile / d.qtiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
   float4* sref = reinterpret_cast<float4*>(pm_smem);
   float(*s_val)[64 * QPT] = reinterpret_cast<float(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4));
   int(*s_grp)[64 * QPT] = reinterpret_cast<int(*)[64 * QPT]>(pm_smem + (size_t)d.tile * sizeof(float4) + 4 * 64 * QPT * sizeof(float));
-  float* s_rmin = reinterpret_cast<float*>(pm_smem + (size_t)d.tile * sizeof(float4) + 8 * 64 * QPT * sizeof(float));  // RS: [tile] reference-side minima
+  float* s_rmin = reinterpret_cast<float*>(pm_smem + (size_t)d.tile * sizeof(float4) + (QS ? 8 * 64 * QPT * sizeof(float) : 0));  // RS: [tile] reference-side minima
 
   static_assert(QPT % 2 == 0, "queries are processed as packed pairs");
   constexpr int QP = QPT / 2;
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
 #pragma unroll
           for (int u = 0; u < PM_CHUNK; ++u) rm[u] = __builtin_fminf(__builtin_fminf(rm[u], e[u][0]), e[u][1]);  // v_min3_f32
         }
+        if constexpr (QS) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const float m0 = __builtin_fminf(__builtin_fminf(e[0][h], e[1][h]), e[2][h]);  // v_min3_f32
@@ -188,6 +197,7 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
           const bool better = m < best[2 * p + h];
           best[2 * p + h] = better ? m : best[2 * p + h];
           bestj[2 * p + h] = better ? base + j : bestj[2 * p + h];
+        }
         }
       }
       if constexpr (RS) {
@@ -201,13 +211,15 @@ __global__ __launch_bounds__(PM_THREADS) void pairmin_fwd_kernel(PmDir d0, PmDir
     }
     if (!single) __syncthreads();
   }
+  if constexpr (QS) {
 #pragma unroll
   for (int k = 0; k < QPT; ++k) {
     s_val[wave][k * 64 + lane] = best[k];
     s_grp[wave][k * 64 + lane] = bestj[k];
   }
-  __syncthreads();
-  for (int t = tid; t < 64 * QPT; t += PM_THREADS) {
+  }
+  __syncthreads();  // (RS: also orders the waves' s_rmin stores before the block-wide read below)
+  for (int t = tid; QS && t < 64 * QPT; t += PM_THREADS) {
     const int qi = qt * (64 * QPT) + t;
     if (qi >= d.nq) continue;
     float bv = s_val[0][t];
@@ -722,12 +734,12 @@ int choose_qpt(int B, int nq, int nr) {
   return 2;
 }
 
-template <int QPT, bool RS = false>
+template <int QPT, bool RS = false, bool QS = true>
 void launch_fwd_t(dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b) {
   static const int xcd = [] { const char* e = getenv("OBMAN_PM_XCD"); return e ? atoi(e) : 1; }();  // A/B knob
   const PmGrid pg{(int)grid.x, (int)grid.z, (int)grid.y, xcd};
   const unsigned blocks = (unsigned)(((pg.B + 7) / 8) * 8) * grid.x * grid.z;  // samples padded to a multiple of 8 (one group per XCD slot)
-  pairmin_fwd_kernel<QPT, RS><<<dim3(blocks), PM_THREADS, smem, st>>>(a, b, pg);
+  pairmin_fwd_kernel<QPT, RS, QS><<<dim3(blocks), PM_THREADS, smem, st>>>(a, b, pg);
 }
 void launch_fwd(int qpt, dim3 grid, size_t smem, hipStream_t st, const PmDir& a, const PmDir& b, int kid) {
   ObmanProfScope prof(kid, st);
@@ -840,29 +852,33 @@ int launch_pairmin(const float* x, const float* y, int B, int Nx, int Ny, float*
   PmDir d0{x, y, min_x, idx_x, nullptr, Nx, Ny, 0, 1, Ny, PM_REF_TILE, nullptr};
   PmDir d1{y, x, min_y, idx_y, nullptr, Ny, Nx, 0, 1, Nx, PM_REF_TILE, nullptr};
   {
-    // Round 6, the fused sweep: both directions wanted, one side long (>= 8192 points: where the swapped-role direction needs the
-    // split path) and the other a single LDS tile.  The long side is the query side (10 per lane); the short side's minima come out
+    // Round 6, the fused sweep: the SHORT side's minima wanted (with or without the long side's), one side long (>= 8192 points:
+    // where the swapped-role direction needs the split path) and the other a single LDS tile.  The long side is the query side (10 per lane); the short side's minima come out
     // of the same distances (pairmin_fwd_kernel<10, true>) and pairmin_resolve_kernel finds their arg-mins.  OBMAN_PM_FUSED=0: the
     // two independent sweeps (the checker).
-    static const int fused_on = [] { const char* e = getenv("OBMAN_PM_FUSED"); return e ? atoi(e) : 1; }();
+    const char* fe = getenv("OBMAN_PM_FUSED");  // read per call: tests flip it inside one process to get the checker
+    const int fused_on = fe ? atoi(fe) : 1;
     const bool x_long = Nx >= Ny;
     const int nl = x_long ? Nx : Ny, ns = x_long ? Ny : Nx;
     const long need = (long)sizeof(u64) * B * ns;
-    if (fused_on && min_x && min_y && nl >= 8192 && ns <= PM_REF_TILE && ws && ws_bytes >= need) {
+    float* min_s = x_long ? min_y : min_x;  // minima of the short side = the reference side of this sweep
+    float* min_l = x_long ? min_x : min_y;
+    if (fused_on && min_s && nl >= 8192 && ns <= PM_REF_TILE && ws && ws_bytes >= need) {
       PmDir d = x_long ? d0 : d1;
       d.qtiles = obman_cdiv(d.nq, 640);
       d.tile = ((ns + 31) / 32) * 32;
       d.rs_ws = (u64*)ws;
       (void)obman_fill_u32(ws, 0xffffffffu, (size_t)2 * B * ns, st);
-      const size_t smem = (size_t)d.tile * sizeof(float4) + (size_t)8 * 64 * 10 * sizeof(float) + (size_t)d.tile * sizeof(float);
+      // only the short side wanted (the contact term's hand -> object minima): the sweep without the per-query bookkeeping
+      const bool qs = min_l != nullptr;
+      const size_t smem = (size_t)d.tile * sizeof(float4) + (qs ? (size_t)8 * 64 * 10 * sizeof(float) : 0) + (size_t)d.tile * sizeof(float);
       {
         ObmanProfScope prof(kid, st);
-        launch_fwd_t<10, true>(dim3(d.qtiles, B, 1), smem, st, d, d);
+        if (qs) launch_fwd_t<10, true>(dim3(d.qtiles, B, 1), smem, st, d, d);
+        else launch_fwd_t<10, true, false>(dim3(d.qtiles, B, 1), smem, st, d, d);
       }
       OBMAN_LAUNCH_CHECK();
-      const long nw = (long)B * ns;
-      (void)nw;
-      pairmin_resolve_kernel<<<((B + 7) / 8) * 8 * obman_cdiv(ns, 4), 256, 0, st>>>((const u64*)ws, d.q, d.r, B, d.nq, d.nr, 640, x_long ? min_y : min_x,
+      pairmin_resolve_kernel<<<((B + 7) / 8) * 8 * obman_cdiv(ns, 4), 256, 0, st>>>((const u64*)ws, d.q, d.r, B, d.nq, d.nr, 640, min_s,
                                                                                     x_long ? idx_y : idx_x);
       OBMAN_LAUNCH_CHECK();
       return 0;

@@ -149,13 +149,15 @@ def test_chamfer_single_launch_means_and_self_cleaning_sync_buffer():
         np.testing.assert_allclose(l2.cpu().numpy(), o2.numpy(), rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,nx,ny", [(2, 16050, 600), (3, 8192, 1), (2, 20000, 2048), (1, 600, 9000), (2, 64050, 600), (5, 8200, 33)])
-def test_fused_sweep_equals_the_two_independent_sweeps(B, nx, ny):
+@pytest.mark.parametrize("B,nx,ny", [(2, 16050, 600), (3, 8192, 1), (2, 20000, 2048), (1, 600, 9000), (2, 64050, 600), (5, 8200, 33), (2, 778, 16050)])
+def test_fused_sweep_equals_the_two_independent_sweeps(B, nx, ny, monkeypatch):
     """Round 6 (VERDICT r05 task 4): with one side >= 8192 points and the other a single LDS tile, a bidirectional call evaluates
-    every pair ONCE (csrc/pairmin.hip, pairmin_fwd_kernel<10, true> + pairmin_resolve_kernel).  The one-directional calls still run
-    the independent sweeps (queries in registers; the swapped-role direction with its split reference set and 64-bit merge): minima,
-    arg-mins and the tie rule must agree BIT FOR BIT - including duplicated points (first index wins), a far outlier, and samples
-    with NaN / inf coordinates."""
+    every pair ONCE (csrc/pairmin.hip, pairmin_fwd_kernel<10, true> + pairmin_resolve_kernel), and a call that wants only the
+    SHORT side's minima (the contact term: 778 hand vertices against the object's points) runs the same sweep without the
+    per-query bookkeeping (pairmin_fwd_kernel<10, true, false>).  The checker is OBMAN_PM_FUSED=0 (read per call): the independent
+    sweeps (queries in registers; the swapped-role direction with its split reference set and 64-bit merge).  Minima, arg-mins
+    and the tie rule must agree BIT FOR BIT - including duplicated points (first index wins), a far outlier, and samples with
+    NaN / inf coordinates."""
     from obman_train_amd import ops
 
     x, y = _rand(B, nx, 21, offset=10.0), _rand(B, ny, 22, offset=-4.0)
@@ -172,8 +174,18 @@ def test_fused_sweep_equals_the_two_independent_sweeps(B, nx, ny):
         short[1, 0, 2] = float("nan")
     xc, yc = x.cuda(), y.cuda()
     mx, ix, my, iy = ops.pairmin(xc, yc)
+    # the short side alone (RS-only sweep) against the bidirectional call
+    if nx >= ny:
+        _, _, ms_, is_ = ops.pairmin(xc, yc, want_x=False)
+        assert torch.equal(ms_.view(torch.int32), my.view(torch.int32)) and torch.equal(is_, iy)
+    else:
+        ms_, is_, _, _ = ops.pairmin(xc, yc, want_y=False)
+        assert torch.equal(ms_.view(torch.int32), mx.view(torch.int32)) and torch.equal(is_, ix)
+    monkeypatch.setenv("OBMAN_PM_FUSED", "0")  # the checker: two independent sweeps
     mx1, ix1, _, _ = ops.pairmin(xc, yc, want_y=False)
     _, _, my1, iy1 = ops.pairmin(xc, yc, want_x=False)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("OBMAN_PM_FUSED")
     assert torch.equal(mx.view(torch.int32), mx1.view(torch.int32)) and torch.equal(ix, ix1)
     assert torch.equal(my.view(torch.int32), my1.view(torch.int32)), (my != my1).nonzero()[:5]
     assert torch.equal(iy, iy1), ((iy != iy1).nonzero()[:5], iy[iy != iy1][:5], iy1[iy != iy1][:5])

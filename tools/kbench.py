@@ -75,6 +75,19 @@ def bench_chamfer():
             fwd_valu_TFLOPs=round(pairs * 5 / t_f / 1e12, 1))), flush=True)
 
 
+def bench_contactmin():
+    """The contact term's pair-min: 778 hand vertices against the object's points, ONLY the hand side's minima wanted
+    (networks/branches/contactloss.py).  Whole call by stream events (fill + sweep + resolve / unpack)."""
+    from obman_train_amd import ops
+
+    for B, n_obj in ((64, 16050), (64, 64050)):
+        hand = torch.randn(B, 778, 3, device="cuda") * 40
+        obj = torch.randn(B, n_obj, 3, device="cuda") * 40
+        t = timeit(lambda: ops.pairmin(hand, obj, want_y=False), iters=40, warmup=5)
+        print(json.dumps(dict(kernel="contact_pairmin", fused=os.environ.get("OBMAN_PM_FUSED", "1"), B=B, n_hand=778, n_obj=n_obj,
+                              call_us=round(t * 1e6, 1), Tpairs_per_s=round(B * 778.0 * n_obj / t / 1e12, 3))), flush=True)
+
+
 def bench_tile_sweep():
     """BASELINE.json configs[4]: LDS reference-tile sweep of the pair-min kernel at 25 x 2562 predicted vertices.
     The tile cap is read once per process (OBMAN_PM_TILE), so this re-executes itself per value."""
@@ -243,6 +256,8 @@ if __name__ == "__main__":
         bench_chamfer()
     if which == "tiles":
         bench_tile_sweep()
+    if which == "contactmin":
+        bench_contactmin()
     if which in ("mano", "all"):
         bench_mano()
     if which in ("contains", "all"):
