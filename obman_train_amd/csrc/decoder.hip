@@ -16,6 +16,7 @@
 // fp32 in / fp32 accumulate MFMA (exact fp32 fma chains): 157 TF peak = the fp32 vector rate, but it
 // leaves the VALU free for the fused loaders/epilogues.  Tile: 128 x 64 x 32, 4 waves (2x2), each wave
 // 64 x 32 = two 32x32 accumulators; LDS tiles k-major with +1 padding (conflict-free b32 reads/writes).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -777,39 +778,46 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 // ================================================================================================ small kernels
 namespace dec {
 
-constexpr int PREP_COLS = 4;  // 129 blocks at C1 = 515
-constexpr int PREP_NT = 1024;  // threads of prep_kernel: 16 waves walk the 64 samples / the template vertices of a block's 4 channels
+constexpr int PREP_COLS = 4;   // channels per block of prep_ps_kernel (per-sample grids)
+constexpr int PREP_SCOLS = 2;  // channels per block of prep_kernel (shared template grid): 264 blocks at ld1 = 528
+constexpr int PREP_NT = 1024;  // threads of prep_kernel: 16 waves walk the 64 samples / the template vertices of a block's channels
 
-// Layer 1 in factored form + closed-form BN-1 statistics.  One block = PREP_COLS output channels.
+// G[n,c] = W1[c,0:3].grid[n] with a pinned operation order: the statistics pass and l1_fill_kernel must see the same values
+__device__ __forceinline__ float l1_gval(float w0, float w1, float w2, float g0, float g1, float g2) {
+  return __fmaf_rn(w2, g2, __fmaf_rn(w1, g1, w0 * g0));
+}
+
+// Layer 1 in factored form + closed-form BN-1 statistics.  One block = COLS output channels.
 //   G[n,c] = W1[c,0:3].grid[n],  F[b,c] = b1[c] + W1[c,3:].feat[b]
 //   train: mean = mean_n G + mean_b F, var = var_n G + var_b F (biased; exact for the B x N product set)
 //   Gx = rstd*(G - gm), Fx = rstd*(F - fm)  with gm + fm = mean  =>  xhat1[b,n,c] = Gx[n,c] + Fx[b,c]
+// This kernel leaves the per-channel constants (gmean1 = gm, rstd1), Fx and the pre-scaled Fy = gamma Fx + beta; the [N, ld1] arrays
+// Gx and Gy = gamma Gx are l1_fill_kernel's.  (Until r06 a block also wrote its 4 channels of Gx - 16-byte pieces of 2 112-byte rows
+// from 132 blocks - and prescale_l1_kernel read Gx back to write Gy: 220 + 61 us at N = 64 050.)
+template <int COLS>
 __global__ __launch_bounds__(PREP_NT) void prep_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                                    const float* __restrict__ grid, const float* __restrict__ feat, int B, int N,
                                                    int C1, int ld1, int training, float eps, float momentum,
-                                                   float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ Gx,
-                                                   float* __restrict__ Fx, float* __restrict__ mean1, float* __restrict__ rstd1) {
+                                                   float* __restrict__ rmean, float* __restrict__ rvar, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ Fx, float* __restrict__ Fy,
+                                                   float* __restrict__ mean1, float* __restrict__ rstd1, float* __restrict__ gmean1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Cf = C1 - 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = PREP_NT / 64, NPART = NW / PREP_COLS;  // 16 waves: 4 per channel in the statistics pass
-  double* sPart = reinterpret_cast<double*>(smem);      // [PREP_COLS][NPART][2]: partial (sum, sum of squares) over n
-  float* sW = reinterpret_cast<float*>(sPart + PREP_COLS * NPART * 2);  // [PREP_COLS][C1]
-  float* sF = sW + PREP_COLS * C1;                      // [PREP_COLS][B]
-  float* sStat = sF + PREP_COLS * B;                    // [PREP_COLS][4]: gm, fm, rstd
-  // G[n,c] (3 MACs) is recomputed wherever needed instead of being staged: N reaches 64 050 (25 x 2562)
-  auto Gval = [&](int j, int n) {
-    return sW[j * C1] * grid[n * 3] + sW[j * C1 + 1] * grid[n * 3 + 1] + sW[j * C1 + 2] * grid[n * 3 + 2];
-  };
-  const int c0 = blockIdx.x * PREP_COLS;
-  for (int i = tid; i < PREP_COLS * C1; i += PREP_NT) {
+  constexpr int NW = PREP_NT / 64, NPART = NW / COLS;  // 16 waves: NPART per channel in the statistics pass
+  double* sPart = reinterpret_cast<double*>(smem);      // [COLS][NPART][2]: partial (sum, sum of squares) over n
+  float* sW = reinterpret_cast<float*>(sPart + COLS * NPART * 2);  // [COLS][C1]
+  float* sF = sW + COLS * C1;                      // [COLS][B]
+  float* sStat = sF + COLS * B;                    // [COLS][4]: gm, fm, rstd
+  const int c0 = blockIdx.x * COLS;
+  for (int i = tid; i < COLS * C1; i += PREP_NT) {
     const int c = c0 + i / C1;
     sW[i] = c < C1 ? W1[(size_t)c * C1 + i % C1] : 0.f;
   }
   __syncthreads();
   for (int b = wave; b < B; b += NW) {  // one wave per sample: lanes stride over the feature
-    float acc[PREP_COLS];
+    float acc[COLS];
 #pragma unroll
-    for (int j = 0; j < PREP_COLS; ++j) acc[j] = 0.f;
+    for (int j = 0; j < COLS; ++j) acc[j] = 0.f;
     for (int k0 = 0; k0 < Cf; k0 += 512) {  // 8 independent loads in flight per lane
       float f[8];
 #pragma unroll
@@ -819,28 +827,43 @@ __global__ __launch_bounds__(PREP_NT) void prep_kernel(const float* __restrict__
         const int k = k0 + lane + 64 * u;
         if (k < Cf) {
 #pragma unroll
-          for (int j = 0; j < PREP_COLS; ++j) acc[j] = __fmaf_rn(f[u], sW[j * C1 + 3 + k], acc[j]);
+          for (int j = 0; j < COLS; ++j) acc[j] = __fmaf_rn(f[u], sW[j * C1 + 3 + k], acc[j]);
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < PREP_COLS; ++j) {
+    for (int j = 0; j < COLS; ++j) {
       const float r = obman_wave_sum(acc[j]);
       if (lane == 0) sF[j * B + b] = r + ((c0 + j < C1) ? b1[c0 + j] : 0.f);
     }
   }
   __syncthreads();
-  // per-channel statistics in fp64: wave = (channel j, part); the parts split the template vertices and meet in LDS (fixed order)
+  // per-channel statistics in fp64: wave = (channel j, part); the parts split the template vertices and meet in LDS (fixed order).
+  // G[n,c] (3 MACs) is recomputed instead of being staged: N reaches 64 050 (25 x 2562).  Four vertices' coordinates are requested
+  // before the first sum (a lane's vertices keep their order).
   {
-    const int j = wave % PREP_COLS, part = wave / PREP_COLS;
+    const int j = wave % COLS, part = wave / COLS;
+    const float w0 = sW[j * C1], w1 = sW[j * C1 + 1], w2 = sW[j * C1 + 2];
     double sg = 0, sgg = 0;
-    for (int n = part * 64 + lane; n < N; n += 64 * NPART) { const double v = Gval(j, n); sg += v; sgg += v * v; }
+    constexpr int STEP = 64 * NPART;
+    for (int n = part * 64 + lane; n < N; n += 4 * STEP) {
+      float g[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nn = n + u * STEP < N ? n + u * STEP : n;
+        g[u][0] = grid[nn * 3]; g[u][1] = grid[nn * 3 + 1]; g[u][2] = grid[nn * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (n + u * STEP < N) { const double v = l1_gval(w0, w1, w2, g[u][0], g[u][1], g[u][2]); sg += v; sgg += v * v; }
+      }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgg += __shfl_xor(sgg, off, 64); }
     if (lane == 0) { sPart[(j * NPART + part) * 2] = sg; sPart[(j * NPART + part) * 2 + 1] = sgg; }
   }
   __syncthreads();
-  for (int j = wave; j < PREP_COLS; j += NW) {
+  for (int j = wave; j < COLS; j += NW) {
     const int c = c0 + j;
     double sg = 0, sgg = 0, sf = 0, sff = 0;
     for (int q = 0; q < NPART; ++q) { sg += sPart[(j * NPART + q) * 2]; sgg += sPart[(j * NPART + q) * 2 + 1]; }
@@ -865,19 +888,64 @@ __global__ __launch_bounds__(PREP_NT) void prep_kernel(const float* __restrict__
       sStat[j * 4] = gm; sStat[j * 4 + 1] = fm; sStat[j * 4 + 2] = rs;
       mean1[c] = gm + fm;
       rstd1[c] = rs;
+      gmean1[c] = gm;
     }
   }
   __syncthreads();
   // columns C1 .. ld1-1 (the pitch padding, covered by the extra blocks of the grid) are written as zeros: the bf16 flavour's
   // operand generators read whole 8-wide chunks and rely on finite padding
-  for (int i = tid; i < PREP_COLS * N; i += PREP_NT) {
-    const int n = i / PREP_COLS, j = i % PREP_COLS;  // consecutive lanes -> consecutive channels (32-byte segments)
-    if (c0 + j < ld1) Gx[(size_t)n * ld1 + c0 + j] = c0 + j < C1 ? (Gval(j, n) - sStat[j * 4]) * sStat[j * 4 + 2] : 0.f;
+  for (int i = tid; i < COLS * B; i += PREP_NT) {
+    const int b = i / COLS, j = i % COLS, c = c0 + j;
+    if (c < ld1) {
+      const float fx = c < C1 ? (sF[j * B + b] - sStat[j * 4 + 1]) * sStat[j * 4 + 2] : 0.f;
+      Fx[(size_t)b * ld1 + c] = fx;
+      if (Fy) Fy[(size_t)b * ld1 + c] = c < C1 ? __fmaf_rn(gamma[c], fx, beta[c]) : 0.f;
+    }
   }
-  for (int i = tid; i < PREP_COLS * B; i += PREP_NT) {
-    const int b = i / PREP_COLS, j = i % PREP_COLS;
-    if (c0 + j < ld1) Fx[(size_t)b * ld1 + c0 + j] = c0 + j < C1 ? (sF[j * B + b] - sStat[j * 4 + 1]) * sStat[j * 4 + 2] : 0.f;
+}
+
+// The [N, ld1] halves of layer 1's factors, whole rows at a time: Gx[n,c] = rstd (G[n,c] - gm) and (shared-template flavours) the
+// pre-scaled Gy = gamma Gx that the h2 GEMM and the layer-2 weight gradient regenerate a1 = relu(Gy[n] + Fy[b]) from, plus Gy's
+// sentinel row N (-3e38: rows outside the problem read it, relu(-3e38 + Fy) = 0 exactly).  The per-channel constants sit in LDS
+// (6 x ld1 floats); a thread forms four channels of a row and stores them as 16 bytes.
+constexpr int L1F_NT = 256, L1F_ITEMS = 16;  // items (four channels of a row) per thread: up to 16, fewer on small templates (>= ~1024 blocks)
+__global__ __launch_bounds__(L1F_NT) void l1_fill_kernel(const float* __restrict__ W1, const float* __restrict__ grid,
+                                                         const float* __restrict__ gmean1, const float* __restrict__ rstd1,
+                                                         const float* __restrict__ gamma, int N, int C1, int ld1, int items,
+                                                         float* __restrict__ Gx, float* __restrict__ Gy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = reinterpret_cast<float*>(smem);  // [6][ld1]: w0, w1, w2, gm, rstd, gamma
+  const int tid = threadIdx.x;
+  for (int c = tid; c < ld1; c += L1F_NT) {
+    const bool ok = c < C1;
+    sc[c] = ok ? W1[(size_t)c * C1] : 0.f; sc[ld1 + c] = ok ? W1[(size_t)c * C1 + 1] : 0.f; sc[2 * ld1 + c] = ok ? W1[(size_t)c * C1 + 2] : 0.f;
+    sc[3 * ld1 + c] = ok ? gmean1[c] : 0.f; sc[4 * ld1 + c] = ok ? rstd1[c] : 0.f; sc[5 * ld1 + c] = ok && Gy ? gamma[c] : 0.f;
   }
+  __syncthreads();
+  const unsigned q4 = (unsigned)ld1 >> 2, total = (unsigned)N * q4;
+  const unsigned i0 = blockIdx.x * (unsigned)(L1F_NT * items) + tid;
+#pragma unroll 4
+  for (int k = 0; k < items; ++k) {
+    const unsigned i = i0 + k * L1F_NT;
+    if (i >= total) break;
+    const unsigned n = i / q4, c = (i - n * q4) * 4;
+    const float g0 = grid[n * 3], g1 = grid[n * 3 + 1], g2 = grid[n * 3 + 2];
+    const float4 w0 = *reinterpret_cast<const float4*>(sc + c), w1 = *reinterpret_cast<const float4*>(sc + ld1 + c),
+                 w2 = *reinterpret_cast<const float4*>(sc + 2 * ld1 + c), gm = *reinterpret_cast<const float4*>(sc + 3 * ld1 + c),
+                 rs = *reinterpret_cast<const float4*>(sc + 4 * ld1 + c);
+    float4 x;
+    x.x = (int)c < C1 ? (l1_gval(w0.x, w1.x, w2.x, g0, g1, g2) - gm.x) * rs.x : 0.f;
+    x.y = (int)c + 1 < C1 ? (l1_gval(w0.y, w1.y, w2.y, g0, g1, g2) - gm.y) * rs.y : 0.f;
+    x.z = (int)c + 2 < C1 ? (l1_gval(w0.z, w1.z, w2.z, g0, g1, g2) - gm.z) * rs.z : 0.f;
+    x.w = (int)c + 3 < C1 ? (l1_gval(w0.w, w1.w, w2.w, g0, g1, g2) - gm.w) * rs.w : 0.f;
+    *reinterpret_cast<float4*>(Gx + (size_t)n * ld1 + c) = x;
+    if (Gy) {
+      const float4 ga = *reinterpret_cast<const float4*>(sc + 5 * ld1 + c);
+      *reinterpret_cast<float4*>(Gy + (size_t)n * ld1 + c) = make_float4(ga.x * x.x, ga.y * x.y, ga.z * x.z, ga.w * x.w);
+    }
+  }
+  if (Gy && blockIdx.x == 0)
+    for (int c = tid; c < ld1; c += L1F_NT) Gy[(size_t)N * ld1 + c] = -3.0e38f;
 }
 
 constexpr int L1PS_ROWS = 128;  // rows per block of the per-sample-grid layer-1 backward
@@ -1327,12 +1395,22 @@ template <> struct L4Raw<bfraw> {
   u32x4 v;
   __device__ __forceinline__ void load(const bfraw* p) { v = *reinterpret_cast<const u32x4*>(p); }
   __device__ __forceinline__ void get(float* o) const { unpack8act(v, o); }
+  __device__ __forceinline__ void get2(f32x2v* o) const {
+    o[0] = f32x2v{bf_lo(v.x), bf_hi(v.x)}; o[1] = f32x2v{bf_lo(v.y), bf_hi(v.y)};
+    o[2] = f32x2v{bf_lo(v.z), bf_hi(v.z)}; o[3] = f32x2v{bf_lo(v.w), bf_hi(v.w)};
+  }
 };
 template <> struct L4Raw<float> {
   float4 a, b;
   __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
   __device__ __forceinline__ void get(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+  __device__ __forceinline__ void get2(f32x2v* o) const {
+    o[0] = f32x2v{a.x, a.y}; o[1] = f32x2v{a.z, a.w}; o[2] = f32x2v{b.x, b.y}; o[3] = f32x2v{b.z, b.w};
+  }
 };
+// The per-element arithmetic runs on channel PAIRS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): ~17 vector instructions per
+// element made this pass VALU-bound (r06: 118 us at R = 1.03 M rows for 263 MB of bf16 activations, 364 us at 4.1 M), the packed
+// form issues ~9.  Element-wise the operations and their order are the scalar ones.
 template <class HT>
 __global__ __launch_bounds__(256, 2) void l4w_bwd_kernel(const float* __restrict__ G, const HT* __restrict__ H3, const float* __restrict__ s3,
                                                          const float* __restrict__ t3, const float* __restrict__ mean3,
@@ -1340,42 +1418,56 @@ __global__ __launch_bounds__(256, 2) void l4w_bwd_kernel(const float* __restrict
                                                          int rows_per_blk, double* __restrict__ sums, float* __restrict__ gw) {
   const int tid = threadIdx.x, sub = tid & 15, rl = tid >> 4, c0 = sub * 8;
   const long rbeg = (long)blockIdx.x * rows_per_blk, rend = min(R, rbeg + rows_per_blk);
-  float cs[8], ct[8], cm[8], cr[8], w0[8], w1[8], w2[8];
+  f32x2v cs[4], ct[4], cm[4], cr[4], w0[4], w1[4], w2[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    cs[j] = s3[c0 + j]; ct[j] = t3[c0 + j]; cm[j] = mean3[c0 + j]; cr[j] = rstd3[c0 + j];
-    w0[j] = W4[c0 + j]; w1[j] = W4[L4W_C + c0 + j]; w2[j] = W4[2 * L4W_C + c0 + j];
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + 2 * j;
+    cs[j] = f32x2v{s3[c], s3[c + 1]}; ct[j] = f32x2v{t3[c], t3[c + 1]}; cm[j] = f32x2v{mean3[c], mean3[c + 1]};
+    cr[j] = f32x2v{rstd3[c], rstd3[c + 1]};
+    w0[j] = f32x2v{W4[c], W4[c + 1]}; w1[j] = f32x2v{W4[L4W_C + c], W4[L4W_C + c + 1]}; w2[j] = f32x2v{W4[2 * L4W_C + c], W4[2 * L4W_C + c + 1]};
   }
-  float p1[8], p2[8], ga[8][3], gb[3] = {0.f, 0.f, 0.f};
+  f32x2v p1[4], p2[4], ga[4][3];
+  float gb[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { p1[j] = 0.f; p2[j] = 0.f; ga[j][0] = ga[j][1] = ga[j][2] = 0.f; }
-  for (long rq = rbeg + rl; rq < rend; rq += 64) {  // four rows per lane and step (16 apart), loads first
-    float gq[4][3];
-    L4Raw<HT> hq[4];
+  for (int j = 0; j < 4; ++j) { p1[j] = f32x2v{0.f, 0.f}; p2[j] = p1[j]; ga[j][0] = ga[j][1] = ga[j][2] = p1[j]; }
+  // two rows per lane and step (16 apart); the NEXT step's rows are requested before this step's arithmetic (a lane's rows keep
+  // their order: rq, rq + 16, rq + 32, ..)
+  float gq[2][3], gn[2][3];
+  L4Raw<HT> hq[2], hn[2];
+  auto request = [&](long rq, L4Raw<HT>(&h)[2], float(&g)[2][3]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const long r = rq + 16 * u;
       const bool ok = r < rend;
-      const long rr = ok ? r : rq;
-      gq[u][0] = ok ? G[rr * 3] : 0.f; gq[u][1] = ok ? G[rr * 3 + 1] : 0.f; gq[u][2] = ok ? G[rr * 3 + 2] : 0.f;  // g = 0: the row adds nothing
-      hq[u].load(H3 + (size_t)rr * L4W_C + c0);
+      const long rr = ok ? r : rbeg;
+      g[u][0] = ok ? G[rr * 3] : 0.f; g[u][1] = ok ? G[rr * 3 + 1] : 0.f; g[u][2] = ok ? G[rr * 3 + 2] : 0.f;  // g = 0: the row adds nothing
+      h[u].load(H3 + (size_t)rr * L4W_C + c0);
     }
+  };
+  request(rbeg + rl, hq, gq);
+  for (long rq = rbeg + rl; rq < rend; rq += 32) {
+    request(rq + 32, hn, gn);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const float g0 = f * gq[u][0], g1 = f * gq[u][1], g2 = f * gq[u][2];
-      float hv[8];
-      hq[u].get(hv);
+      f32x2v hv[4];
+      hq[u].get2(hv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float y = __fmaf_rn(cs[j], hv[j], ct[j]);
-        const float a = fmaxf(y, 0.f);
-        const float gy = y > 0.f ? (g0 * w0[j] + g1 * w1[j] + g2 * w2[j]) : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const f32x2v y = __builtin_elementwise_fma(cs[j], hv[j], ct[j]);
+        const f32x2v d = __builtin_elementwise_fma(w2[j], f32x2v{g2, g2}, __builtin_elementwise_fma(w1[j], f32x2v{g1, g1}, w0[j] * g0));
+        const f32x2v a = f32x2v{fmaxf(y[0], 0.f), fmaxf(y[1], 0.f)};
+        const f32x2v gy = f32x2v{y[0] > 0.f ? d[0] : 0.f, y[1] > 0.f ? d[1] : 0.f};
         p1[j] += gy;
-        p2[j] = __fmaf_rn(gy, (hv[j] - cm[j]) * cr[j], p2[j]);
-        ga[j][0] = __fmaf_rn(g0, a, ga[j][0]); ga[j][1] = __fmaf_rn(g1, a, ga[j][1]); ga[j][2] = __fmaf_rn(g2, a, ga[j][2]);
+        p2[j] = __builtin_elementwise_fma(gy, (hv[j] - cm[j]) * cr[j], p2[j]);
+        ga[j][0] = __builtin_elementwise_fma(f32x2v{g0, g0}, a, ga[j][0]);
+        ga[j][1] = __builtin_elementwise_fma(f32x2v{g1, g1}, a, ga[j][1]);
+        ga[j][2] = __builtin_elementwise_fma(f32x2v{g2, g2}, a, ga[j][2]);
       }
       gb[0] += g0; gb[1] += g1; gb[2] += g2;
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { hq[u] = hn[u]; gq[u][0] = gn[u][0]; gq[u][1] = gn[u][1]; gq[u][2] = gn[u][2]; }
   }
   // 16 row lanes hold partials of the same channels: fixed-order sum through LDS (row lane 0 adds 1 .. 15 in order), fp64 for S1 / S2
   __shared__ float sp[15][16][16];  // [row lane - 1][octet][p1[8] | p2[8]]
@@ -1383,28 +1475,34 @@ __global__ __launch_bounds__(256, 2) void l4w_bwd_kernel(const float* __restrict
   __shared__ float sg[16][3];
   if (rl > 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sp[rl - 1][sub][j] = p1[j]; sp[rl - 1][sub][8 + j] = p2[j]; }
+    for (int j = 0; j < 8; ++j) { sp[rl - 1][sub][j] = p1[j >> 1][j & 1]; sp[rl - 1][sub][8 + j] = p2[j >> 1][j & 1]; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sf[rl - 1][sub][3 * j] = ga[j][0]; sf[rl - 1][sub][3 * j + 1] = ga[j][1]; sf[rl - 1][sub][3 * j + 2] = ga[j][2]; }
+    for (int j = 0; j < 8; ++j) {
+      sf[rl - 1][sub][3 * j] = ga[j >> 1][0][j & 1]; sf[rl - 1][sub][3 * j + 1] = ga[j >> 1][1][j & 1]; sf[rl - 1][sub][3 * j + 2] = ga[j >> 1][2][j & 1];
+    }
   }
   if (sub == 0) { sg[rl][0] = gb[0]; sg[rl][1] = gb[1]; sg[rl][2] = gb[2]; }
   __syncthreads();
   if (rl == 0) {
     double S1[8], S2[8];
+    float gs[8][3];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { S1[j] = (double)p1[j]; S2[j] = (double)p2[j]; }
+    for (int j = 0; j < 8; ++j) {
+      S1[j] = (double)p1[j >> 1][j & 1]; S2[j] = (double)p2[j >> 1][j & 1];
+      gs[j][0] = ga[j >> 1][0][j & 1]; gs[j][1] = ga[j >> 1][1][j & 1]; gs[j][2] = ga[j >> 1][2][j & 1];
+    }
     for (int w = 0; w < 15; ++w) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { S1[j] += (double)sp[w][sub][j]; S2[j] += (double)sp[w][sub][8 + j]; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ga[j][0] += sf[w][sub][3 * j]; ga[j][1] += sf[w][sub][3 * j + 1]; ga[j][2] += sf[w][sub][3 * j + 2]; }
+      for (int j = 0; j < 8; ++j) { gs[j][0] += sf[w][sub][3 * j]; gs[j][1] += sf[w][sub][3 * j + 1]; gs[j][2] += sf[w][sub][3 * j + 2]; }
     }
     float* dst = gw + (size_t)blockIdx.x * (3 * L4W_C + 4);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       sums[((size_t)blockIdx.x * L4W_C + c0 + j) * 2] = S1[j];
       sums[((size_t)blockIdx.x * L4W_C + c0 + j) * 2 + 1] = S2[j];
-      dst[c0 + j] = ga[j][0]; dst[L4W_C + c0 + j] = ga[j][1]; dst[2 * L4W_C + c0 + j] = ga[j][2];
+      dst[c0 + j] = gs[j][0]; dst[L4W_C + c0 + j] = gs[j][1]; dst[2 * L4W_C + c0 + j] = gs[j][2];
     }
     if (sub < 3) {
       float e = 0.f;
@@ -1478,6 +1576,15 @@ __global__ __launch_bounds__(256) void l1_reduce2_kernel(const float* __restrict
     for (int g = 0; g < groups; ++g) s += Qp[((size_t)g * N + n) * ld1 + c];
     Q[(size_t)n * ld1 + c] = s;
   }
+}
+
+// With ONE sample group (B <= 64 on the second-generation data-gradient kernels) Q IS the single partial: only the B rows of P are
+// summed and the consumers read Qp in place (r06: the copy was 37 us at N = 16 050, 93 us at 64 050).  Returns where Q lives.
+const float* launch_l1_reduce2(const float* Pp, const float* Qp, int ld1, int B, int N, int C1, int tiles, int groups, float* P, float* Q,
+                               hipStream_t st) {
+  const int rows = groups == 1 ? B : B + N;
+  l1_reduce2_kernel<<<dim3(rows, obman_cdiv(C1, 256)), 256, 0, st>>>(Pp, Qp, ld1, B, N, C1, tiles, groups, P, Q);
+  return groups == 1 ? Qp : Q;
 }
 
 // BN-1 backward in factored form.  Block = 64 channels x 16 row groups (coalesced along channels; the rows of P/Fx
@@ -1607,19 +1714,20 @@ __global__ __launch_bounds__(1024) void l1_seg_apply_kernel(const float* __restr
   const int n0 = blockIdx.y * L1_SEG_ROWS, n1 = min(N, n0 + L1_SEG_ROWS);
   __shared__ double red[16][4][64];
   __shared__ float redf[16][4][64];
-  // channel constants: sample rows split over the 16 row groups, segment partials summed in index order by every group
+  // channel constants: the sample rows AND the segment partials are split over the 16 row groups and meet in LDS in group order
+  // (r06: every group used to walk all nseg partials itself - 126 dependent L2 round trips per block at N = 64 050, 386 us)
   double s1 = 0, s2 = 0, sgx = 0, sfx = 0;
-  if (ok)
+  if (ok) {
     for (int b = rg; b < B; b += 16) {
       const double p = P[(size_t)b * ld1 + c], fx = Fx[(size_t)b * ld1 + c];
       s1 += p; s2 += p * fx; sfx += fx;
     }
-  red[rg][0][cl] = s1; red[rg][1][cl] = s2; red[rg][3][cl] = sfx;
+    for (int sg = rg; sg < nseg; sg += 16) { s2 += seg[((size_t)sg * 2) * C1 + c]; sgx += seg[((size_t)sg * 2 + 1) * C1 + c]; }
+  }
+  red[rg][0][cl] = s1; red[rg][1][cl] = s2; red[rg][2][cl] = sgx; red[rg][3][cl] = sfx;
   __syncthreads();
-  s1 = s2 = sfx = 0;
-  for (int g = 0; g < 16; ++g) { s1 += red[g][0][cl]; s2 += red[g][1][cl]; sfx += red[g][3][cl]; }
-  if (ok)
-    for (int sg = 0; sg < nseg; ++sg) { s2 += seg[((size_t)sg * 2) * C1 + c]; sgx += seg[((size_t)sg * 2 + 1) * C1 + c]; }
+  s1 = s2 = sgx = sfx = 0;
+  for (int g = 0; g < 16; ++g) { s1 += red[g][0][cl]; s2 += red[g][1][cl]; sgx += red[g][2][cl]; sfx += red[g][3][cl]; }
   const double R = (double)B * N;
   const float k1 = ok ? gamma[c] * rstd1[c] : 0.f;
   const float k2 = training ? (float)(s1 / R) : 0.f, k3 = training ? (float)(s2 / R) : 0.f;
@@ -1631,9 +1739,22 @@ __global__ __launch_bounds__(1024) void l1_seg_apply_kernel(const float* __restr
         dF[(size_t)b * ld1 + c] = v;
         gb += v;
       }
-    for (int n = n0 + rg; n < n1; n += 16) {
-      const float v = k1 * (Q[(size_t)n * ld1 + c] - B * k2 - k3 * (B * Gx[(size_t)n * ld1 + c] + (float)sfx));
-      w0 = __fmaf_rn(v, grid[n * 3], w0); w1 = __fmaf_rn(v, grid[n * 3 + 1], w1); w2 = __fmaf_rn(v, grid[n * 3 + 2], w2);
+    // four rows' operands requested before the first product (the row index is wave-uniform); the products keep their row order
+    for (int n = n0 + rg; n < n1; n += 64) {
+      float q[4], gx[4], g0[4], g1[4], g2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nn = n + 16 * u < n1 ? n + 16 * u : n;
+        q[u] = Q[(size_t)nn * ld1 + c]; gx[u] = Gx[(size_t)nn * ld1 + c];
+        g0[u] = grid[nn * 3]; g1[u] = grid[nn * 3 + 1]; g2[u] = grid[nn * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (n + 16 * u < n1) {
+          const float v = k1 * (q[u] - B * k2 - k3 * (B * gx[u] + (float)sfx));
+          w0 = __fmaf_rn(v, g0[u], w0); w1 = __fmaf_rn(v, g1[u], w1); w2 = __fmaf_rn(v, g2[u], w2);
+        }
+      }
     }
   }
   redf[rg][0][cl] = gb; redf[rg][1][cl] = w0; redf[rg][2][cl] = w1; redf[rg][3][cl] = w2;
@@ -1654,7 +1775,14 @@ __global__ __launch_bounds__(256) void l1_seg_w_kernel(const float* __restrict__
   const int i = blockIdx.x * 256 + threadIdx.x;  // i = k * C1 + c, k < 3
   if (i >= 3 * C1) return;
   float s = 0.f;
-  for (int sg = 0; sg < nseg; ++sg) s += segw[(size_t)sg * 3 * C1 + i];
+  for (int sg = 0; sg < nseg; sg += 8) {  // eight partials requested at once, added in segment order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = sg + u < nseg ? segw[(size_t)(sg + u) * 3 * C1 + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (sg + u < nseg) s += v[u];
+  }
   const int k = i / C1, c = i - k * C1;
   gW1[(size_t)c * C1 + k] = s;
 }
@@ -1759,7 +1887,7 @@ constexpr int TN_CHUNK_ROWS = 1024;  // rows per split-K chunk of the weight-gra
 constexpr long WS_TAIL_FLOATS = 256;  // 1 KB
 // forward workspace (kept for the backward), float offsets
 struct FwdWs {
-  long Gx, Fx, Gy, Fy, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
+  long Gx, Fx, Gy, Fy, gm1, mean1, rstd1, H2, mean2, rstd2, s2, t2, H3, mean3, rstd3, s3, t3, moments, mred, wb2, wb3, total;
 };
 FwdWs fwd_ws(const Dims& d) {
   FwdWs w; long o = 0;
@@ -1772,9 +1900,10 @@ FwdWs fwd_ws(const Dims& d) {
   w.mred = take(d.rb > PRE_MIN_ROWS ? (long)PRE_SEGMENTS_NARROW * d.C2 * 2 * 2 : 0);  // doubles: pre-reduced moments
   w.wb2 = take(d.bf16 ? ((long)d.C2 * kpad(d.C1) + 1) / 2 : 0);  // bf16 [C2][kpad(C1)] image of W2
   w.wb3 = take(d.bf16 ? ((long)d.C3 * kpad(d.C2) + 1) / 2 : 0);
-  // pre-scaled layer-1 factors (prescale_l1_kernel): the bf16 flavour and the second-generation fp32 kernels (shared template grid)
+  // pre-scaled layer-1 factors (Gy = gamma Gx: l1_fill_kernel, Fy = gamma Fx + beta: prep_kernel): the bf16 flavour and the second-generation fp32 kernels (shared template grid)
   w.Gy = take(d.bf16 || !d.ps ? (long)(d.N + 1) * d.ld1 : 0);
   w.Fy = take(d.bf16 || !d.ps ? (long)d.B * d.ld1 : 0);
+  w.gm1 = take(d.ps ? 0 : d.ld1);  // the grid factor's channel means (prep_kernel -> l1_fill_kernel)
   w.total = o + WS_TAIL_FLOATS;
   return w;
 }
@@ -2021,19 +2150,6 @@ int pre_reduce(const T*& part, int& rows, int cols, T* scratch, hipStream_t st) 
   part = scratch;
   rows = segs;
   return 0;
-}
-// Gy[n,c] = gamma[c] * Gx[n,c],  Fy[b,c] = gamma[c] * Fx[b,c] + beta[c]  (pitch columns stay zero): relu(Gy + Fy) = a1
-__global__ __launch_bounds__(256) void prescale_l1_kernel(const float* __restrict__ Gx, const float* __restrict__ Fx, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int N, int B, int ld, int C, float* __restrict__ Gy,
-                                                          float* __restrict__ Fy) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x, total = (long)(N + 1 + B) * ld;
-  if (i >= total) return;
-  const long row = i / ld;
-  const int c = (int)(i - row * ld);
-  const bool ok = c < C;
-  if (row < N) Gy[i] = ok ? gamma[c] * Gx[i] : 0.f;
-  else if (row == N) Gy[i] = -3.0e38f;  // the row that rows outside the problem read: relu(-3e38 + Fy) = 0 exactly
-  else { const long j = i - (long)(N + 1) * ld; Fy[j] = ok ? __fmaf_rn(gamma[c], Fx[j], beta[c]) : 0.f; }
 }
 
 // layer 4: the 16-lanes-per-row kernels (l4w_*) serve the production width; OBMAN_DEC_L4W=0 = the first-generation kernels (A/B)
@@ -2351,10 +2467,8 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
     bfraw* wb = reinterpret_cast<bfraw*>(ws + w.wb2);
     const double* mom = moments;
     int mrows;
-    // pre-scaled layer-1 factors (+ the sentinel row): read by the h2 GEMM below and by the weight-gradient GEMM of the backward pass
-    prescale_l1_kernel<<<obman_cdiv((long)(d.N + 1 + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
-                                                                                      d.C1, ws + w.Gy, ws + w.Fy);
-    OBMAN_LAUNCH_CHECK();
+    // the pre-scaled layer-1 factors Gy / Fy (+ the sentinel row) come from prep_kernel / l1_fill_kernel: read by the h2 GEMM below and
+    // by the weight-gradient GEMM of the backward pass
     if (rows2_enabled() && r2_addr32(d) && r2_lds_bytes<BGridFeatPre, EpiStoreB2>(kpad16(d.C1), r2_geo(d, d.C2, 2)) <= R2_LDS_LIMIT) {
       const int Kp = kpad16(d.C1);
       // rows as (8 samples x 4 vertices) per wave: a load instruction touches 4 rows of the layer-1 grid factor and 8 of the
@@ -2416,7 +2530,7 @@ int forward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, 
 
 // everything of the backward up to (and including) P[b,c] = sum_n gy1, Q[n,c] = sum_b gy1; the caller continues with layer 1
 int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w, const BwdWs& v, const float* g_out, const float* ws,
-                  float* ws2, const obman_pointgen_grads* g, hipStream_t st) {
+                  float* ws2, const obman_pointgen_grads* g, const float** q_sum, hipStream_t st) {
   const int tr = p->training;
   double* sums = reinterpret_cast<double*>(ws2 + v.sums);
   float *k1 = ws2 + v.k, *k2 = k1 + d.ld1, *k3 = k2 + d.ld1;
@@ -2547,8 +2661,7 @@ int backward_bf16(const obman_pointgen_params* p, const Dims& d, const FwdWs& w,
     const float* pp = ws2 + v.Pp;
     int prow = l1_prow;
     if ((rc = pre_reduce<float>(pp, prow, d.B * d.ld1, ws2 + v.Ppre, st))) return rc;
-    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, l1_groups,
-                                                                                ws2 + v.P, ws2 + v.Q);
+    *q_sum = launch_l1_reduce2(pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, l1_groups, ws2 + v.P, ws2 + v.Q, st);
     OBMAN_LAUNCH_CHECK();
   }
   return 0;
@@ -2578,15 +2691,23 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
   ObmanProfScope prof(OBMAN_K_DECODER_FWD, st);
   {
     const size_t sm = sizeof(float) * ((size_t)PREP_COLS * (d.C1 + d.B) + PREP_COLS * 4);
-    const size_t sm_prep = sm + sizeof(double) * PREP_COLS * (PREP_NT / 64 / PREP_COLS) * 2;
+    const size_t sm_prep = sizeof(float) * ((size_t)PREP_SCOLS * (d.C1 + d.B) + PREP_SCOLS * 4) + sizeof(double) * (PREP_NT / 64) * 2;
     if (d.ps)
       prep_ps_kernel<<<obman_cdiv(d.C1, PREP_COLS), 256, sm, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
                                                                     p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
                                                                     ws + w.mean1, ws + w.rstd1);
     else
-      prep_kernel<<<obman_cdiv(d.ld1, PREP_COLS), PREP_NT, sm_prep, st>>>(p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps,
-                                                                 p->momentum, p->bn_rm[0], p->bn_rv[0], ws + w.Gx, ws + w.Fx,
-                                                                 ws + w.mean1, ws + w.rstd1);
+    {  // shared template grid: channel constants + the sample factor, then the vertex factor (and both pre-scaled images) row-wise
+      if ((long)d.N * (d.ld1 / 4) + (long)L1F_NT * L1F_ITEMS >= (1L << 32)) return -1;
+      prep_kernel<PREP_SCOLS><<<obman_cdiv(d.ld1, PREP_SCOLS), PREP_NT, sm_prep, st>>>(
+          p->w1, p->b1, p->grid, p->feat, d.B, d.N, d.C1, d.ld1, tr, p->eps, p->momentum, p->bn_rm[0], p->bn_rv[0], p->bn_w[0], p->bn_b[0],
+          ws + w.Fx, ws + w.Fy, ws + w.mean1, ws + w.rstd1, ws + w.gm1);
+      OBMAN_LAUNCH_CHECK();
+      const long quads = (long)d.N * (d.ld1 / 4);
+      const int items = (int)std::min<long>(L1F_ITEMS, std::max<long>(1, quads / (L1F_NT * 1024L)));
+      l1_fill_kernel<<<obman_cdiv(quads, L1F_NT * items), L1F_NT, sizeof(float) * 6 * d.ld1, st>>>(
+          p->w1, p->grid, ws + w.gm1, ws + w.rstd1, p->bn_w[0], d.N, d.C1, d.ld1, items, ws + w.Gx, ws + w.Gy);
+    }
     OBMAN_LAUNCH_CHECK();
   }
   if (d.bf16) return forward_bf16(p, d, w, out, ws, st);
@@ -2595,9 +2716,6 @@ int obman_pointgen_fwd(const obman_pointgen_params* p, float* out, float* ws, ob
   {  // h2 = W2 relu(bn1(h1)) + b2
     int rc, mrows = d.rb;
     if (f2) {
-      prescale_l1_kernel<<<obman_cdiv((long)(d.N + 1 + d.B) * d.ld1, 256), 256, 0, st>>>(ws + w.Gx, ws + w.Fx, p->bn_w[0], p->bn_b[0], d.N, d.B, d.ld1,
-                                                                                        d.C1, ws + w.Gy, ws + w.Fy);
-      OBMAN_LAUNCH_CHECK();
       F2GridFeatPre a{ws + w.Gy, ws + w.Fy, d.ld1, d.N};
       F2EpiStore<4> e4{ws + w.H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
       F2EpiStore<2> e2{ws + w.H2, p->b2, tr ? moments : nullptr, d.ld2, d.C2};
@@ -2655,8 +2773,9 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
   const int R = (int)d.R;
   ObmanProfScope prof(OBMAN_K_DECODER_BWD, st);
   int rc;
+  const float* Qsum = ws2 + v.Q;  // Q[n,c] = sum_b gy1 (or the single partial it equals, see launch_l1_reduce2)
   if (d.bf16) {
-    if ((rc = backward_bf16(p, d, w, v, g_out, ws, ws2, g, st))) return rc;
+    if ((rc = backward_bf16(p, d, w, v, g_out, ws, ws2, g, &Qsum, st))) return rc;
   } else {
     double* sums = reinterpret_cast<double*>(ws2 + v.sums);
     float *k1 = ws2 + v.k, *k2 = k1 + d.ld1, *k3 = k2 + d.ld1;
@@ -2780,8 +2899,7 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
                                                                                            ws2 + v.Qp);
       OBMAN_LAUNCH_CHECK();
     }
-    l1_reduce2_kernel<<<dim3(d.B + d.N, obman_cdiv(d.C1, 256)), 256, 0, st>>>(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, groups,
-                                                                                ws2 + v.P, ws2 + v.Q);
+    Qsum = launch_l1_reduce2(ws2 + v.Pp, ws2 + v.Qp, d.ld1, d.B, d.N, d.C1, prow, groups, ws2 + v.P, ws2 + v.Q, st);
     OBMAN_LAUNCH_CHECK();
     }
   }
@@ -2791,15 +2909,15 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     const int nseg = obman_cdiv(d.N, L1_SEG_ROWS);
     double* seg = reinterpret_cast<double*>(ws2 + v.seg);
     const dim3 grid(obman_cdiv(d.C1, 64), nseg);
-    l1_seg_stats_kernel<<<grid, 1024, 0, st>>>(ws2 + v.Q, ws + w.Gx, d.ld1, d.N, d.C1, seg);
+    l1_seg_stats_kernel<<<grid, 1024, 0, st>>>(Qsum, ws + w.Gx, d.ld1, d.N, d.C1, seg);
     OBMAN_LAUNCH_CHECK();
-    l1_seg_apply_kernel<<<grid, 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0], ws + w.rstd1,
+    l1_seg_apply_kernel<<<grid, 1024, 0, st>>>(ws2 + v.P, Qsum, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0], ws + w.rstd1,
                                                 p->grid, seg, nseg, g->bn_w[0], g->bn_b[0], g->b1, ws2 + v.dF, ws2 + v.segw);
     OBMAN_LAUNCH_CHECK();
     l1_seg_w_kernel<<<obman_cdiv(3 * d.C1, 256), 256, 0, st>>>(ws2 + v.segw, nseg, d.C1, g->w1);
     OBMAN_LAUNCH_CHECK();
   } else {
-    l1_finalize_kernel<<<obman_cdiv(d.C1, L1F_CH), 1024, 0, st>>>(ws2 + v.P, ws2 + v.Q, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
+    l1_finalize_kernel<<<obman_cdiv(d.C1, L1F_CH), 1024, 0, st>>>(ws2 + v.P, Qsum, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
                                                                ws + w.rstd1, p->grid, g->bn_w[0], g->bn_b[0], g->b1, g->w1, ws2 + v.dF, ws2 + v.dG);
     OBMAN_LAUNCH_CHECK();
   }

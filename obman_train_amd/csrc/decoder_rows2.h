@@ -69,7 +69,7 @@ struct R2Geo {
 };
 
 // Layer-1 activation from PRE-SCALED factors (h2 only):  a1 = relu(Gy[n,k] + Fy[b,k]),  Gy = gamma * Gx,  Fy = gamma * Fx + beta
-// (prescale_l1_kernel).  Two VALU operations per element instead of three and no per-channel constants; with geometry mode 2 the
+// (l1_fill_kernel / prep_kernel).  Two VALU operations per element instead of three and no per-channel constants; with geometry mode 2 the
 // block's 8 rows of Fy sit in LDS for the block's whole life, so a k-step fetches 32 bytes per lane instead of 64.
 struct BGridFeatPre {
   const float *Gy, *Fy;
@@ -717,7 +717,7 @@ struct EpiMaskB2 {  // C = bf16(acc * (y > 0)), y = s*H+t; column sums S1 = sum 
 // Leftover (side) columns of the last column group: one row per lane; their vertex / sample sums go through lane exchanges.
 struct EpiL1B2 {
   float *Pp, *Qp;  // [spb][B][ld], [nbg][N][ld]
-  // the PRE-SCALED layer-1 factors of the forward pass (prescale_l1_kernel): the mask is the forward's own relu argument,
+  // the PRE-SCALED layer-1 factors of the forward pass (l1_fill_kernel / prep_kernel): the mask is the forward's own relu argument,
   // Gy[n] + Fy[b] > 0.  A block's 64 samples and its columns are fixed for its whole life, so its Fy values sit in registers
   // (16 per lane) and a tile only fetches the 4 x 4 Gy values of its vertices: 16 load instructions per tile instead of 40.
   // Vertices beyond N read Gy's sentinel row (-3e38) and samples beyond B cache -3e38: no selects.

@@ -75,7 +75,7 @@ struct F2Geo {
 // row(): per tile and lane; load(): issues the loads of k-step s (nothing consumes a loaded value); fin(): 4 operand values
 // a[t] = A[row, 8 s + 4 half + t].  Per-channel constants live in LDS (kcs), staged once per block.  Columns >= K: every source
 // array holds zeros (or finite values under a relu with zero constants) in its pitch padding and the weight slice is zero there.
-struct F2GridFeatPre {  // a1 = relu(Gy[n] + Fy[b]): the pre-scaled layer-1 factors (prescale_l1_kernel); row N of Gy = -3e38
+struct F2GridFeatPre {  // a1 = relu(Gy[n] + Fy[b]): the pre-scaled layer-1 factors (l1_fill_kernel / prep_kernel); row N of Gy = -3e38
   const float *Gy, *Fy;
   int ld, N;
   struct Row { const float *g, *f; };

@@ -18,7 +18,7 @@ constexpr int T2_KT = 64;
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4v* lds_s16x4_ptr;
 
-struct T2Pre {  // a1[r, c .. c+7] = relu(Gy[n] + Fy[b])  (prescale_l1_kernel; Gy row N = -3e38)
+struct T2Pre {  // a1[r, c .. c+7] = relu(Gy[n] + Fy[b])  (l1_fill_kernel / prep_kernel; Gy row N = -3e38)
   const float *Gy, *Fy;
   int ld, N, B;
   struct Consts {};
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NTB) void tn2w_bf16_kernel(AOp aop, BOp bop, int M,
 }
 
 // gh2_inplace_kernel + the weight-gradient rows of the NS <= 3 channels of a1 the wide tile leaves out (m0 .. m0 + NS - 1):
-//   side[c][n] += bf16(a1[r, m0 + c]) * bf16(gh2[r, n])      a1 = relu(Gy[vertex of r] + Fy[sample of r])  (prescale_l1_kernel)
+//   side[c][n] += bf16(a1[r, m0 + c]) * bf16(gh2[r, n])      a1 = relu(Gy[vertex of r] + Fy[sample of r])  (l1_fill_kernel / prep_kernel)
 // from exactly the rounded operands the MFMA path would have consumed (products of two bf16 values are exact in fp32; fp32
 // accumulation).  A wave owns one row at a time (blockDim = (64 octet slots, 4 row slots)), so the three a1 values of a row are
 // wave-uniform: scalar loads.  grid-stride over row groups; one partial [NS][ld] per block, summed by reduce_tn_kernel.

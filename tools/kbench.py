@@ -227,13 +227,15 @@ def bench_decoder():
     cases = [(64, 1, "f32"), (64, 1, "bf16")]
     if os.environ.get("OBMAN_KBENCH_C3"):  # configs[2]: 25 patches
         cases += [(64, 25, "f32"), (64, 25, "bf16")]
-    if os.environ.get("OBMAN_KBENCH_DEC"):  # e.g. "bf16:25" = one case (for profiling)
-        mode, patches = os.environ["OBMAN_KBENCH_DEC"].split(":")
+    level = 3
+    if os.environ.get("OBMAN_KBENCH_DEC"):  # e.g. "bf16:25" = one case (for profiling); "bf16:25:4" = the 2562-point template of configs[4]
+        mode, patches, *lv = os.environ["OBMAN_KBENCH_DEC"].split(":")
         cases = [(64, int(patches), mode)]
+        level = int(lv[0]) if lv else 3
     for B, patches, mode in cases:
         dec = PointGenCon(bottleneck_size=515).cuda().train()
         dec.mfma_dtype = mode
-        grid = torch.from_numpy(multi_patch(3, patches)[0].astype(np.float32)).cuda()
+        grid = torch.from_numpy(multi_patch(level, patches)[0].astype(np.float32)).cuda()
         feats = torch.randn(B, 512, device="cuda").requires_grad_()
         t_f = kernel_us(lambda: ops.pointgen_decode(dec, feats, grid), 8, iters=10, warmup=3)
         if os.environ.get("OBMAN_GEMM_VARIANT"):
