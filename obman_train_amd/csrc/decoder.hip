@@ -1675,116 +1675,130 @@ __global__ __launch_bounds__(1024) void l1_finalize_kernel(const float* __restri
 }
 
 // The same computation for large templates (N > L1_SPLIT_N: 25 patches = 16 050 vertices), where nine 64-channel blocks
-// would crawl over N rows on nine CUs (0.86 ms at configs[2]).  Three launches over (row segment, 64 channels) blocks:
-//   l1_seg_stats : per segment  sum_n Gx*Q, sum_n Gx                               -> seg[segment][2][C]   (fp64)
-//   l1_seg_apply : every block re-derives the channel constants from seg[] (fixed order) and the B sample rows, then its
-//                  rows' dG . grid products                                        -> segw[segment][3][C]; segment 0 also
-//                  writes dF, g_b1, g_gamma1, g_beta1
-//   l1_seg_w     : gW1[:, 0:3] = sum_segment segw                                   (fixed order)
-constexpr int L1_SPLIT_N = 2048, L1_SEG_ROWS = 512;
-__global__ __launch_bounds__(1024) void l1_seg_stats_kernel(const float* __restrict__ Q, const float* __restrict__ Gx, int ld1, int N, int C1,
-                                                            double* __restrict__ seg) {
+// would crawl over N rows on nine CUs (0.86 ms at configs[2]).  dG[n,c] = k1 (Q - B k2 - k3 (B Gx + sum_b Fx)) is affine in the
+// per-channel constants, so gW1[c, 0:3] = sum_n dG[n,c] grid[n] follows from row sums that need NO constant:
+//   l1_seg_stats : ONE pass over Q and Gx, per (row segment, 64 channels) block, fp64:
+//                  sum_n Gx Q, sum_n Gx, sum_n Q grid_k, sum_n Gx grid_k (k < 3)   -> seg[segment][8][C]
+//   l1_seg_final : per channel, the segment sums in fixed order, the B sample rows, sum_n grid; constants, dF, g_b1, g_gamma1,
+//                  g_beta1 and gW1[:, 0:3] (combined in fp64)
+// (Until r06 a second pass re-read Q and Gx to form dG . grid with the constants in hand, and a third launch summed its
+// segment partials: 63 + 111 + 11 us at N = 64 050.)
+constexpr int L1_SPLIT_N = 2048, L1_SEG_ROWS = 512, L1_SEG_Q = 8;
+__global__ __launch_bounds__(1024) void l1_seg_stats_kernel(const float* __restrict__ Q, const float* __restrict__ Gx,
+                                                            const float* __restrict__ grid, int ld1, int N, int C1, double* __restrict__ seg) {
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-  const int n0 = blockIdx.y * L1_SEG_ROWS, n1 = min(N, n0 + L1_SEG_ROWS);
-  __shared__ double red[16][2][64];
-  double s2 = 0, sgx = 0;
-  if (c < C1)
-    for (int n = n0 + rg; n < n1; n += 16) {
-      const double gx = Gx[(size_t)n * ld1 + c];
-      s2 += gx * (double)Q[(size_t)n * ld1 + c];
-      sgx += gx;
-    }
-  red[rg][0][cl] = s2; red[rg][1][cl] = sgx;
-  __syncthreads();
-  if (rg == 0 && c < C1) {
-    s2 = sgx = 0;
-    for (int g = 0; g < 16; ++g) { s2 += red[g][0][cl]; sgx += red[g][1][cl]; }
-    seg[((size_t)blockIdx.y * 2) * C1 + c] = s2;
-    seg[((size_t)blockIdx.y * 2 + 1) * C1 + c] = sgx;
-  }
-}
-__global__ __launch_bounds__(1024) void l1_seg_apply_kernel(const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ Gx,
-                                                            const float* __restrict__ Fx, int ld1, int B, int N, int C1, int training,
-                                                            const float* __restrict__ gamma, const float* __restrict__ rstd1,
-                                                            const float* __restrict__ grid, const double* __restrict__ seg, int nseg,
-                                                            float* __restrict__ g_gamma, float* __restrict__ g_beta, float* __restrict__ g_b1,
-                                                            float* __restrict__ dF, float* __restrict__ segw) {
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-  const bool ok = c < C1;
   const int n0 = blockIdx.y * L1_SEG_ROWS, n1 = min(N, n0 + L1_SEG_ROWS);
   __shared__ double red[16][4][64];
-  __shared__ float redf[16][4][64];
-  // channel constants: the sample rows AND the segment partials are split over the 16 row groups and meet in LDS in group order
-  // (r06: every group used to walk all nseg partials itself - 126 dependent L2 round trips per block at N = 64 050, 386 us)
-  double s1 = 0, s2 = 0, sgx = 0, sfx = 0;
-  if (ok) {
-    for (int b = rg; b < B; b += 16) {
-      const double p = P[(size_t)b * ld1 + c], fx = Fx[(size_t)b * ld1 + c];
-      s1 += p; s2 += p * fx; sfx += fx;
-    }
-    for (int sg = rg; sg < nseg; sg += 16) { s2 += seg[((size_t)sg * 2) * C1 + c]; sgx += seg[((size_t)sg * 2 + 1) * C1 + c]; }
-  }
-  red[rg][0][cl] = s1; red[rg][1][cl] = s2; red[rg][2][cl] = sgx; red[rg][3][cl] = sfx;
-  __syncthreads();
-  s1 = s2 = sgx = sfx = 0;
-  for (int g = 0; g < 16; ++g) { s1 += red[g][0][cl]; s2 += red[g][1][cl]; sgx += red[g][2][cl]; sfx += red[g][3][cl]; }
-  const double R = (double)B * N;
-  const float k1 = ok ? gamma[c] * rstd1[c] : 0.f;
-  const float k2 = training ? (float)(s1 / R) : 0.f, k3 = training ? (float)(s2 / R) : 0.f;
-  float gb = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
-  if (ok) {
-    if (blockIdx.y == 0)
-      for (int b = rg; b < B; b += 16) {
-        const float v = k1 * (P[(size_t)b * ld1 + c] - N * k2 - k3 * ((float)sgx + N * Fx[(size_t)b * ld1 + c]));
-        dF[(size_t)b * ld1 + c] = v;
-        gb += v;
-      }
-    // four rows' operands requested before the first product (the row index is wave-uniform); the products keep their row order
-    for (int n = n0 + rg; n < n1; n += 64) {
-      float q[4], gx[4], g0[4], g1[4], g2[4];
+  double a[L1_SEG_Q];
+#pragma unroll
+  for (int q = 0; q < L1_SEG_Q; ++q) a[q] = 0;
+  if (c < C1)
+    for (int n = n0 + rg; n < n1; n += 64) {  // four rows' operands requested before the first sum; a lane's rows keep their order
+      float qv[4], gv[4], g0[4], g1[4], g2[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int nn = n + 16 * u < n1 ? n + 16 * u : n;
-        q[u] = Q[(size_t)nn * ld1 + c]; gx[u] = Gx[(size_t)nn * ld1 + c];
+        qv[u] = Q[(size_t)nn * ld1 + c]; gv[u] = Gx[(size_t)nn * ld1 + c];
         g0[u] = grid[nn * 3]; g1[u] = grid[nn * 3 + 1]; g2[u] = grid[nn * 3 + 2];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (n + 16 * u < n1) {
-          const float v = k1 * (q[u] - B * k2 - k3 * (B * gx[u] + (float)sfx));
-          w0 = __fmaf_rn(v, g0[u], w0); w1 = __fmaf_rn(v, g1[u], w1); w2 = __fmaf_rn(v, g2[u], w2);
+          const double q = qv[u], gx = gv[u];
+          a[0] += gx * q; a[1] += gx;
+          a[2] += q * (double)g0[u]; a[3] += q * (double)g1[u]; a[4] += q * (double)g2[u];
+          a[5] += gx * (double)g0[u]; a[6] += gx * (double)g1[u]; a[7] += gx * (double)g2[u];
         }
       }
     }
-  }
-  redf[rg][0][cl] = gb; redf[rg][1][cl] = w0; redf[rg][2][cl] = w1; redf[rg][3][cl] = w2;
-  __syncthreads();
-  if (rg == 0 && ok) {
-    gb = w0 = w1 = w2 = 0.f;
-    for (int g = 0; g < 16; ++g) { gb += redf[g][0][cl]; w0 += redf[g][1][cl]; w1 += redf[g][2][cl]; w2 += redf[g][3][cl]; }
-    float* dst = segw + (size_t)blockIdx.y * 3 * C1;
-    dst[c] = w0; dst[C1 + c] = w1; dst[2 * C1 + c] = w2;
-    if (blockIdx.y == 0) {
-      g_gamma[c] = (float)s2;
-      g_beta[c] = (float)s1;
-      g_b1[c] = gb;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {  // the 16 row groups meet in LDS in group order, four quantities at a time
+    if (half) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[rg][q][cl] = a[4 * half + q];
+    __syncthreads();
+    if (rg < 4 && c < C1) {
+      double t = 0;
+      for (int g = 0; g < 16; ++g) t += red[g][rg][cl];
+      seg[((size_t)blockIdx.y * L1_SEG_Q + 4 * half + rg) * C1 + c] = t;
     }
   }
 }
-__global__ __launch_bounds__(256) void l1_seg_w_kernel(const float* __restrict__ segw, int nseg, int C1, float* __restrict__ gW1) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // i = k * C1 + c, k < 3
-  if (i >= 3 * C1) return;
-  float s = 0.f;
-  for (int sg = 0; sg < nseg; sg += 8) {  // eight partials requested at once, added in segment order
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = sg + u < nseg ? segw[(size_t)(sg + u) * 3 * C1 + i] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (sg + u < nseg) s += v[u];
+__global__ __launch_bounds__(1024) void l1_seg_final_kernel(const float* __restrict__ P, const float* __restrict__ Fx, int ld1, int B, int N,
+                                                            int C1, int training, const float* __restrict__ gamma,
+                                                            const float* __restrict__ rstd1, const float* __restrict__ grid,
+                                                            const double* __restrict__ seg, int nseg, float* __restrict__ g_gamma,
+                                                            float* __restrict__ g_beta, float* __restrict__ g_b1, float* __restrict__ dF,
+                                                            float* __restrict__ gW1) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const bool ok = c < C1;
+  __shared__ double sgrid[16][3];
+  __shared__ float redf[16][64];
+  // sum_n grid[n] (channel independent): every thread a strided share, waves meet in LDS in wave order
+  {
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int n = threadIdx.x; n < N; n += 1024) { t0 += grid[n * 3]; t1 += grid[n * 3 + 1]; t2 += grid[n * 3 + 2]; }
+    t0 = wave_sum_f64(t0); t1 = wave_sum_f64(t1); t2 = wave_sum_f64(t2);
+    if (cl == 0) { sgrid[rg][0] = t0; sgrid[rg][1] = t1; sgrid[rg][2] = t2; }
   }
-  const int k = i / C1, c = i - k * C1;
-  gW1[(size_t)c * C1 + k] = s;
+  // channel sums, one quantity per row group (fixed order): groups 0 .. 7 the eight segment quantities, 8 .. 10 the sample sums
+  __shared__ double tot[11][64];
+  if (ok && rg < 11) {
+    double t = 0;
+    if (rg < L1_SEG_Q) {
+      for (int sg = 0; sg < nseg; sg += 8) {  // eight partials requested at once, added in segment order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sg + u < nseg ? seg[((size_t)(sg + u) * L1_SEG_Q + rg) * C1 + c] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+    } else {
+      for (int b = 0; b < B; b += 8) {
+        float pv[8], fv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bb = b + u < B ? b + u : b;
+          pv[u] = P[(size_t)bb * ld1 + c]; fv[u] = Fx[(size_t)bb * ld1 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (b + u < B) t += rg == 8 ? (double)pv[u] : (rg == 9 ? (double)pv[u] * (double)fv[u] : (double)fv[u]);
+      }
+    }
+    tot[rg][cl] = t;
+  }
+  __syncthreads();
+  double sg0 = 0, sg1 = 0, sg2 = 0;
+  for (int g = 0; g < 16; ++g) { sg0 += sgrid[g][0]; sg1 += sgrid[g][1]; sg2 += sgrid[g][2]; }
+  const double s1 = ok ? tot[8][cl] : 0.0, sfx = ok ? tot[10][cl] : 0.0;
+  const double s2 = ok ? tot[9][cl] + tot[0][cl] : 0.0;  // sum_b P Fx + sum_n Gx Q
+  const double sgx = ok ? tot[1][cl] : 0.0;
+  const double R = (double)B * N;
+  const float k1 = ok ? gamma[c] * rstd1[c] : 0.f;
+  const float k2 = training ? (float)(s1 / R) : 0.f, k3 = training ? (float)(s2 / R) : 0.f;
+  float gb = 0.f;
+  if (ok)
+    for (int b = rg; b < B; b += 16) {
+      const float v = k1 * (P[(size_t)b * ld1 + c] - N * k2 - k3 * ((float)sgx + N * Fx[(size_t)b * ld1 + c]));
+      dF[(size_t)b * ld1 + c] = v;
+      gb += v;
+    }
+  redf[rg][cl] = gb;
+  __syncthreads();
+  if (rg == 0 && ok) {
+    gb = 0.f;
+    for (int g = 0; g < 16; ++g) gb += redf[g][cl];
+    g_gamma[c] = (float)s2;
+    g_beta[c] = (float)s1;
+    g_b1[c] = gb;
+    // gW1[c,k] = k1 (sum_n Q grid_k - B k2 sum_n grid_k - k3 (B sum_n Gx grid_k + sum_b Fx sum_n grid_k))
+    const double sgk[3] = {sg0, sg1, sg2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      gW1[(size_t)c * C1 + k] =
+          (float)((double)k1 * (tot[2 + k][cl] - (double)B * k2 * sgk[k] - (double)k3 * ((double)B * tot[5 + k][cl] + sfx * sgk[k])));
+  }
 }
 
 // g_feat[b,k] = sum_c dF[b,c] * W1[c, 3+k]: 64 samples x 512 features, contraction 515 - far too skinny for the tiled
@@ -2006,8 +2020,8 @@ BwdWs bwd_ws(const Dims& d) {
   w.Ppre = take(d.bf16 && l1_geo(d).tiles > PRE_MIN_ROWS ? (long)pre_segments((long)d.B * d.ld1) * d.B * d.ld1 : 0);  // same rule as pre_reduce
   {  // large-template layer-1 finalize: per-segment partials
     const long nseg = d.N > L1_SPLIT_N ? (d.N + L1_SEG_ROWS - 1) / L1_SEG_ROWS : 0;
-    w.seg = take(nseg * 2 * d.C1 * 2);  // doubles
-    w.segw = take(nseg * 3 * d.C1);
+    w.seg = take(nseg * L1_SEG_Q * d.C1 * 2);  // doubles
+    w.segw = take(0);
   }
   {  // split-K partials: the largest of the three weight-gradient products
     auto need = [&](int M, int Nc, long R) {
@@ -2158,11 +2172,15 @@ bool l4_wide(const Dims& d) {
   return on != 0 && d.C3 == L4W_C && d.ld3 == L4W_C;
 }
 // rows per block of the layer-4 backward: L4_ROWS for the first-generation kernel (the workspace is sized for it); the wide kernel
-// takes >= 64 rows (one pass of its 16 row lanes x 4) and ~1024 blocks on large problems - fewer, larger partial rows
+// takes >= 64 rows and at most L4W_MAX_ROWS, in WHOLE rounds of the resident block slots (three 4-wave blocks per CU at its ~150
+// registers): 1 004 blocks of 1 024 rows on 768 slots were a full round plus a 31 % one (r06: 85 -> see profiles/r06_kernels.md)
+int device_cus();
 int l4_rows(const Dims& d) {
   if (!l4_wide(d)) return L4_ROWS;
-  long rows = (d.R + 1023) / 1024;
-  rows = (rows + 63) / 64 * 64;
+  const long slots = 3L * device_cus();
+  const long rounds = (d.R + slots * L4W_MAX_ROWS - 1) / (slots * L4W_MAX_ROWS);
+  long rows = (d.R + slots * rounds - 1) / (slots * rounds);
+  rows = (rows + 31) / 32 * 32;
   return (int)(rows < 64 ? 64 : (rows > L4W_MAX_ROWS ? L4W_MAX_ROWS : rows));
 }
 // ---- second-generation rows GEMMs (decoder_rows2.h): persistent blocks, weights stationary in LDS
@@ -2909,12 +2927,10 @@ int obman_pointgen_bwd(const obman_pointgen_params* p, const float* g_out, const
     const int nseg = obman_cdiv(d.N, L1_SEG_ROWS);
     double* seg = reinterpret_cast<double*>(ws2 + v.seg);
     const dim3 grid(obman_cdiv(d.C1, 64), nseg);
-    l1_seg_stats_kernel<<<grid, 1024, 0, st>>>(Qsum, ws + w.Gx, d.ld1, d.N, d.C1, seg);
+    l1_seg_stats_kernel<<<grid, 1024, 0, st>>>(Qsum, ws + w.Gx, p->grid, d.ld1, d.N, d.C1, seg);
     OBMAN_LAUNCH_CHECK();
-    l1_seg_apply_kernel<<<grid, 1024, 0, st>>>(ws2 + v.P, Qsum, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0], ws + w.rstd1,
-                                                p->grid, seg, nseg, g->bn_w[0], g->bn_b[0], g->b1, ws2 + v.dF, ws2 + v.segw);
-    OBMAN_LAUNCH_CHECK();
-    l1_seg_w_kernel<<<obman_cdiv(3 * d.C1, 256), 256, 0, st>>>(ws2 + v.segw, nseg, d.C1, g->w1);
+    l1_seg_final_kernel<<<obman_cdiv(d.C1, 64), 1024, 0, st>>>(ws2 + v.P, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0], ws + w.rstd1, p->grid, seg,
+                                                                nseg, g->bn_w[0], g->bn_b[0], g->b1, ws2 + v.dF, g->w1);
     OBMAN_LAUNCH_CHECK();
   } else {
     l1_finalize_kernel<<<obman_cdiv(d.C1, L1F_CH), 1024, 0, st>>>(ws2 + v.P, Qsum, ws + w.Gx, ws + w.Fx, d.ld1, d.B, d.N, d.C1, tr, p->bn_w[0],
