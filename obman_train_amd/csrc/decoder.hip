@@ -2250,6 +2250,7 @@ int launch_rows2(const AOp& a, const bfraw* Wb, int Kp, int Nc, const R2Geo& geo
         case 3: go(rows2_bf16_kernel<AOp, Epi, 3>); break;
         case 4: go(rows2_bf16_kernel<AOp, Epi, 4>); break;
         case 6: go(rows2_bf16_kernel<AOp, Epi, 6>); break;
+        case 9: go(rows2_bf16_kernel<AOp, Epi, 9>); break;
         case 8: {
           go(rows2_bf16_kernel<AOp, Epi, 8>);
           (void)hipStreamSynchronize(st);

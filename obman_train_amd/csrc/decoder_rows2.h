@@ -354,8 +354,13 @@ struct R2Fin<BGradH3> {
     unpack8(q.h, h);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+#ifdef OBMAN_ABL_GH3CONST  // measurement only (wrong results): ONE channel's constants for all eight elements - an eighth of the LDS reads
+      const float4 c0 = *reinterpret_cast<const float4*>(kcs + (size_t)k * 8);
+      const float4 c1 = *reinterpret_cast<const float4*>(kcs + (size_t)k * 8 + 4);
+#else
       const float4 c0 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8);      // s, t, kb, kc
       const float4 c1 = *reinterpret_cast<const float4*>(kcs + (size_t)(k + j) * 8 + 4);  // ka*w0, ka*w1, ka*w2
+#endif
       // select instead of a divergent skip: the dot product is three FMAs
       const float d = __fmaf_rn(w.g2, c1.z, __fmaf_rn(w.g1, c1.y, w.g0 * c1.x));
       const float gy = __fmaf_rn(c0.x, h[j], c0.y) > 0.f ? d : 0.f;
@@ -909,6 +914,12 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
       if constexpr (R2SelfMask<AOp>::value) roff = src.off_masked(aop, r, h, ok);
       else roff = src.off(aop, r, b, n, h);
     }
+#ifdef OBMAN_ABLATION
+    if constexpr (ABL == 9 && std::is_same<AOp, BPlain>::value) {
+      // measurement only (wrong results): the A operand AS IF stored fragment-major - a wave-level load = one contiguous 1 KB
+      roff.o = (unsigned)(((size_t)(bg * geo.nvt + vt) * R2_WAVES + wave) * (size_t)nks * 1024u) + (unsigned)lane * 16u;
+    }
+#endif
     f32x16 acc[R2_NT];
 #pragma unroll
     for (int j = 0; j < R2_NT; ++j)
@@ -927,7 +938,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
     constexpr int DQ = R2Depth<AOp>::value;
     typename AOp::Raw q[DQ];
 #pragma unroll
-    for (int u = 0; u < DQ; ++u) src.load(q[u], roff, u);
+    for (int u = 0; u < DQ; ++u) src.load(q[u], roff, ABL == 9 ? u * 32 : u);
     auto step = [&](typename AOp::Raw& qs, int s) {
       // the four weight fragments of this k-step first: the transform below covers their LDS latency (left to itself the
       // compiler sank each read next to its MFMA: read -> wait -> MFMA, four exposed LDS round trips per k-step)
@@ -945,7 +956,7 @@ __global__ __launch_bounds__(R2_THREADS) void rows2_bf16_kernel(AOp aop, const b
         R2Fin<AOp>::fin(aop, row, kcs, Kp, kf, qs, o0);
         a0 = pack8(o0);
       }
-      if constexpr (ABL != 1) src.load(qs, roff, s + DQ);
+      if constexpr (ABL != 1) src.load(qs, roff, ABL == 9 ? (s + DQ) * 32 : s + DQ);
       if constexpr (!R2Sentinel<AOp>::value && !R2SelfMask<AOp>::value) { if (!ok) a0 = u32x4{0u, 0u, 0u, 0u}; }
       const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
       if constexpr (ABL == 4) {
