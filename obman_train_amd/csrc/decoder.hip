@@ -1569,7 +1569,14 @@ __global__ __launch_bounds__(256) void l1_reduce2_kernel(const float* __restrict
   if (c >= C1) return;
   float s = 0.f;
   if (row < B) {
-    for (int t = 0; t < tiles; ++t) s += Pp[((size_t)t * B + row) * ld1 + c];
+    for (int t = 0; t < tiles; t += 8) {  // eight partials requested at once, added in tile order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = t + u < tiles ? Pp[((size_t)(t + u) * B + row) * ld1 + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (t + u < tiles) s += v[u];
+    }
     P[(size_t)row * ld1 + c] = s;
   } else {
     const int n = row - B;

@@ -483,30 +483,47 @@ __global__ __launch_bounds__(256) void gh2_inplace_side_kernel(bfraw* __restrict
   long r = (long)blockIdx.x * 4 + ry;
   int bs = (int)(r / N), n = (int)(r - (long)bs * N);
   const int sb = stride / N, sn = stride - sb * N;
-  for (; r < R; r += stride, bs += sb, n += sn) {
+  // TWO rows of the wave (r and r + stride) per step, both rows' operands requested before the first is used (r06: one row per step
+  // left a wave with 1 KB in flight - 34 of its 64 lanes cover a 272-column row - and the pass at 4.9 TB/s); the side sums take the
+  // rows in the same order as before
+  for (; r < R; r += 2 * stride) {
     if (n >= N) { n -= N; ++bs; }
-    float a1[NS];
+    int bs1 = bs + sb, n1 = n + sn;
+    if (n1 >= N) { n1 -= N; ++bs1; }
+    const bool two = r + stride < R;
+    const long r1 = two ? r + stride : r;
+    if (!two) { bs1 = bs; n1 = n; }
+    float a1[2][NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float y = Gy[(size_t)n * ld1 + m0 + s] + Fy[(size_t)bs * ld1 + m0 + s];
-      a1[s] = bf_lo(relu_bf16x2(pack_bf16(y, 0.f)));
+      const float y0 = Gy[(size_t)n * ld1 + m0 + s] + Fy[(size_t)bs * ld1 + m0 + s];
+      const float y1 = Gy[(size_t)n1 * ld1 + m0 + s] + Fy[(size_t)bs1 * ld1 + m0 + s];
+      a1[0][s] = bf_lo(relu_bf16x2(pack_bf16(y0, 0.f)));
+      a1[1][s] = bf_lo(relu_bf16x2(pack_bf16(y1, 0.f)));
     }
     if (live) {
-      const size_t o = (size_t)r * ld + c0;
-      float gy[8], h[8], y[8];
-      unpack8(*reinterpret_cast<const u32x4*>(GY + o), gy);
-      unpack8(*reinterpret_cast<const u32x4*>(H + o), h);
+      const size_t o0 = (size_t)r * ld + c0, o1 = (size_t)r1 * ld + c0;
+      const u32x4 g0 = *reinterpret_cast<const u32x4*>(GY + o0), h0 = *reinterpret_cast<const u32x4*>(H + o0);
+      const u32x4 g1 = *reinterpret_cast<const u32x4*>(GY + o1), h1 = *reinterpret_cast<const u32x4*>(H + o1);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = __fmaf_rn(a[e], gy[e], __fmaf_rn(b[e], h[e], c[e]));
-      const u32x4 pk = pack8(y);
-      *reinterpret_cast<u32x4*>(GY + o) = pk;
-      float yr[8];
-      unpack8(pk, yr);  // the STORED (rounded) gh2, as dW2's B operand reads it
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        float gy[8], h[8], y[8];
+        unpack8(u ? g1 : g0, gy);
+        unpack8(u ? h1 : h0, h);
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+        for (int e = 0; e < 8; ++e) y[e] = __fmaf_rn(a[e], gy[e], __fmaf_rn(b[e], h[e], c[e]));
+        const u32x4 pk = pack8(y);
+        *reinterpret_cast<u32x4*>(GY + (u ? o1 : o0)) = pk;
+        float yr[8];
+        unpack8(pk, yr);  // the STORED (rounded) gh2, as dW2's B operand reads it
 #pragma unroll
-        for (int e = 0; e < 8; ++e) side[s][e] = __fmaf_rn(a1[s], yr[e], side[s][e]);
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) side[s][e] = __fmaf_rn(a1[u][s], yr[e], side[s][e]);
+      }
     }
+    bs = bs1 + sb; n = n1 + sn;
   }
   if (ry > 0) {
 #pragma unroll
