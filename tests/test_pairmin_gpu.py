@@ -149,7 +149,7 @@ def test_chamfer_single_launch_means_and_self_cleaning_sync_buffer():
         np.testing.assert_allclose(l2.cpu().numpy(), o2.numpy(), rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,nx,ny", [(2, 16050, 600), (3, 8192, 1), (2, 20000, 2048), (1, 600, 9000), (2, 64050, 600), (5, 8200, 33), (2, 778, 16050)])
+@pytest.mark.parametrize("B,nx,ny", [(2, 16050, 600), (3, 8192, 1), (2, 20000, 2048), (1, 600, 9000), (2, 64050, 600), (5, 8200, 33), (2, 778, 16050), (1, 778, 64050)])
 def test_fused_sweep_equals_the_two_independent_sweeps(B, nx, ny, monkeypatch):
     """Round 6 (VERDICT r05 task 4): with one side >= 8192 points and the other a single LDS tile, a bidirectional call evaluates
     every pair ONCE (csrc/pairmin.hip, pairmin_fwd_kernel<10, true> + pairmin_resolve_kernel), and a call that wants only the
